@@ -1,0 +1,345 @@
+"""Generate tests/golden/*.pt by running the REFERENCE (imported from /root/reference).
+
+Run in the build container only:   python oracle/make_golden.py
+The reference never travels to the GPU box; only the small tensors written here do.
+Each fixture stores the inputs (or the seeds that regenerate them), the RoPE offsets the
+reference drew, and the reference's outputs / intermediates / gradients.  The script also
+asserts, on the spot, that the oracle restatement (oracle/dit_oracle.py) reproduces the
+reference in fp32 -- `tests/test_oracle_golden.py` re-checks that from the fixtures alone.
+
+Fixtures:
+  g1_tiny_hd64.pt / g1_tiny_hd72.pt  op-level intermediates + all grads, DiT-tiny, fp32 & bf16
+  g2_dit_s_c1.pt                      DiT-S at BASELINE config-1 shape: output, loss, grad digests
+  g3_harness.pt                       train.py::forward: t, noise, z_t, v, loss
+  g4_optim.pt                         get_mup_setup tables (DiT-S, DiT-XL), 2 AdamW steps, LR schedule
+"""
+import importlib.machinery
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
+
+# the reference's train.py imports wandb (not installed): stub it with a ModuleSpec
+_w = types.ModuleType("wandb")
+_w.__spec__ = importlib.machinery.ModuleSpec("wandb", None)
+sys.modules["wandb"] = _w
+
+import model as ref_model  # noqa: E402  (reference)
+from oracle import dit_oracle as O  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def cfg_kwargs(cfg: O.DiTConfig):
+    return dict(in_channels=cfg.in_channels, patch_size=cfg.patch_size,
+                time_patch_size=cfg.time_patch_size, hidden_size=cfg.hidden_size,
+                depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                cross_attn_input_size=cfg.cross_attn_input_size, residual_v=cfg.residual_v,
+                train_bias_and_rms=cfg.train_bias_and_rms, use_rope=True)
+
+
+def build_ref(cfg: O.DiTConfig, P):
+    m = ref_model.DiT(**cfg_kwargs(cfg))
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not unexpected, unexpected
+    assert all("rope" in k for k in missing), missing
+    return m
+
+
+def run_ref(m, x, ctx, t, seed_rope):
+    """Forward with the global RNG seeded right before the call; returns (out, (st,sh,sw))."""
+    torch.manual_seed(seed_rope)
+    thw = (x.shape[2] // m.time_patch_size, x.shape[3] // m.patch_size, x.shape[4] // m.patch_size)
+    start = O.draw_rope_offsets(thw)  # consumes exactly the reference's three draws
+    torch.manual_seed(seed_rope)
+    out = m(x, ctx, t)
+    return out, start
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+
+
+def capture_hooks(m, store):
+    hs = []
+
+    def hook(name):
+        def f(mod, inp, out):
+            store[name] = (out[0] if isinstance(out, tuple) else out).detach().float().clone()
+        return f
+
+    for i, blk in enumerate(m.blocks):
+        hs.append(blk.register_forward_hook(hook(f"blocks.{i}.x_out")))
+        hs.append(blk.qkv.register_forward_hook(hook(f"blocks.{i}.qkv")))
+        hs.append(blk.attn_proj.register_forward_hook(hook(f"blocks.{i}.y_sa")))
+        hs.append(blk.mlp.register_forward_hook(hook(f"blocks.{i}.y_mlp")))
+        hs.append(blk.adaLN_modulation.register_forward_hook(hook(f"blocks.{i}.mod")))
+        if blk.cross_proj is not None:
+            hs.append(blk.cross_proj.register_forward_hook(hook(f"blocks.{i}.y_ca")))
+    hs.append(m.time_embed.register_forward_hook(hook("t_emb")))
+    hs.append(m.patch_embed.register_forward_hook(hook("patch_tokens")))
+    hs.append(m.final_proj.register_forward_hook(hook("final_tokens")))
+    return hs
+
+
+def digest(t: torch.Tensor, n=4096):
+    """norm + a strided subsample (keeps the fixture small)."""
+    f = t.detach().float().flatten()
+    step = max(1, f.numel() // n)
+    return {"norm": f.norm().item(), "sum": f.double().sum().item(), "step": step,
+            "sample": f[::step].clone(), "numel": f.numel()}
+
+
+def g1(name, cfg: O.DiTConfig, seed):
+    g = torch.Generator().manual_seed(seed)
+    P = O.init_params(cfg, seed=seed, randomize_zero_init=True, init_std_factor=1.0)
+    # make lambda != 0.5 and norm weights != 1 so they are exercised
+    tweaks = {}
+    for k in P:
+        if k.endswith("lambda_param"):
+            P[k] = tweaks[k] = torch.tensor([0.35]) + 0.1 * torch.rand(1, generator=g)
+        if "norm" in k:
+            P[k] = tweaks[k] = 1 + 0.1 * torch.randn(P[k].shape, generator=g)
+    B, Lc = 2, 8
+    x = torch.randn(B, cfg.in_channels, 4, 8, 8, generator=g)
+    ctx = torch.randn(B, Lc, cfg.cross_attn_input_size, generator=g)
+    t = torch.rand(B, generator=g)
+    dout = torch.randn(B, cfg.in_channels, 4, 8, 8, generator=g)
+    fx = {"cfg": cfg.__dict__.copy(), "seed": seed, "x": x, "context": ctx, "t": t, "dout": dout,
+          "param_init": {"seed": seed, "randomize_zero_init": True, "init_std_factor": 1.0},
+          "param_tweaks": tweaks, "param_digest": {k: digest(v, 64) for k, v in P.items()}}
+    for dt, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        m = build_ref(cfg, P).to(dt)
+        store = {}
+        hs = capture_hooks(m, store)
+        out, start = run_ref(m, x.to(dt), ctx.to(dt), t.to(dt), seed_rope=100 + seed)
+        for h in hs:
+            h.remove()
+        (out.float() * dout).sum().backward()
+        grads = {k: p.grad.detach().float().clone() for k, p in m.named_parameters()
+                 if p.grad is not None}  # blocks.0.lambda_param is unused (v_0 is None there)
+        fx[tag] = {"out": out.detach().float().clone(), "inter": store,
+                   "grads": {k: (v if v.numel() <= 20000 else digest(v)) for k, v in grads.items()}}
+        fx["rope_start"] = start
+        if dt == torch.float32:
+            # oracle check
+            Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+            cap = {}
+            o = O.dit_forward(Pg, cfg, x, ctx, t, start, cap)
+            (o * dout).sum().backward()
+            e = rel(o, out)
+            assert e < 2e-5, e
+            for k in grads:
+                eg = rel(Pg[k].grad, grads[k])
+                assert eg < 2e-4, (k, eg)
+            for i in range(cfg.depth):
+                assert rel(cap[f"blocks.{i}.x_out"], store[f"blocks.{i}.x_out"]) < 2e-5
+            print(f"[{name}] oracle fp32 vs reference: out rel {e:.2e}; grads OK; rope_start {start}")
+    torch.save(fx, os.path.join(GOLD, name + ".pt"))
+
+
+def g2():
+    cfg = O.DiTConfig(in_channels=16, patch_size=2, time_patch_size=2, hidden_size=384, depth=12,
+                      num_heads=6, mlp_ratio=4.0, cross_attn_input_size=4096, residual_v=True,
+                      train_bias_and_rms=False)
+    seed = 7
+    P = O.init_params(cfg, seed=seed, randomize_zero_init=True, init_std_factor=0.1)
+    g = torch.Generator().manual_seed(1234)
+    B = 4
+    x = torch.randn(B, 16, 8, 16, 16, generator=g)
+    ctx = torch.randn(B, 512, 4096, generator=g)
+    t = O.time_shift(torch.randn(B, generator=g))
+    v = torch.randn(B, 16, 8, 16, 16, generator=g)
+    m = build_ref(cfg, P)
+    out, start = run_ref(m, x, ctx, t, seed_rope=4321)
+    loss = (v - out).pow(2).mean(dim=(1, 2, 3, 4)).mean()
+    loss.backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    # oracle check
+    Pg = {k: w.clone().requires_grad_(True) for k, w in P.items()}
+    o = O.dit_forward(Pg, cfg, x, ctx, t, start)
+    lo, _ = O.flow_loss(v, o)
+    lo.backward()
+    assert rel(o, out) < 5e-5, rel(o, out)
+    assert abs(lo.item() - loss.item()) / loss.item() < 1e-5
+    worst = max(rel(Pg[k].grad, grads[k]) for k in grads)
+    assert worst < 1e-3, worst
+    print(f"[g2] oracle fp32 vs reference: out rel {rel(o, out):.2e} loss {lo.item():.6f} "
+          f"vs {loss.item():.6f}; worst grad rel {worst:.2e}")
+    fx = {"cfg": cfg.__dict__.copy(), "param_seed": seed, "input_seed": 1234, "rope_start": start,
+          "x_digest": digest(x), "ctx_digest": digest(ctx), "t": t, "out": out.detach().clone(),
+          "loss": loss.item(),
+          "grad_digest": {k: digest(gv) for k, gv in grads.items()},
+          "grad_full": {k: grads[k].detach().clone() for k in
+                        ("final_proj.weight", "blocks.1.lambda_param", "blocks.5.lambda_param",
+                         "register_tokens", "blocks.0.mlp.2.bias", "final_proj.bias")}}
+    torch.save(fx, os.path.join(GOLD, "g2_dit_s_c1.pt"))
+
+
+def g3():
+    import train as ref_train  # reference harness
+
+    cfg = O.DiTConfig(in_channels=16, patch_size=2, time_patch_size=2, hidden_size=128, depth=2,
+                      num_heads=2, mlp_ratio=4.0, cross_attn_input_size=64, residual_v=True,
+                      train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=3, randomize_zero_init=True, init_std_factor=1.0)
+    m = build_ref(cfg, P).to(torch.bfloat16)
+    B, Lc = 3, 512
+    gi = torch.Generator().manual_seed(99)
+    latent = torch.randn(B, 16, 4, 8, 8, generator=gi)
+    ctx = torch.randn(B, Lc, 64, generator=gi).to(torch.bfloat16)
+
+    class Tok:
+        def __call__(self, prompt, **kw):
+            return types.SimpleNamespace(input_ids=torch.zeros(len(prompt), Lc, dtype=torch.long))
+
+    class Enc:
+        dtype = torch.bfloat16
+
+        def __call__(self, ids, **kw):
+            return types.SimpleNamespace(hidden_states=[ctx])
+
+    cap = {}
+    real_call = m.forward
+
+    def spy(z_t, c, t):
+        cap["z_t"], cap["context"], cap["t"] = z_t.clone(), c.clone(), t.clone()
+        o = real_call(z_t, c, t)
+        cap["out"] = o.detach().clone()
+        return o
+
+    m.forward = spy
+    gen = torch.Generator().manual_seed(2024)
+    torch.manual_seed(555)  # global RNG: do_zero_out draw then the 3 rope draws
+    zero_mask = torch.rand(B) < 0.01
+    thw = (2, 4, 4)
+    start = O.draw_rope_offsets(thw)
+    torch.manual_seed(555)
+    total, diff = ref_train.forward(m, {"latent": latent, "prompt": ["a"] * B}, Enc(), Tok(), "cpu",
+                                    1, False, generator=gen, return_index=-1)
+    # regenerate the generator draws the way the harness does
+    gen2 = torch.Generator().manual_seed(2024)
+    z = torch.randn(B, dtype=torch.bfloat16, generator=gen2)
+    noise = torch.randn(latent.shape, dtype=torch.bfloat16, generator=gen2)
+    Pb = {k: v.to(torch.bfloat16) for k, v in P.items()}
+    c2 = {}
+    lo = O.train_forward(Pb, cfg, latent, ctx, z, noise, start, cap=c2)
+    assert torch.equal(c2["t"], cap["t"]), "time-shift mismatch"
+    assert torch.equal(c2["z_t"], cap["z_t"]), "z_t mismatch"
+    print(f"[g3] harness: loss ref {total.item():.6f} oracle(bf16) {lo.item():.6f} "
+          f"out rel {rel(c2['output'], cap['out']):.2e}")
+    assert rel(c2["output"], cap["out"]) < 3e-2
+    fx = {"cfg": cfg.__dict__.copy(), "param_seed": 3, "latent": latent, "context": ctx,
+          "gen_seed": 2024, "global_seed": 555, "zero_mask": zero_mask, "rope_start": start,
+          "z": z, "noise": noise, "t": cap["t"], "z_t": cap["z_t"], "out": cap["out"],
+          "loss": total.item()}
+    torch.save(fx, os.path.join(GOLD, "g3_harness.pt"))
+
+
+def g4():
+    from transformers import get_cosine_schedule_with_warmup, get_linear_schedule_with_warmup
+
+    fx = {}
+    consts = ["patch_proj", "context_kv", "positional_embedding"]
+    for tag, kw in (("dit_s", dict(hidden_size=384, depth=12, num_heads=6)),
+                    ("dit_xl", dict(hidden_size=1152, depth=28, num_heads=16))):
+        cfg = O.DiTConfig(in_channels=16, cross_attn_input_size=4096, residual_v=True,
+                          train_bias_and_rms=False, **kw)
+        with torch.device("meta"):
+            m = ref_model.DiT(**cfg_kwargs(cfg))
+        groups, settings = m.get_mup_setup(1e-4, 0.1, consts)
+        mine = O.mup_settings(O.param_shapes(cfg), 1e-4, 0.1, consts)
+        assert list(mine.keys()) == list(settings.keys())
+        for k in settings:
+            assert mine[k]["lr"] == settings[k]["lr"] and mine[k]["wd"] == settings[k]["wd"], k
+        fx[tag] = {"settings": {k: {"lr": v["lr"], "wd": v["wd"], "shape": tuple(v["shape"])}
+                                for k, v in settings.items()},
+                   "n_groups": len(groups)}
+        print(f"[g4] {tag}: {len(settings)} params, {len(groups)} groups; oracle table identical")
+    # with biases / norms trainable too
+    cfg = O.DiTConfig(in_channels=16, hidden_size=144, depth=2, num_heads=2, cross_attn_input_size=64,
+                      residual_v=True, train_bias_and_rms=True)
+    m = ref_model.DiT(**cfg_kwargs(cfg))
+    groups, settings = m.get_mup_setup(3e-4, 0.1, consts)
+    mine = O.mup_settings(O.param_shapes(cfg), 3e-4, 0.1, consts)
+    assert {k: (v["lr"], v["wd"]) for k, v in settings.items()} == \
+        {k: (v["lr"], v["wd"]) for k, v in mine.items()}
+    fx["tiny_bias"] = {"settings": {k: {"lr": v["lr"], "wd": v["wd"], "shape": tuple(v["shape"])}
+                                    for k, v in settings.items()}, "n_groups": len(groups)}
+    # two AdamW steps with synthetic grads
+    g = torch.Generator().manual_seed(11)
+    P0 = {k: p.detach().clone() for k, p in m.named_parameters()}
+    G = [{k: torch.randn(p.shape, generator=g) * 0.01 for k, p in P0.items()} for _ in range(2)]
+    opt = torch.optim.AdamW(groups, betas=(0.95, 0.99))
+    sched = get_cosine_schedule_with_warmup(opt, 20, 1000)
+    lrs = []
+    for s in range(2):
+        for k, p in m.named_parameters():
+            p.grad = G[s][k].clone()
+        lrs.append([gr["lr"] for gr in opt.param_groups])
+        opt.step()
+        sched.step()
+    P2 = {k: p.detach().clone() for k, p in m.named_parameters()}
+    # oracle replay
+    Pm = {k: v.clone() for k, v in P0.items()}
+    M = {k: torch.zeros_like(v) for k, v in P0.items()}
+    V = {k: torch.zeros_like(v) for k, v in P0.items()}
+    for s in range(2):
+        mult = O.lr_lambda(s, "cosine", 20, 1000)
+        for k in Pm:
+            O.adamw_step(Pm[k], G[s][k], M[k], V[k], s + 1, mine[k]["lr"] * mult, mine[k]["wd"])
+    worst = max(rel(Pm[k], P2[k]) for k in Pm)
+    assert worst < 1e-6, worst
+    print(f"[g4] 2 AdamW steps: oracle vs torch.optim.AdamW worst rel {worst:.2e}")
+    keep = ["blocks.0.attn_proj.weight", "blocks.1.lambda_param", "blocks.0.mlp.0.bias",
+            "final_proj.weight", "time_embed.2.bias", "blocks.1.norm2.weight",
+            "patch_embed.patch_proj.weight"]
+    fx["adamw"] = {"cfg": cfg.__dict__.copy(), "lr": 3e-4, "wd": 0.1, "p0": {k: P0[k] for k in keep},
+                   "grads": [{k: G[s][k] for k in keep} for s in range(2)],
+                   "p2": {k: P2[k] for k in keep}}
+    # LR schedules
+    dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sc = get_cosine_schedule_with_warmup(dummy, 20, 200)
+    cos_vals = []
+    for s in range(220):
+        cos_vals.append(sc.get_last_lr()[0])
+        dummy.step()
+        sc.step()
+    dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sl = get_linear_schedule_with_warmup(dummy, 20, 200)
+    lin_vals = []
+    for s in range(220):
+        lin_vals.append(sl.get_last_lr()[0])
+        dummy.step()
+        sl.step()
+    for s in range(220):
+        assert abs(O.lr_lambda(s, "cosine", 20, 200) - cos_vals[s]) < 1e-12
+        assert abs(O.lr_lambda(s, "linear", 20, 200) - lin_vals[s]) < 1e-12
+    fx["sched"] = {"cosine": cos_vals, "linear": lin_vals, "warmup": 20, "total": 200}
+    torch.save(fx, os.path.join(GOLD, "g4_optim.pt"))
+
+
+if __name__ == "__main__":
+    with torch.no_grad():
+        pass
+    g1("g1_tiny_hd64", O.DiTConfig(in_channels=16, hidden_size=128, depth=2, num_heads=2,
+                                   cross_attn_input_size=64, residual_v=True,
+                                   train_bias_and_rms=False), seed=1)
+    g1("g1_tiny_hd72", O.DiTConfig(in_channels=16, hidden_size=144, depth=2, num_heads=2,
+                                   cross_attn_input_size=64, residual_v=True,
+                                   train_bias_and_rms=True), seed=2)
+    g2()
+    g3()
+    g4()
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
