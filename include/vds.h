@@ -1,0 +1,206 @@
+/* vds.h -- C ABI of the MI355X-native video-DiT train-step kernels (libvds_hip.so).
+ *
+ * The reference (fal-ai-community/video-diffusion-speedrun) has no FFI layer: its operator
+ * surface is the set of torch call sites inside model.py / train.py.
+ * Each entry point below replaces one (group of) call site(s), cited as file:line of the
+ * reference.  Conventions:
+ *   - plain pointers + sizes only, no torch types; all pointers are DEVICE pointers;
+ *   - the caller owns/allocates every buffer (inputs, outputs, workspace); kernels never
+ *     allocate, free or synchronise;
+ *   - every call is asynchronous on the hipStream_t passed last (void* here so that the
+ *     header is usable from plain C / ctypes / cgo without the HIP headers);
+ *   - return 0 on success, negative VDS_ERR_* on bad arguments / unsupported shapes /
+ *     launch failure (the Python host turns that into RuntimeError, matching the
+ *     reference's exception convention);
+ *   - bf16 tensors are raw uint16 bit patterns; "f32" are IEEE floats;
+ *   - thread-compatible: one caller thread per process (one process per GPU).
+ */
+#ifndef VDS_H
+#define VDS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDS_OK 0
+#define VDS_ERR_ARG (-1)
+#define VDS_ERR_UNSUPPORTED (-2)
+#define VDS_ERR_LAUNCH (-3)
+
+typedef void* vds_stream_t; /* hipStream_t */
+
+int vds_version(void);
+const char* vds_last_error(void);
+
+/* ------------------------------------------------------------------ GEMM (MFMA) ------
+ * C[M,N] = sum_k opA[m,k] * opB[k,n], bf16 operands, fp32 accumulate.
+ *   layout VDS_NT: A[M,K] (lda), B[N,K] (ldb)   nn.Linear forward  y = x W^T
+ *                  (model.py:125,138,147,150,159,84,86,184,390,90,319,321)
+ *   layout VDS_NN: A[M,K] (lda), B[K,N] (ldb)   its input gradient  dx = dy W
+ *   layout VDS_TN: A[K,M] (lda), B[K,N] (ldb)   its weight gradient dW = dy^T x  (fp32 out)
+ * epilogues fuse the elementwise work the reference runs as separate kernels:
+ *   VDS_EPI_STORE      C = bf16(acc + bias[n])
+ *   VDS_EPI_BIAS_GELU  C = bf16(pre), C2 = bf16(gelu_erf(pre)), pre = acc + bias[n]  (model.py:84-85)
+ *   VDS_EPI_GATE_RES   C = bf16(y), C2 = bf16(aux[m,n] + y*gate[m/rows_per_batch, n]),
+ *                      y = acc + bias[n]                         (model.py:138-139,159-160,165)
+ *   VDS_EPI_DGELU      C = bf16(acc * gelu'(aux[m,n]))           (backward of model.py:85)
+ *   VDS_EPI_F32        C(f32) = acc, or atomically += when split_k > 1 (C pre-zeroed)
+ * Requirements: K % 64 == 0 for the k-contiguous operands (NT: A,B; NN: A); N % 8 == 0;
+ * ld* % 8 == 0; every tensor < 4 GiB. */
+enum { VDS_NT = 0, VDS_NN = 1, VDS_TN = 2 };
+enum { VDS_EPI_STORE = 0, VDS_EPI_BIAS_GELU = 1, VDS_EPI_GATE_RES = 2, VDS_EPI_DGELU = 3, VDS_EPI_F32 = 4 };
+
+typedef struct vds_gemm_args {
+  int32_t layout, epilogue;
+  int32_t M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  void* C2; int64_t ldc2;
+  const void* bias;            /* bf16 [N] or NULL */
+  const void* aux; int64_t ldaux; /* bf16 [M,N]: residual (GATE_RES) or pre-activation (DGELU) */
+  const float* gate; int64_t ldgate; /* f32 [batch, ldgate], column n */
+  int32_t rows_per_batch;
+  int32_t split_k;             /* TN only; >=1 */
+} vds_gemm_args;
+
+int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);
+
+/* --------------------------------------------------------------- attention (MFMA) ----
+ * F.scaled_dot_product_attention(q,k,v) full/non-causal (model.py:136,157), flash style.
+ * q/k/v are addressed as base + b*stride_b + h*stride_h + l*stride_l (elements), rows of
+ * head_dim contiguous bf16; O/dO the same.  lse [B,H,Lq] f32 = log-sum-exp of the scaled
+ * scores (natural log).  head_dim in {64, 72, 128}. */
+typedef struct vds_attn_args {
+  int32_t B, H, Lq, Lk, head_dim;
+  const void* q; int64_t q_sb, q_sh, q_sl;
+  const void* k; int64_t k_sb, k_sh, k_sl;
+  const void* v; int64_t v_sb, v_sh, v_sl;
+  void* o; int64_t o_sb, o_sh, o_sl;
+  float* lse;
+  /* backward only */
+  const void* d_o; int64_t do_sb, do_sh, do_sl;
+  void* dq; int64_t dq_sb, dq_sh, dq_sl;
+  void* dk; int64_t dk_sb, dk_sh, dk_sl;
+  void* dv; int64_t dv_sb, dv_sh, dv_sl;
+  float* delta;                /* workspace [B,H,Lq] f32 */
+} vds_attn_args;
+
+int vds_attn_fwd(const vds_attn_args* args, vds_stream_t stream);
+int vds_attn_bwd(const vds_attn_args* args, vds_stream_t stream);
+
+/* ------------------------------------------------------ normalisation / modulation ---
+ * y = bf16( rmsnorm(x)[*w] * (1 + scale[b]) + shift[b] ), rstd saved (model.py:34-41,123,144,164,389).
+ * x,y [B*L, D] bf16; mod f32 [B, ldmod] with shift at column shift_col, scale at scale_col;
+ * w bf16 [D] or NULL; rstd f32 [B*L]. */
+int vds_rmsnorm_mod_fwd(const void* x, int64_t ldx, const void* w, const float* mod, int64_t ldmod,
+                        int32_t shift_col, int32_t scale_col, void* y, int64_t ldy, float* rstd,
+                        int32_t B, int32_t L, int32_t D, float eps, vds_stream_t stream);
+/* dx = bf16( dres + d/dx ), dmod[b, shift_col..] += sum_l dy, dmod[b, scale_col..] += sum_l dy*xhat*w,
+ * dw (f32 [D], atomically +=) if w != NULL.  dres may be NULL. */
+int vds_rmsnorm_mod_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* w,
+                        const float* mod, int64_t ldmod, int32_t shift_col, int32_t scale_col,
+                        const float* rstd, const void* dres, int64_t lddres, void* dx, int64_t lddx,
+                        float* dmod, float* dw, int32_t B, int32_t L, int32_t D, vds_stream_t stream);
+
+/* gate backward of  x_new = x + y*gate  (model.py:139,160,165):
+ *   dy = bf16(dx_new * gate[b]),  dmod[b, gate_col + n] += sum_l dx_new*y,
+ *   dbias[n] (f32, atomically +=) += sum_{b,l} dy   if dbias != NULL. */
+int vds_gate_bwd(const void* dxn, int64_t lddxn, const void* y, int64_t ldy, const float* mod,
+                 int64_t ldmod, int32_t gate_col, void* dy, int64_t lddy, float* dmod, float* dbias,
+                 int32_t B, int32_t L, int32_t D, vds_stream_t stream);
+
+/* column sums: out[n] (f32, atomically +=) += sum_m x[m,n]  (bias gradients). */
+int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M, int32_t N, vds_stream_t stream);
+
+/* ----------------------------------------------------- qkv split / RoPE / residual-V --
+ * forward of model.py:126-134: qkv [B,L,3D] token-major (k h d) ->
+ *   q,k [B,H,L,hdp] rotated (fp32 math, half-split, cos/sin [L, hd/2] f32; model.py:266-275)
+ *   v   [B,H,L,hdp] = lam*v_raw + (1-lam)*v0  (model.py:129-130) when v0 != NULL else v_raw.
+ * hdp >= hd is the padded row length (pad columns are written as zero). lam: bf16 device scalar
+ * (the bf16-cast lambda_param, as under the reference's bf16 param policy). */
+int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float* sinb, const void* v0,
+                     const void* lam, void* q, void* k, void* v, int32_t B, int32_t L, int32_t H,
+                     int32_t hd, int32_t hdp, vds_stream_t stream);
+/* backward: dq,dk,dv [B,H,L,hdp] -> dqkv [B,L,3D] (un-rotated, dv*lam);
+ *   dv0_acc (f32 [B,H,L,hdp]) += (1-lam)*dv  when mix != 0;  dlam (f32 scalar) += sum dv*(v_raw - v0);
+ *   when add_dv0 != 0 (block 0): dv_total = dv + dv0_acc. */
+int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, const float* cosb,
+                     const float* sinb, const void* qkv_raw, const void* v0, const void* lam,
+                     float* dv0_acc, float* dlam, void* dqkv, int32_t mix, int32_t add_dv0, int32_t B,
+                     int32_t L, int32_t H, int32_t hd, int32_t hdp, vds_stream_t stream);
+
+/* ------------------------------------------------------------- small-M linears (B rows) --
+ * y[b, n] = act_out( sum_k act_in(x[b,k]) * W[n,k] + bias[n] ), M = B <= 16 rows:
+ * time_embed / adaLN_modulation / final_modulation (model.py:90,318-322,339-341).
+ * x f32 [M,K]; W bf16 [N,K]; bias bf16 [N]; y f32 [M,N].  act: 0 none, 1 SiLU. */
+int vds_small_linear_fwd(const float* x, const void* W, const void* bias, float* y, int32_t M,
+                         int32_t N, int32_t K, int32_t act_in, vds_stream_t stream);
+/* dW[n,k] (f32) = sum_b dy[b,n]*act_in(x[b,k]);  dbias[n] (f32) = sum_b dy[b,n]  (overwritten);
+ * dx[b,k] (f32) += act_in'(x[b,k]) * sum_n dy[b,n] W[n,k]   (atomically accumulated: the
+ * conditioning vector c collects a gradient from every block).  dW/dbias or dx may be NULL. */
+int vds_small_linear_bwd(const float* dy, const float* x, const void* W, float* dW, float* dbias,
+                         float* dx, int32_t M, int32_t N, int32_t K, int32_t act_in,
+                         vds_stream_t stream);
+/* sinusoid [cos | sin](t * f_i), t unscaled (model.py:12-22), rounded through bf16 like
+ * the reference's .to(x.dtype): out f32 [B, D]. */
+int vds_timestep_embedding(const float* t, float* out, int32_t B, int32_t D, vds_stream_t stream);
+
+/* ------------------------------------------------------------ patchify / unpatchify ---
+ * latent [B,C,T,H,W] bf16 -> patches [B*N, C*pt*p*p] bf16, token order (h w t)
+ * (Conv3d k=stride + rearrange, model.py:182-186); the GEMM with patch_proj follows. */
+int vds_patchify(const void* latent, void* patches, int32_t B, int32_t C, int32_t T, int32_t H,
+                 int32_t W, int32_t pt, int32_t p, vds_stream_t stream);
+/* tokens y [B*N, p*p*pt*C] bf16 (p1 p2 p3 c) -> out [B,C,T,H,W] bf16 (model.py:392-401) */
+int vds_unpatchify(const void* y, void* out, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                   int32_t pt, int32_t p, vds_stream_t stream);
+/* gradient wrt tokens: dy[B*N, P] bf16 from dout [B,C,T,H,W] bf16 (inverse permutation) */
+int vds_unpatchify_bwd(const void* dout, void* dy, int32_t B, int32_t C, int32_t T, int32_t H,
+                       int32_t W, int32_t pt, int32_t p, vds_stream_t stream);
+/* x[b, 0:R] = reg[0:R] ; used to prepend the 16 register tokens (model.py:362) */
+int vds_fill_registers(const void* reg, void* x, int64_t batch_stride, int32_t B, int32_t R,
+                       int32_t D, vds_stream_t stream);
+/* dreg[r,d] (f32) += sum_b dx[b, r, d] */
+int vds_registers_bwd(const void* dx, int64_t batch_stride, float* dreg, int32_t B, int32_t R,
+                      int32_t D, vds_stream_t stream);
+
+/* ------------------------------------------------------------ noising + loss (train.py) --
+ * z_t = x(1-t) + n t ; v = x - n  in bf16 (train.py:115-117); t f32 [B] already bf16-rounded. */
+int vds_noise_latents(const void* x, const void* noise, const float* t, void* z_t, void* v,
+                      int32_t B, int64_t per_sample, vds_stream_t stream);
+/* loss = mean_b mean_chw (v - out)^2 in f32 (train.py:121-125):
+ * loss_out[0] += ... (pre-zeroed), per_sample[b] +=.  dout = bf16( 2 (out - v) * gscale/(B*per_sample) ). */
+int vds_flow_loss(const void* v, const void* out, float* loss_out, float* per_sample, void* dout,
+                  float gscale, int32_t B, int64_t per_sample_n, vds_stream_t stream);
+
+/* -------------------------------------------------------------------- optimizer ------
+ * Multi-tensor AdamW on fp32 master shards (torch.optim.AdamW(fused=True) semantics,
+ * train.py:340-344,433) + bf16 shadow copy for the next all-gather.
+ * desc: one vds_adamw_tensor per parameter (device array). */
+typedef struct vds_adamw_tensor {
+  float* p; const float* g; float* m; float* v; void* p_bf16; int64_t numel; float lr; float wd;
+} vds_adamw_tensor;
+/* work list: chunk i updates elements [chunk_start[i], chunk_start[i]+chunk_elems) of tensor
+ * chunk_tensor[i]; lr_mult is the LR-schedule multiplier of this step (train.py:349-364,434),
+ * step counts from 1, grad_scale multiplies every gradient (1.0 normally). */
+int vds_adamw_multi(const vds_adamw_tensor* desc_dev, const int32_t* chunk_tensor_dev,
+                    const int64_t* chunk_start_dev, int32_t n_chunks, int32_t chunk_elems,
+                    float beta1, float beta2, float eps, int32_t step, float lr_mult,
+                    float grad_scale, vds_stream_t stream);
+
+/* f32 -> bf16 cast (FSDP param_dtype cast before all-gather, model.py:516-518) */
+int vds_cast_f32_bf16(const float* src, void* dst, int64_t n, vds_stream_t stream);
+/* bf16 -> f32 */
+int vds_cast_bf16_f32(const void* src, float* dst, int64_t n, vds_stream_t stream);
+
+/* hardware self-test of the MFMA / LDS-transpose / LDS-DMA lane maps the kernels rely on.
+ * scratch_dev: >= 2080 bytes of device memory; int32[8] mismatch counts are left at byte
+ * offset 2048 (all zero = every map as assumed). */
+int vds_selftest_lanemaps(void* scratch_dev, vds_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDS_H */

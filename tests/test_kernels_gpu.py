@@ -1,0 +1,393 @@
+"""GPU parity of every hand-written HIP kernel against the CPU oracle / plain fp32 torch math
+on the same seeded inputs (runs on the MI355X box: pytest -m gpu).  All calls go through the
+C ABI (ctypes) -- nothing here can pass on a silent fallback because there is none."""
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import dit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from video_diffusion_speedrun_amd import ops as _ops
+    return _ops
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+def close(name, got, ref, tol):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite values"
+    e = rel(got, ref)
+    if e >= tol:
+        d = (got - ref).abs()
+        idx = d.argmax().item()
+        raise AssertionError(f"{name}: rel {e:.3e} >= {tol:.1e}; max|d| {d.max():.4e} at flat {idx} "
+                             f"(got {got.flatten()[idx]:.5f} ref {ref.flatten()[idx]:.5f}); |ref| max {ref.abs().max():.4f}")
+    return e
+
+
+def gen(*shape, seed=0, scale=1.0, dtype=bf16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def test_lane_maps(ops):
+    """MFMA 16x16x32 / 32x32x16 operand maps, accumulator-as-operand permutation,
+    ds_read_b64_tr_b16 and LDS-DMA placement, checked on the device with exact integers."""
+    res = ops.selftest_lanemaps()
+    assert res[:5] == [0, 0, 0, 0, 0], f"lane-map self test mismatches: {res}"
+
+
+# ------------------------------------------------------------------------------- GEMM ----
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 384, 192), (1000, 1152, 1152), (4112, 128, 768),
+                                   (131, 64, 64)])
+def test_gemm_nt_store_bias(ops, M, N, K):
+    x, w, b = gen(M, K, seed=1), gen(N, K, seed=2, scale=0.05), gen(N, seed=3)
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
+    ref = x.float() @ w.float().t() + b.float()
+    close("nt+bias", y, ref, 4e-3)
+    y2 = ops.linear_fwd(x.cuda(), w.cuda(), None)
+    close("nt", y2, x.float() @ w.float().t(), 4e-3)
+
+
+def test_gemm_nt_asymmetric_identity(ops):
+    """A = I against an asymmetric B catches transposed / permuted fragment maps."""
+    K = 128
+    a = torch.eye(K).to(bf16)
+    w = (torch.arange(K * 256).reshape(256, K) % 251 - 125).float().to(bf16)
+    y = ops.linear_fwd(a.cuda(), w.cuda())
+    assert torch.equal(y.cpu().float(), w.float().t().contiguous())
+
+
+def test_gemm_nt_gelu(ops):
+    M, N, K = 520, 512, 256
+    x, w, b = gen(M, K, seed=4), gen(N, K, seed=5, scale=0.08), gen(N, seed=6, scale=0.5)
+    pre, act = ops.linear_fwd_gelu(x.cuda(), w.cuda(), b.cuda())
+    ref = x.float() @ w.float().t() + b.float()
+    close("gelu.pre", pre, ref, 4e-3)
+    close("gelu.act", act, O.gelu_erf(ref), 5e-3)
+
+
+def test_gemm_nt_gate_residual(ops):
+    B, L, N, K = 3, 173, 384, 256
+    M = B * L
+    x, w, res = gen(M, K, seed=7), gen(N, K, seed=8, scale=0.06), gen(M, N, seed=9)
+    b = gen(N, seed=10, scale=0.3)
+    mod = gen(B, 9 * N, seed=11, dtype=f32)
+    for bias in (None, b):
+        y, xn = ops.linear_fwd_gate_res(x.cuda(), w.cuda(), bias.cuda() if bias is not None else None, mod.cuda(),
+                                        2 * N, res.cuda(), L)
+        yr = x.float() @ w.float().t() + (bias.float() if bias is not None else 0)
+        gate = mod[:, 2 * N:3 * N].repeat_interleave(L, dim=0)
+        close("gate.y", y, yr, 4e-3)
+        close("gate.xnew", xn, res.float() + yr * gate, 4e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (777, 1152, 384), (4112, 768, 3072), (200, 128, 64)])
+def test_gemm_nn_dgrad(ops, M, N, K):
+    """dx[M,K] = dy[M,N] W[N,K]"""
+    dy, w = gen(M, N, seed=12), gen(N, K, seed=13, scale=0.05)
+    dx = ops.linear_dgrad(dy.cuda(), w.cuda())
+    close("nn", dx, dy.float() @ w.float(), 4e-3)
+
+
+def test_gemm_nn_asymmetric_identity(ops):
+    N = 128
+    dy = torch.eye(N).to(bf16)
+    w = (torch.arange(N * 384).reshape(N, 384) % 241 - 120).float().to(bf16)
+    dx = ops.linear_dgrad(dy.cuda(), w.cuda())
+    assert torch.equal(dx.cpu().float(), w.float())
+
+
+def test_gemm_nn_dgelu(ops):
+    M, N, K = 333, 256, 512
+    dy, w, pre = gen(M, N, seed=14), gen(N, K, seed=15, scale=0.05), gen(M, K, seed=16)
+    dx = ops.linear_dgrad(dy.cuda(), w.cuda(), pre.cuda())
+    p = pre.float().requires_grad_(True)
+    O.gelu_erf(p).backward(dy.float() @ w.float())
+    close("dgelu", dx, p.grad, 5e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 384, 1152), (4112, 1152, 384), (8208, 128, 768),
+                                   (77, 64, 128)])
+def test_gemm_tn_wgrad(ops, M, N, K):
+    """dW[N,K] = dy[M,N]^T x[M,K], ragged token count M, fp32 out, split-K atomics"""
+    dy, x = gen(M, N, seed=17), gen(M, K, seed=18)
+    dW = torch.zeros(N, K, dtype=f32, device="cuda")
+    ops.linear_wgrad(dy.cuda(), x.cuda(), dW)
+    close("tn", dW, dy.float().t() @ x.float(), 2e-3)
+
+
+def test_gemm_tn_asymmetric(ops):
+    M = 192
+    dy = torch.zeros(M, 128)
+    dy[torch.arange(128), torch.arange(128)] = 1  # dy^T x = x[:128]
+    x = (torch.arange(M * 256).reshape(M, 256) % 239 - 119).float()
+    dW = torch.zeros(128, 256, dtype=f32, device="cuda")
+    ops.linear_wgrad(dy.to(bf16).cuda(), x.to(bf16).cuda(), dW)
+    assert torch.equal(dW.cpu(), x[:128])
+
+
+# -------------------------------------------------------------------------- attention ----
+def attn_ref(q, k, v, do=None):
+    q, k, v = q.float().requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True)
+    o = O.attention(q, k, v)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    lse = torch.logsumexp(s, dim=-1)
+    if do is None:
+        return o, lse
+    o.backward(do.float())
+    return o, lse, q.grad, k.grad, v.grad
+
+
+@pytest.mark.parametrize("hd,Lq,Lk", [(64, 272, 272), (64, 130, 512), (128, 200, 333), (72, 272, 272),
+                                      (72, 129, 512), (128, 64, 64), (64, 1040, 1040)])
+def test_attention_fwd_bwd(ops, hd, Lq, Lk):
+    B, H = 2, 3
+    hdp = {64: 64, 72: 96, 128: 128}[hd]
+    q, k, v = gen(B, H, Lq, hd, seed=20), gen(B, H, Lk, hd, seed=21), gen(B, H, Lk, hd, seed=22)
+    do = gen(B, Lq, H * hd, seed=23)
+    # device layouts: q/k/v head-major padded rows [B,H,L,hdp]; o/do token-major [B,L,H*hd]
+    def pad(t):
+        out = torch.zeros(*t.shape[:-1], hdp, dtype=bf16)
+        out[..., :hd] = t
+        return out.cuda()
+    qd, kd, vd = pad(q), pad(k), pad(v)
+    o_tok = torch.zeros(B * Lq, H * hd, dtype=bf16, device="cuda")
+    lse = torch.zeros(B, H, Lq, dtype=f32, device="cuda")
+    ov = ops.heads_view(o_tok, B, Lq, H, hd)
+    ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ov, lse)
+    do_h = do.reshape(B, Lq, H, hd).permute(0, 2, 1, 3)
+    o_ref, lse_ref, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, do_h)
+    close("attn.o", o_tok.reshape(B, Lq, H, hd).permute(0, 2, 1, 3), o_ref, 6e-3)
+    close("attn.lse", lse, lse_ref, 1e-3)
+    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    delta = torch.zeros(B, H, Lq, dtype=f32, device="cuda")
+    dod = do.reshape(B * Lq, H * hd).cuda()
+    ops.attn_bwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ov, lse, ops.heads_view(dod, B, Lq, H, hd),
+                 dq[..., :hd], dk[..., :hd], dv[..., :hd], delta)
+    close("attn.dv", dv[..., :hd], dv_ref, 8e-3)
+    close("attn.dk", dk[..., :hd], dk_ref, 8e-3)
+    close("attn.dq", dq[..., :hd], dq_ref, 8e-3)
+    if hdp > hd:
+        assert dq[..., hd:].abs().max().item() == 0  # pad columns are never written
+
+
+def test_attention_token_major_cross(ops):
+    """cross-attention layout: q from [B,L,D], k/v from [B,Lc,2D] token-major buffers (hd=72)"""
+    B, H, hd, L, Lc = 2, 2, 72, 150, 512
+    D = H * hd
+    qb, kvb = gen(B * L, D, seed=30), gen(B * Lc, 2 * D, seed=31)
+    qd, kvd = qb.cuda(), kvb.cuda()
+    o = torch.zeros(B * L, D, dtype=bf16, device="cuda")
+    lse = torch.zeros(B, H, L, dtype=f32, device="cuda")
+    qv = ops.heads_view(qd, B, L, H, hd)
+    kv_k = ops.heads_view(kvd, B, Lc, H, hd, 0)
+    kv_v = ops.heads_view(kvd, B, Lc, H, hd, D)
+    ops.attn_fwd(qv, kv_k, kv_v, ops.heads_view(o, B, L, H, hd), lse)
+    q = qb.reshape(B, L, H, hd).permute(0, 2, 1, 3)
+    k = kvb[:, :D].reshape(B, Lc, H, hd).permute(0, 2, 1, 3)
+    v = kvb[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3)
+    do = gen(B * L, D, seed=32)
+    o_ref, _, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, do.reshape(B, L, H, hd).permute(0, 2, 1, 3))
+    close("cross.o", o.reshape(B, L, H, hd).permute(0, 2, 1, 3), o_ref, 6e-3)
+    dqb = torch.zeros_like(qd)
+    dkvb = torch.zeros_like(kvd)
+    delta = torch.zeros(B, H, L, dtype=f32, device="cuda")
+    ops.attn_bwd(qv, kv_k, kv_v, ops.heads_view(o, B, L, H, hd), lse, ops.heads_view(do.cuda(), B, L, H, hd),
+                 ops.heads_view(dqb, B, L, H, hd), ops.heads_view(dkvb, B, Lc, H, hd, 0),
+                 ops.heads_view(dkvb, B, Lc, H, hd, D), delta)
+    close("cross.dq", dqb.reshape(B, L, H, hd).permute(0, 2, 1, 3), dq_ref, 8e-3)
+    close("cross.dk", dkvb[:, :D].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dk_ref, 8e-3)
+    close("cross.dv", dkvb[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dv_ref, 8e-3)
+
+
+def test_attention_online_softmax_rescale(ops):
+    """spike one key late in the sequence so the running max jumps in the last tile"""
+    B, H, hd, L = 1, 1, 64, 256
+    q, k, v = gen(B, H, L, hd, seed=40), gen(B, H, L, hd, seed=41), gen(B, H, L, hd, seed=42)
+    k[0, 0, 250] = q[0, 0, 7] * 3
+    o = torch.zeros(B * L, H * hd, dtype=bf16, device="cuda")
+    lse = torch.zeros(B, H, L, dtype=f32, device="cuda")
+    ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), ops.heads_view(o, B, L, H, hd), lse)
+    o_ref, lse_ref = attn_ref(q, k, v)
+    close("spike.o", o.reshape(B, L, H, hd).permute(0, 2, 1, 3), o_ref.detach(), 6e-3)
+    close("spike.lse", lse, lse_ref.detach(), 1e-3)
+
+
+# ----------------------------------------------------------- norm / modulation / gate ----
+@pytest.mark.parametrize("D,with_w", [(384, False), (1152, False), (144, True), (768, True)])
+def test_rmsnorm_mod_fwd_bwd(ops, D, with_w):
+    B, L = 3, 75
+    x = gen(B * L, D, seed=50)
+    w = (1 + 0.1 * gen(D, seed=51, dtype=f32)).to(bf16) if with_w else None
+    mod = gen(B, 9 * D, seed=52, dtype=f32) * 0.5
+    dy, dres = gen(B * L, D, seed=53), gen(B * L, D, seed=54)
+    y, rstd = ops.rmsnorm_mod_fwd(x.cuda(), w.cuda() if with_w else None, mod.cuda(), 3 * D, 4 * D, B, L)
+    xf = x.float().reshape(B, L, D).requires_grad_(True)
+    wf = w.float().requires_grad_(True) if with_w else None
+    mf = mod.clone().requires_grad_(True)
+    yr = O.modulate(O.rms_norm(xf, wf), mf[:, 3 * D:4 * D], mf[:, 4 * D:5 * D])
+    close("rms.y", y, yr.reshape(B * L, D), 4e-3)
+    yr.backward(dy.float().reshape(B, L, D))
+    dmod = torch.zeros(B, 9 * D, dtype=f32, device="cuda")
+    dw = torch.zeros(D, dtype=f32, device="cuda") if with_w else None
+    dx = ops.rmsnorm_mod_bwd(dy.cuda(), x.cuda(), w.cuda() if with_w else None, mod.cuda(), 3 * D, 4 * D, rstd,
+                             dres.cuda(), dmod, dw, B, L)
+    close("rms.dx", dx, xf.grad.reshape(B * L, D) + dres.float(), 5e-3)
+    close("rms.dmod", dmod, mf.grad, 2e-3)
+    if with_w:
+        close("rms.dw", dw, wf.grad, 2e-3)
+
+
+def test_gate_bwd_and_colsum(ops):
+    B, L, D = 2, 203, 384
+    dxn, y = gen(B * L, D, seed=60), gen(B * L, D, seed=61)
+    mod = gen(B, 9 * D, seed=62, dtype=f32)
+    dmod = torch.zeros(B, 9 * D, dtype=f32, device="cuda")
+    dbias = torch.zeros(D, dtype=f32, device="cuda")
+    dy = ops.gate_bwd(dxn.cuda(), y.cuda(), mod.cuda(), 5 * D, dmod, dbias, B, L)
+    gate = mod[:, 5 * D:6 * D].repeat_interleave(L, dim=0)
+    dyr = dxn.float() * gate
+    close("gate.dy", dy, dyr, 4e-3)
+    ref = torch.zeros(B, 9 * D)
+    ref[:, 5 * D:6 * D] = (dxn.float() * y.float()).reshape(B, L, D).sum(1)
+    close("gate.dmod", dmod, ref, 1e-3)
+    close("gate.dbias", dbias, dyr.to(bf16).float().sum(0), 3e-3)
+    cs = torch.zeros(D, dtype=f32, device="cuda")
+    ops.colsum(y.cuda(), cs)
+    close("colsum", cs, y.float().sum(0), 1e-4)
+
+
+# ----------------------------------------------------------------- qkv / rope / res-V ----
+@pytest.mark.parametrize("hd,hdp", [(64, 64), (72, 96), (128, 128)])
+def test_qkv_rope_fwd_bwd(ops, hd, hdp):
+    B, H, thw = 2, 2, (2, 4, 5)
+    N = thw[0] * thw[1] * thw[2]
+    L = N + 16
+    D = H * hd
+    cos, sin = O.rope_cos_sin(hd, thw, (3, 7, 11))
+    qkv = gen(B * L, 3 * D, seed=70)
+    v0 = gen(B, H, L, hdp, seed=71)
+    v0[..., hd:] = 0
+    lam = torch.tensor([0.37]).to(bf16)
+    qd, kd, vd = ops.qkv_rope_fwd(qkv.cuda(), cos.cuda(), sin.cuda(), v0.cuda(), lam.cuda(), B, L, H, hd, hdp)
+    q, k, v = O.split_heads(qkv.reshape(B, L, 3 * D), 3, H)
+    qr, kr = O.apply_rotary(q, cos, sin), O.apply_rotary(k, cos, sin)
+    vm = lam * v + (1 - lam) * v0[..., :hd]
+    close("rope.q", qd[..., :hd], qr, 1e-3)
+    close("rope.k", kd[..., :hd], kr, 1e-3)
+    close("rope.v", vd[..., :hd], vm, 4e-3)
+    if hdp > hd:
+        assert qd[..., hd:].abs().max().item() == 0 and vd[..., hd:].abs().max().item() == 0
+    # no-mix variant (block 0)
+    _, _, v_raw = ops.qkv_rope_fwd(qkv.cuda(), cos.cuda(), sin.cuda(), None, None, B, L, H, hd, hdp)
+    assert torch.equal(v_raw[..., :hd].cpu(), v.contiguous())
+    # backward
+    dq, dk, dv = gen(B, H, L, hdp, seed=72), gen(B, H, L, hdp, seed=73), gen(B, H, L, hdp, seed=74)
+    qf = qkv.float().reshape(B, L, 3 * D).requires_grad_(True)
+    v0f = v0[..., :hd].float().requires_grad_(True)
+    lf = lam.float().requires_grad_(True)
+    q2, k2, v2 = O.split_heads(qf, 3, H)
+    loss = (O.apply_rotary(q2, cos, sin) * dq[..., :hd].float()).sum() + \
+           (O.apply_rotary(k2, cos, sin) * dk[..., :hd].float()).sum() + \
+           ((lf * v2 + (1 - lf) * v0f) * dv[..., :hd].float()).sum()
+    loss.backward()
+    dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device="cuda")
+    dlam = torch.zeros(1, dtype=f32, device="cuda")
+    dqkv = ops.qkv_rope_bwd(dq.cuda(), dk.cuda(), dv.cuda(), cos.cuda(), sin.cuda(), qkv.cuda(), v0.cuda(),
+                            lam.cuda(), dv0, dlam, True, False, B, L, H, hd, hdp)
+    close("rope.dqkv", dqkv, qf.grad.reshape(B * L, 3 * D), 4e-3)
+    close("rope.dv0", dv0[..., :hd], v0f.grad, 1e-3)
+    close("rope.dlam", dlam, lf.grad, 2e-3)
+    # block-0 variant: dv_total = dv + dv0_acc, no mix
+    dqkv0 = ops.qkv_rope_bwd(dq.cuda(), dk.cuda(), dv.cuda(), cos.cuda(), sin.cuda(), None, None, None, dv0, None,
+                             False, True, B, L, H, hd, hdp)
+    want = (dv[..., :hd].float() + dv0[..., :hd].cpu()).permute(0, 2, 1, 3).reshape(B * L, D)
+    close("rope.dv_block0", dqkv0[:, 2 * D:], want, 4e-3)
+
+
+# -------------------------------------------------------------------- small linears ----
+def test_small_linear_and_timestep(ops):
+    M, N, K = 4, 1152, 384
+    x = gen(M, K, seed=80, dtype=f32)
+    W, b = gen(N, K, seed=81, scale=0.05), gen(N, seed=82, scale=0.1)
+    for act in (0, 1):
+        y = ops.small_linear_fwd(x.cuda(), W.cuda(), b.cuda(), act)
+        xr = x.clone().requires_grad_(True)
+        yr = O.linear(O.silu(xr) if act else xr, W.float(), b.float())
+        close(f"small.y{act}", y, yr, 1e-4)
+        dy = gen(M, N, seed=83, dtype=f32)
+        yr.backward(dy)
+        dW = torch.zeros(N, K, dtype=f32, device="cuda")
+        db = torch.zeros(N, dtype=f32, device="cuda")
+        dx = torch.zeros(M, K, dtype=f32, device="cuda")
+        ops.small_linear_bwd(dy.cuda(), x.cuda(), W.cuda(), dW, db, dx, act)
+        Wf = W.float().requires_grad_(True)
+        O.linear(O.silu(x) if act else x, Wf, None).backward(dy)
+        close(f"small.dW{act}", dW, Wf.grad, 1e-4)
+        close(f"small.db{act}", db, dy.sum(0), 1e-5)
+        close(f"small.dx{act}", dx, xr.grad, 1e-4)
+    t = torch.tensor([0.03, 0.5, 0.97, 0.2])
+    e = ops.timestep_embedding(t.cuda(), 384)
+    close("temb", e, O.timestep_embedding(t, 384).to(bf16), 2e-3)
+
+
+# ---------------------------------------------------------------- patches / loss ----
+@pytest.mark.parametrize("pt", [1, 2])
+def test_patchify_unpatchify(ops, pt):
+    B, C, T, H, W, p = 2, 16, 4, 8, 6, 2
+    x = gen(B, C, T, H, W, seed=90)
+    pat = ops.patchify(x.cuda(), pt, p)
+    ref = O.patchify(x, pt, p)
+    assert torch.equal(pat.cpu().reshape(ref.shape), ref)
+    n = ref.shape[1]
+    y = gen(B * n, p * p * pt * C, seed=91)
+    img = ops.unpatchify(y.cuda(), B, C, T, H, W, pt, p)
+    ref_img = O.unpatchify(y.reshape(B, n, -1), C, T // pt, H // p, W // p, pt, p)
+    assert torch.equal(img.cpu(), ref_img)
+    back = ops.unpatchify_bwd(img, pt, p)
+    assert torch.equal(back.cpu(), y)
+
+
+def test_registers_noise_loss_cast(ops):
+    B, R, D, L = 3, 16, 128, 40
+    reg = gen(R, D, seed=100)
+    x = torch.zeros(B * L, D, dtype=bf16, device="cuda")
+    ops.fill_registers(reg.cuda(), x, L * D, B, R, D)
+    assert torch.equal(x.reshape(B, L, D)[:, :R].cpu(), reg.expand(B, R, D))
+    dx = gen(B * L, D, seed=101)
+    dreg = torch.zeros(R, D, dtype=f32, device="cuda")
+    ops.registers_bwd(dx.cuda(), L * D, dreg, B, R, D)
+    close("dreg", dreg, dx.float().reshape(B, L, D)[:, :R].sum(0), 1e-5)
+    lat, noise = gen(B, 16, 4, 8, 8, seed=102), gen(B, 16, 4, 8, 8, seed=103)
+    t = O.time_shift(gen(B, seed=104))
+    zt, v = ops.noise_latents(lat.cuda(), noise.cuda(), t.float().cuda())
+    zr, vr = O.noise_latents(lat, noise, t)
+    assert torch.equal(zt.cpu(), zr) and torch.equal(v.cpu(), vr)
+    out = gen(B, 16, 4, 8, 8, seed=105)
+    loss, per, dout = ops.flow_loss(v, out.cuda(), True)
+    of = out.float().requires_grad_(True)
+    lr, pr = O.flow_loss(vr, of)
+    lr.backward()
+    close("loss", loss.reshape(1), lr.reshape(1), 1e-5)
+    close("loss.per", per, pr, 1e-5)
+    close("loss.dout", dout, of.grad, 4e-3)
+    a = gen(1000003, seed=106, dtype=f32)
+    d = torch.empty(a.numel(), dtype=bf16, device="cuda")
+    ops.cast_f32_bf16(a.cuda(), d)
+    assert torch.equal(d.cpu(), a.to(bf16))

@@ -1,0 +1,111 @@
+"""ctypes binding of libvds_hip.so (the C ABI declared in include/vds.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a kernel returns an
+error this raises, it never routes to a CPU / eager-torch path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvds_hip.so")
+
+VDS_NT, VDS_NN, VDS_TN = 0, 1, 2
+EPI_STORE, EPI_BIAS_GELU, EPI_GATE_RES, EPI_DGELU, EPI_F32 = 0, 1, 2, 3, 4
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("layout", c_i32), ("epilogue", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("C", c_vp), ("ldc", c_i64),
+                ("C2", c_vp), ("ldc2", c_i64), ("bias", c_vp), ("aux", c_vp), ("ldaux", c_i64),
+                ("gate", c_vp), ("ldgate", c_i64), ("rows_per_batch", c_i32), ("split_k", c_i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("B", c_i32), ("H", c_i32), ("Lq", c_i32), ("Lk", c_i32), ("head_dim", c_i32),
+                ("q", c_vp), ("q_sb", c_i64), ("q_sh", c_i64), ("q_sl", c_i64),
+                ("k", c_vp), ("k_sb", c_i64), ("k_sh", c_i64), ("k_sl", c_i64),
+                ("v", c_vp), ("v_sb", c_i64), ("v_sh", c_i64), ("v_sl", c_i64),
+                ("o", c_vp), ("o_sb", c_i64), ("o_sh", c_i64), ("o_sl", c_i64),
+                ("lse", c_vp),
+                ("d_o", c_vp), ("do_sb", c_i64), ("do_sh", c_i64), ("do_sl", c_i64),
+                ("dq", c_vp), ("dq_sb", c_i64), ("dq_sh", c_i64), ("dq_sl", c_i64),
+                ("dk", c_vp), ("dk_sb", c_i64), ("dk_sh", c_i64), ("dk_sl", c_i64),
+                ("dv", c_vp), ("dv_sb", c_i64), ("dv_sh", c_i64), ("dv_sl", c_i64),
+                ("delta", c_vp)]
+
+
+class AdamWTensor(C.Structure):
+    _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("p_bf16", c_vp),
+                ("numel", c_i64), ("lr", c_f32), ("wd", c_f32)]
+
+
+# name -> argtypes (restype is int unless noted).  Must list every symbol of include/vds.h.
+SIGNATURES = {
+    "vds_version": [],
+    "vds_last_error": [],
+    "vds_gemm_bf16": [C.POINTER(GemmArgs), c_vp],
+    "vds_attn_fwd": [C.POINTER(AttnArgs), c_vp],
+    "vds_attn_bwd": [C.POINTER(AttnArgs), c_vp],
+    "vds_rmsnorm_mod_fwd": [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
+                            c_f32, c_vp],
+    "vds_rmsnorm_mod_bwd": [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp,
+                            c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "vds_gate_bwd": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32,
+                     c_vp],
+    "vds_colsum_bf16": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp],
+    "vds_qkv_rope_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_qkv_rope_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                         c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_small_linear_fwd": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_small_linear_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_timestep_embedding": [c_vp, c_vp, c_i32, c_i32, c_vp],
+    "vds_patchify": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_unpatchify": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_unpatchify_bwd": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_fill_registers": [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp],
+    "vds_registers_bwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "vds_noise_latents": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
+    "vds_flow_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i64, c_vp],
+    "vds_adamw_multi": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32, c_vp],
+    "vds_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
+    "vds_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
+    "vds_selftest_lanemaps": [c_vp, c_vp],
+}
+
+_lib = None
+
+
+class VdsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once).  Raises if it was not built: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VdsError(
+            f"{LIB_PATH} not found: build the gfx950 kernels first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C video_diffusion_speedrun_amd/csrc).  This package has no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "vds_last_error" else C.c_int
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "VDS_ERR_ARG (bad argument / alignment)", -2: "VDS_ERR_UNSUPPORTED (shape not supported)",
+        -3: "VDS_ERR_LAUNCH (kernel launch failed)"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().vds_last_error()
+        raise VdsError(f"{what} failed: {_ERR.get(rc, rc)} {msg.decode() if msg else ''}")

@@ -1,0 +1,573 @@
+// Flash-style full (non-causal) attention for gfx950, forward and backward, bf16 in /
+// fp32 softmax, head_dim 64 / 72 / 128 (72 = DiT-XL, padded to 80 for the QK contraction and
+// to 96 for the 32-wide output blocks).  Replaces F.scaled_dot_product_attention at
+// model.py:136 (self, L x L) and model.py:157 (cross, L x 512) and its autograd backward.
+//
+// All three kernels are built from two MFMA product forms on v_mfma_f32_32x32x16_bf16:
+//   F1  X[r, c]   = sum_k A[r,k] B[c,k]      both operands row-major, 16-B fragment reads
+//   F2  Y^T[d, c] = sum_r T[r,d] X[r,c]      X = a previous accumulator used in place as the
+//                                            B operand (its row index is the contraction),
+//                                            T^T read from a row-major LDS tile with the
+//                                            transposing read ds_read_b64_tr_b16
+// so the softmax statistics always live on the lane that owns the column c and no tile ever
+// crosses lanes through LDS:
+//   forward   S^T = K Q^T (F1)            O^T  += V^T P^T  (F2)        c = query, lane-local m, l
+//   dQ        S^T = K Q^T, dP^T = V dO^T  dQ^T += K^T dS^T (F2)        c = query
+//   dK,dV     S = Q K^T,  dP = dO V^T     dV^T += dO^T P, dK^T += Q^T dS (F2)   c = key
+// Backward is two kernels (7 products instead of the fused 5) in exchange for no atomics, no
+// dS transpose and bitwise-reproducible gradients.
+//
+// LDS tiles use the 8-row x 32-column sub-tiled, XOR-swizzled image that is conflict-free
+// for both the 16-B row reads and the transposing reads (cdna guide T10 image (a)).
+// K/V (or Q/dO) tiles are staged HBM -> VGPR -> LDS with the loads issued one tile ahead
+// (issue-early / write-late), double-buffered, one barrier per tile.
+#include "common.h"
+#include "../../include/vds.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnP {
+  int B, H, Lq, Lk, hd;
+  const bf16_t* q; long q_sb, q_sh, q_sl;
+  const bf16_t* k; long k_sb, k_sh, k_sl;
+  const bf16_t* v; long v_sb, v_sh, v_sl;
+  bf16_t* o; long o_sb, o_sh, o_sl;
+  float* lse;
+  const bf16_t* d_o; long do_sb, do_sh, do_sl;
+  bf16_t* dq; long dq_sb, dq_sh, dq_sl;
+  bf16_t* dk; long dk_sb, dk_sh, dk_sl;
+  bf16_t* dv; long dv_sb, dv_sh, dv_sl;
+  float* delta;
+  float scale;
+  int n_rt;  // row tiles per (b,h) of the stationary operand
+};
+
+// ---- LDS image (a): rows x HDP bf16, 8x32 sub-tiles of 512 B -------------------------------
+template <int HDP>
+__device__ __forceinline__ int img_off(int row, int ch) {
+  return (row >> 3) * ((HDP / 32) * 512) + (ch >> 2) * 512 + (row & 7) * 64 + ((((ch & 3) ^ ((row >> 2) & 3))) << 4);
+}
+// F1 operand (A or B): 32 rows x 16 k; lane -> row (l&31), k = 16*ks + 8*(l>>5) .. +7
+template <int HDP>
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int row0, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(tile + img_off<HDP>(row0 + (lane & 31), ks * 2 + (lane >> 5)));
+}
+// F2 A operand = T^T: 32 cols (d0..d0+31) x 16 rows (r0..r0+15) of the row-major tile T,
+// k order matching an accumulator used as B: element j of lane-half h is row r0 + 8(j>>2) + 4h + (j&3).
+template <int HDP>
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int r0, int d0, int lane) {
+  const int g = lane >> 4, h = g >> 1, i = lane & 15, qq = i >> 2, pp = i & 3;
+  const int row = r0 + 4 * h + qq;
+  const int ch = (d0 >> 3) + 2 * (g & 1) + (pp >> 1);
+  const char* p0 = tile + img_off<HDP>(row, ch) + 8 * (pp & 1);
+  const char* p1 = tile + img_off<HDP>(row + 8, ch) + 8 * (pp & 1);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p1));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+// accumulator registers 8s..8s+7 -> bf16 operand fragment of k-step s
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)x[8 * s + j];
+  return r;
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+// value of the partner lane (l ^ 32)
+__device__ __forceinline__ float other_half(float x) { return __shfl_xor(x, 32, 64); }
+// row index inside a 32x32 accumulator: reg -> (reg&3) + 8*(reg>>2) + 4*h
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ---- staged tile loads: ROWS x HDP bf16 through registers ------------------------------------
+template <int ROWS, int HDP>
+struct Stage {
+  static constexpr int NCH = HDP / 8;
+  static constexpr int N = ROWS * NCH / 256;
+  u32x4 r[N];
+  // rsrc covers rows [0, L) of one (b,h) slice; rows >= L and chunks >= hd/8 read zero
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, int row0, long sl, int hd, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
+      unsigned off = (unsigned)(((long)(row0 + row) * sl + ch * 8) * 2);
+      if (ch * 8 >= hd) off = 0xfffffff0u;
+      r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+  }
+  __device__ __forceinline__ void commit(char* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
+      *reinterpret_cast<u32x4*>(tile + img_off<HDP>(row, ch)) = r[i];
+    }
+  }
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const bf16_t* base, long sl, int L, int hd) {
+  return make_rsrc(base, (unsigned)((((long)(L - 1)) * sl + hd) * 2));
+}
+
+// XCD-aware (b,h,row-tile) decode: all row tiles of a head run on one XCD so that the
+// streamed operand (K/V or Q/dO of that head) stays in that XCD's L2.
+__device__ __forceinline__ bool decode_block(int n_rt, int BH, int& bh, int& rt) {
+  const int pid = blockIdx.x, xcd = pid & 7, idx = pid >> 3;
+  bh = (idx / n_rt) * 8 + xcd;
+  rt = idx % n_rt;
+  return bh < BH;
+}
+
+// store a transposed accumulator set Y^T[d, c] (c on lanes) as rows Y[c, d] of bf16
+template <int NDB>
+__device__ __forceinline__ void store_rows(bf16_t* rowp, const f32x16 (&acc)[NDB], float mul, int hd, int h) {
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = db * 32 + 8 * rg + 4 * h;
+      if (d < hd) {
+        u32x2 w;
+        w[0] = pack_bf2(acc[db][4 * rg] * mul, acc[db][4 * rg + 1] * mul);
+        w[1] = pack_bf2(acc[db][4 * rg + 2] * mul, acc[db][4 * rg + 3] * mul);
+        *reinterpret_cast<u32x2*>(rowp + d) = w;
+      }
+    }
+}
+
+// ===================================== forward ==============================================
+template <int HDP, int HDQ>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
+  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int qrow = qt * 128 + wave * 32 + (lane & 31);
+
+  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
+  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+
+  bf16x8 qf[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    const int e = ks * 16 + 8 * h;
+    unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
+    if (e >= p.hd) off = 0xfffffff0u;
+    qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+  }
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) o[i] = zero16();
+  float m = -1e30f, l = 0.f;
+  const float c = p.scale * LOG2E;
+  const int nkt = (p.Lk + 63) / 64;
+
+  Stage<64, HDP> sk, sv;
+  sk.issue(rk, 0, p.k_sl, p.hd, tid);
+  sv.issue(rv, 0, p.v_sl, p.hd, tid);
+  sk.commit(smem, tid);
+  sv.commit(smem + TILE, tid);
+  __syncthreads();
+
+  for (int j = 0; j < nkt; ++j) {
+    const bool more = (j + 1 < nkt);
+    if (more) {
+      sk.issue(rk, (j + 1) * 64, p.k_sl, p.hd, tid);
+      sv.issue(rv, (j + 1) * 64, p.v_sl, p.hd, tid);
+    }
+    const char* kt = smem + (j & 1) * 2 * TILE;
+    const char* vt = kt + TILE;
+
+    f32x16 s[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) s[kb] = mfma32(frag_row<HDP>(kt, kb * 32, ks, lane), qf[ks], s[kb]);
+
+    if (j == nkt - 1 && (p.Lk & 63)) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (j * 64 + kb * 32 + acc_row(r, h) >= p.Lk) s[kb][r] = -INFINITY;
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, other_half(mx));
+    const float m_new = fmaxf(m, mx * c);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    m = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[kb][r] * c - m_new);
+        s[kb][r] = e;
+        ls += e;
+      }
+    l = l * alpha + ls;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s[kb], s2);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+          o[db] = mfma32(frag_tr<HDP>(vt, kb * 32 + 16 * s2, db * 32, lane), pf, o[db]);
+      }
+
+    if (more) {
+      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
+      sk.commit(nk, tid);
+      sv.commit(nk + TILE, tid);
+    }
+    __syncthreads();
+  }
+
+  const float lt = l + other_half(l);
+  if (qrow < p.Lq) {
+    store_rows<NDB>(p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, o, 1.0f / lt, p.hd, h);
+    if (h == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m + __builtin_amdgcn_logf(lt)) * LN2;
+  }
+}
+
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per row group; HBM-bound preprocess)
+__global__ void attn_delta_kernel(AttnP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;  // over B*H*Lq
+  if (row >= (long)p.B * p.H * p.Lq) return;
+  const int q = row % p.Lq;
+  const int bh = row / p.Lq;
+  const int b = bh / p.H, hh = bh % p.H;
+  const bf16_t* o = p.o + b * p.o_sb + hh * p.o_sh + (long)q * p.o_sl;
+  const bf16_t* d = p.d_o + b * p.do_sb + hh * p.do_sh + (long)q * p.do_sl;
+  float acc = 0.f;
+  for (int e = lane * 2; e < p.hd; e += 128) {
+    const unsigned a = *reinterpret_cast<const unsigned*>(o + e);
+    const unsigned g = *reinterpret_cast<const unsigned*>(d + e);
+    acc += bflo(a) * bflo(g) + bfhi(a) * bfhi(g);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) p.delta[row] = acc;
+}
+
+// ===================================== dQ ===================================================
+template <int HDP, int HDQ>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
+  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int qrow = qt * 128 + wave * 32 + (lane & 31);
+
+  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rdo = slice_rsrc(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
+  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+
+  bf16x8 qf[KSQ], dof[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    const int e = ks * 16 + 8 * h;
+    unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
+    unsigned off2 = (unsigned)(((long)qrow * p.do_sl + e) * 2);
+    if (e >= p.hd) { off = 0xfffffff0u; off2 = 0xfffffff0u; }
+    qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+    dof[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdo, off2, 0, 0));
+  }
+  const long srow = ((long)b * p.H + hh) * p.Lq + min(qrow, p.Lq - 1);
+  const float lse2 = p.lse[srow] * LOG2E;
+  const float dl = p.delta[srow];
+  const float c = p.scale * LOG2E;
+
+  f32x16 dq[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) dq[i] = zero16();
+  const int nkt = (p.Lk + 63) / 64;
+
+  Stage<64, HDP> sk, sv;
+  sk.issue(rk, 0, p.k_sl, p.hd, tid);
+  sv.issue(rv, 0, p.v_sl, p.hd, tid);
+  sk.commit(smem, tid);
+  sv.commit(smem + TILE, tid);
+  __syncthreads();
+
+  for (int j = 0; j < nkt; ++j) {
+    const bool more = (j + 1 < nkt);
+    if (more) {
+      sk.issue(rk, (j + 1) * 64, p.k_sl, p.hd, tid);
+      sv.issue(rv, (j + 1) * 64, p.v_sl, p.hd, tid);
+    }
+    const char* kt = smem + (j & 1) * 2 * TILE;
+    const char* vt = kt + TILE;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) {
+        s = mfma32(frag_row<HDP>(kt, kb * 32, ks, lane), qf[ks], s);
+        dp = mfma32(frag_row<HDP>(vt, kb * 32, ks, lane), dof[ks], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pr = __builtin_amdgcn_exp2f(s[r] * c - lse2);
+        if (j * 64 + kb * 32 + acc_row(r, h) >= p.Lk) pr = 0.f;
+        s[r] = pr * (dp[r] - dl);  // dS^T (unscaled)
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 df = acc_frag(s, s2);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+          dq[db] = mfma32(frag_tr<HDP>(kt, kb * 32 + 16 * s2, db * 32, lane), df, dq[db]);
+      }
+    }
+    if (more) {
+      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
+      sk.commit(nk, tid);
+      sv.commit(nk + TILE, tid);
+    }
+    __syncthreads();
+  }
+  if (qrow < p.Lq)
+    store_rows<NDB>(p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl, dq, p.scale, p.hd, h);
+}
+
+// ===================================== dK, dV ===============================================
+// Workgroup = 128 keys (4 waves x 32); K and V of those keys stay in LDS for the whole sweep
+// over 64-row Q/dO tiles.  S and dP have the key on the lane; LSE and delta are per register row.
+template <int HDP, int HDQ>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnP p) {
+  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, KV_TILE = 128 * HDP * 2, Q_TILE = 64 * HDP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS: [K 128 rows][V 128 rows][buf0: Q | dO][buf1: Q | dO][stats: 2 bufs x (lse2[64], delta[64])]
+  char* ktile = smem;
+  char* vtile = smem + KV_TILE;
+  char* qbuf = smem + 2 * KV_TILE;
+  float* stats = reinterpret_cast<float*>(smem + 2 * KV_TILE + 4 * Q_TILE);
+  int bh, kt_idx;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, kt_idx)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int key0 = kt_idx * 128;
+  const int krow = key0 + wave * 32 + (lane & 31);
+
+  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rdo = slice_rsrc(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
+  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+  const float* lse_g = p.lse + ((long)b * p.H + hh) * p.Lq;
+  const float* dl_g = p.delta + ((long)b * p.H + hh) * p.Lq;
+  const float c = p.scale * LOG2E;
+
+  {
+    Stage<128, HDP> s0;
+    s0.issue(rk, key0, p.k_sl, p.hd, tid);
+    s0.commit(ktile, tid);
+    s0.issue(rv, key0, p.v_sl, p.hd, tid);
+    s0.commit(vtile, tid);
+  }
+  Stage<64, HDP> sq, sd;
+  float st_l = 0.f, st_d = 0.f;  // threads 0..63 stage the row statistics of the next tile
+  auto issue_stats = [&](int q0) {
+    if (tid < 64) {
+      const int qq = q0 + tid;
+      const bool ok = qq < p.Lq;
+      st_l = ok ? lse_g[qq] * LOG2E : 1e30f;  // rows past Lq: P = exp2(-inf) = 0
+      st_d = ok ? dl_g[qq] : 0.f;
+    }
+  };
+  auto commit_stats = [&](int buf) {
+    if (tid < 64) {
+      stats[buf * 128 + tid] = st_l;
+      stats[buf * 128 + 64 + tid] = st_d;
+    }
+  };
+  sq.issue(rq, 0, p.q_sl, p.hd, tid);
+  sd.issue(rdo, 0, p.do_sl, p.hd, tid);
+  issue_stats(0);
+  sq.commit(qbuf, tid);
+  sd.commit(qbuf + Q_TILE, tid);
+  commit_stats(0);
+  __syncthreads();
+
+  f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) { dk[i] = zero16(); dv[i] = zero16(); }
+  const int nqt = (p.Lq + 63) / 64;
+
+  for (int j = 0; j < nqt; ++j) {
+    const bool more = (j + 1 < nqt);
+    if (more) {
+      sq.issue(rq, (j + 1) * 64, p.q_sl, p.hd, tid);
+      sd.issue(rdo, (j + 1) * 64, p.do_sl, p.hd, tid);
+      issue_stats((j + 1) * 64);
+    }
+    const char* qt = qbuf + (j & 1) * 2 * Q_TILE;
+    const char* dot = qt + Q_TILE;
+    const float* stl = stats + (j & 1) * 128;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) {
+        s = mfma32(frag_row<HDP>(qt, qb * 32, ks, lane), frag_row<HDP>(ktile, wave * 32, ks, lane), s);
+        dp = mfma32(frag_row<HDP>(dot, qb * 32, ks, lane), frag_row<HDP>(vtile, wave * 32, ks, lane), dp);
+      }
+      f32x16 pm;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + qb * 32 + 8 * rg + 4 * h);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qb * 32 + 8 * rg + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rg + e;
+          const float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[e]);
+          pm[r] = pr;
+          s[r] = pr * (dp[r] - d4[e]);  // dS (unscaled)
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(pm, s2);
+        const bf16x8 df = acc_frag(s, s2);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          dv[db] = mfma32(frag_tr<HDP>(dot, qb * 32 + 16 * s2, db * 32, lane), pf, dv[db]);
+          dk[db] = mfma32(frag_tr<HDP>(qt, qb * 32 + 16 * s2, db * 32, lane), df, dk[db]);
+        }
+      }
+    }
+    if (more) {
+      char* nb = qbuf + ((j + 1) & 1) * 2 * Q_TILE;
+      sq.commit(nb, tid);
+      sd.commit(nb + Q_TILE, tid);
+      commit_stats((j + 1) & 1);
+    }
+    __syncthreads();
+  }
+  if (krow < p.Lk) {
+    store_rows<NDB>(p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl, dk, p.scale, p.hd, h);
+    store_rows<NDB>(p.dv + b * p.dv_sb + hh * p.dv_sh + (long)krow * p.dv_sl, dv, 1.0f, p.hd, h);
+  }
+}
+
+AttnP to_p(const vds_attn_args* a) {
+  AttnP p;
+  p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.hd = a->head_dim;
+  p.q = (const bf16_t*)a->q; p.q_sb = a->q_sb; p.q_sh = a->q_sh; p.q_sl = a->q_sl;
+  p.k = (const bf16_t*)a->k; p.k_sb = a->k_sb; p.k_sh = a->k_sh; p.k_sl = a->k_sl;
+  p.v = (const bf16_t*)a->v; p.v_sb = a->v_sb; p.v_sh = a->v_sh; p.v_sl = a->v_sl;
+  p.o = (bf16_t*)a->o; p.o_sb = a->o_sb; p.o_sh = a->o_sh; p.o_sl = a->o_sl;
+  p.lse = a->lse;
+  p.d_o = (const bf16_t*)a->d_o; p.do_sb = a->do_sb; p.do_sh = a->do_sh; p.do_sl = a->do_sl;
+  p.dq = (bf16_t*)a->dq; p.dq_sb = a->dq_sb; p.dq_sh = a->dq_sh; p.dq_sl = a->dq_sl;
+  p.dk = (bf16_t*)a->dk; p.dk_sb = a->dk_sb; p.dk_sh = a->dk_sh; p.dk_sl = a->dk_sl;
+  p.dv = (bf16_t*)a->dv; p.dv_sb = a->dv_sb; p.dv_sh = a->dv_sh; p.dv_sl = a->dv_sl;
+  p.delta = a->delta;
+  p.scale = 1.0f / sqrtf((float)a->head_dim);
+  p.n_rt = 0;
+  return p;
+}
+
+bool strides_ok(const vds_attn_args* a, bool bwd) {
+  auto ok = [](int64_t s) { return (s & 7) == 0; };
+  bool r = ok(a->q_sb) && ok(a->q_sh) && ok(a->q_sl) && ok(a->k_sb) && ok(a->k_sh) && ok(a->k_sl) &&
+           ok(a->v_sb) && ok(a->v_sh) && ok(a->v_sl) && (a->o_sb % 4 == 0) && (a->o_sh % 4 == 0) && (a->o_sl % 4 == 0);
+  if (bwd)
+    r = r && ok(a->do_sb) && ok(a->do_sh) && ok(a->do_sl) && (a->dq_sl % 4 == 0) && (a->dk_sl % 4 == 0) &&
+        (a->dv_sl % 4 == 0) && (a->dq_sh % 4 == 0) && (a->dk_sh % 4 == 0) && (a->dv_sh % 4 == 0) &&
+        (a->dq_sb % 4 == 0) && (a->dk_sb % 4 == 0) && (a->dv_sb % 4 == 0);
+  return r;
+}
+
+template <typename K>
+void set_lds(K kern, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int HDP, int HDQ>
+int run_fwd(AttnP p, hipStream_t s) {
+  constexpr int LDS = 4 * 64 * HDP * 2;
+  static bool once = false;
+  if (!once) { set_lds(attn_fwd_kernel<HDP, HDQ>, LDS); once = true; }
+  p.n_rt = cdiv(p.Lq, 128);
+  const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
+  hipLaunchKernelGGL((attn_fwd_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS, s, p);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+template <int HDP, int HDQ>
+int run_bwd(AttnP p, hipStream_t s) {
+  constexpr int LDS_DQ = 4 * 64 * HDP * 2;
+  constexpr int LDS_DKV = 2 * 128 * HDP * 2 + 4 * 64 * HDP * 2 + 2 * 128 * 4;
+  static bool once = false;
+  if (!once) {
+    set_lds(attn_bwd_dq_kernel<HDP, HDQ>, LDS_DQ);
+    set_lds(attn_bwd_dkv_kernel<HDP, HDQ>, LDS_DKV);
+    once = true;
+  }
+  const long rows = (long)p.B * p.H * p.Lq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
+  p.n_rt = cdiv(p.Lk, 128);
+  int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS_DKV, s, p);
+  p.n_rt = cdiv(p.Lq, 128);
+  grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS_DQ, s, p);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int vds_attn_fwd(const vds_attn_args* a, vds_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || a->Lq <= 0 || a->Lk <= 0) return VDS_ERR_ARG;
+  if (!strides_ok(a, false)) return VDS_ERR_ARG;
+  AttnP p = to_p(a);
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->head_dim) {
+    case 64: return run_fwd<64, 64>(p, s);
+    case 72: return run_fwd<96, 80>(p, s);
+    case 128: return run_fwd<128, 128>(p, s);
+    default: return VDS_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" int vds_attn_bwd(const vds_attn_args* a, vds_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || !a->d_o || !a->dq || !a->dk || !a->dv || !a->delta)
+    return VDS_ERR_ARG;
+  if (!strides_ok(a, true)) return VDS_ERR_ARG;
+  AttnP p = to_p(a);
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->head_dim) {
+    case 64: return run_bwd<64, 64>(p, s);
+    case 72: return run_bwd<96, 80>(p, s);
+    case 128: return run_bwd<128, 128>(p, s);
+    default: return VDS_ERR_UNSUPPORTED;
+  }
+}

@@ -1,0 +1,839 @@
+// HBM-bound glue of the DiT train step, written for wave64 + 16-byte accesses:
+// fused RMSNorm+modulate (fwd/bwd), gate backward, column sums, qkv split + 3-D RoPE +
+// residual-V (fwd/bwd), the B-row "small" linears (time embed / adaLN), sinusoid,
+// patchify / unpatchify, register tokens, noising, flow-matching loss, casts.
+// Reference call sites are cited per kernel (file:line of the reference repo).
+#include "common.h"
+#include "../../include/vds.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4& u, float (&f)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = bflo(u[e]); f[2 * e + 1] = bfhi(u[e]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  u32x4 u;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) u[e] = pack_bf2(f[2 * e], f[2 * e + 1]);
+  return u;
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+
+// ------------------------------------------------------------------ RMSNorm + modulate ---
+// model.py:34-41 (RMSNorm, fp32 statistics, eps 1e-6) fused with model.py:123/144/164/389
+// (norm_x*(1+scale)+shift).  One wave per token row, the row stays in registers; each lane
+// owns 16-byte chunks lane, lane+64, ...  NC = chunks per lane (D <= 512*NC).
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, long ldx, const bf16_t* w,
+                                                              const float* mod, long ldmod, int shift_col,
+                                                              int scale_col, bf16_t* y, long ldy, float* rstd,
+                                                              int B, int L, int D, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= (long)B * L) return;
+  const int b = (int)(row / L);
+  const int nch = D >> 3;
+  float v[NC][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + c * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)D + eps);
+  if (lane == 0) rstd[row] = r;
+  const float* mrow = mod + (long)b * ldmod;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float sh[8], sc[8], o[8], wv[8];
+      load8f(mrow + shift_col + c * 8, sh);
+      load8f(mrow + scale_col + c * 8, sc);
+      if (w) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xn = v[i][e] * r;
+        if (w) xn *= wv[e];
+        o[e] = xn * (1.0f + sc[e]) + sh[e];
+      }
+      *reinterpret_cast<u32x4*>(y + row * ldy + c * 8) = pack8(o);
+    }
+  }
+}
+
+// Backward.  grid = (row-groups, B); each wave walks rows of ONE sample so that the
+// d(shift), d(scale) sums over L stay in registers; one atomicAdd per column per block.
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const bf16_t* dy, long lddy, const bf16_t* x, long ldx,
+                                                              const bf16_t* w, const float* mod, long ldmod,
+                                                              int shift_col, int scale_col, const float* rstd,
+                                                              const bf16_t* dres, long lddres, bf16_t* dx, long lddx,
+                                                              float* dmod, float* dw, int B, int L, int D,
+                                                              int rows_per_block) {
+  __shared__ float red[4][64 * NC * 8 + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int nch = D >> 3;
+  const int l0 = blockIdx.x * rows_per_block;
+  const int l1 = min(L, l0 + rows_per_block);
+  float sc1[NC][8], wv[NC][8], a_shift[NC][8], a_scale[NC][8], a_w[NC][8];
+  const float* mrow = mod + (long)b * ldmod;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a_shift[i][e] = 0.f; a_scale[i][e] = 0.f; a_w[i][e] = 0.f; sc1[i][e] = 0.f; wv[i][e] = 1.f; }
+    if (c < nch) {
+      load8f(mrow + scale_col + c * 8, sc1[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc1[i][e] += 1.0f;
+      if (w) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv[i]);
+    }
+  }
+  for (int l = l0 + wave; l < l1; l += 4) {
+    const long row = (long)b * L + l;
+    const float r = rstd[row];
+    float g[NC][8], xh[NC][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float dyv[8], xv[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dy + row * lddy + c * 8), dyv);
+        unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + c * 8), xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xhat = xv[e] * r;
+          xh[i][e] = xhat;
+          a_shift[i][e] += dyv[e];
+          a_scale[i][e] += dyv[e] * xhat * wv[i][e];
+          const float t = dyv[e] * sc1[i][e];  // d/d(xhat*w)
+          a_w[i][e] += t * xhat;
+          g[i][e] = t * wv[i][e];               // d/d xhat
+          dot += g[i][e] * xhat;
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float o[8];
+        if (dres) unpack8(*reinterpret_cast<const u32x4*>(dres + row * lddres + c * 8), o);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r * (g[i][e] - xh[i][e] * dot);
+        *reinterpret_cast<u32x4*>(dx + row * lddx + c * 8) = pack8(o);
+      }
+    }
+  }
+  // block reduction of the three column sums, one pass each through LDS
+  float* drow = dmod + (long)b * ldmod;
+  for (int pass = 0; pass < 3; ++pass) {
+    if (pass == 2 && !dw) break;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        red[wave][(i * 64 + lane) * 8 + e] = pass == 0 ? a_shift[i][e] : (pass == 1 ? a_scale[i][e] : a_w[i][e]);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NC * 64 * 8; idx += 256) {
+      const int i = idx / 512, rem = idx % 512, ln = rem / 8, e = rem % 8;
+      const int col = (ln + 64 * i) * 8 + e;
+      if (col < D) {
+        const float s = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+        if (pass == 0) atomicAdd(drow + shift_col + col, s);
+        else if (pass == 1) atomicAdd(drow + scale_col + col, s);
+        else atomicAdd(dw + col, s);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------ gate backward ---
+// x_new = x + y*gate (model.py:139,160,165): dy = dx_new*gate, dgate = sum_l dx_new*y,
+// dbias = sum_{b,l} dy.  Same sample-per-blockIdx.y structure as above.
+template <int NC>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long lddxn, const bf16_t* y, long ldy,
+                                                       const float* mod, long ldmod, int gate_col, bf16_t* dy,
+                                                       long lddy, float* dmod, float* dbias, int B, int L, int D,
+                                                       int rows_per_block) {
+  __shared__ float red[4][64 * NC * 8 + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int nch = D >> 3;
+  const int l0 = blockIdx.x * rows_per_block;
+  const int l1 = min(L, l0 + rows_per_block);
+  float gt[NC][8], a_g[NC][8], a_b[NC][8];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a_g[i][e] = 0.f; a_b[i][e] = 0.f; gt[i][e] = 0.f; }
+    if (c < nch) load8f(mod + (long)b * ldmod + gate_col + c * 8, gt[i]);
+  }
+  for (int l = l0 + wave; l < l1; l += 4) {
+    const long row = (long)b * L + l;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float d[8], yv[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dxn + row * lddxn + c * 8), d);
+        unpack8(*reinterpret_cast<const u32x4*>(y + row * ldy + c * 8), yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          a_g[i][e] += d[e] * yv[e];
+          o[e] = d[e] * gt[i][e];
+          a_b[i][e] += o[e];
+        }
+        *reinterpret_cast<u32x4*>(dy + row * lddy + c * 8) = pack8(o);
+      }
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && !dbias) break;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][(i * 64 + lane) * 8 + e] = pass == 0 ? a_g[i][e] : a_b[i][e];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NC * 64 * 8; idx += 256) {
+      const int i = idx / 512, rem = idx % 512, ln = rem / 8, e = rem % 8;
+      const int col = (ln + 64 * i) * 8 + e;
+      if (col < D) {
+        const float s = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+        if (pass == 0) atomicAdd(dmod + (long)b * ldmod + gate_col + col, s);
+        else atomicAdd(dbias + col, s);
+      }
+    }
+  }
+}
+
+// column sums of a bf16 matrix (bias gradients): block = 64 column-chunks x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, long ldx, float* out, int M, int N,
+                                                     int rows_per_block) {
+  __shared__ float red[4][64 * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float a[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+  if (c * 8 < N)
+    for (int r = r0 + wave; r < r1; r += 4) {
+      float v[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + (long)r * ldx + c * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = a[e];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 512; idx += 256) {
+    const int col = blockIdx.x * 512 + idx;
+    if (col < N) atomicAdd(out + col, red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx]);
+  }
+}
+
+// ------------------------------------------------- qkv split + RoPE + residual-V (fwd) ---
+// model.py:126-134,266-275.  One thread = 4 elements d..d+3 of the first half of one head of
+// one token and their rotation partners d+hd/2.. (hd/2 is a multiple of 4 for 64/72/128).
+__global__ __launch_bounds__(256) void qkv_rope_fwd_kernel(const bf16_t* qkv, const float* cosb, const float* sinb,
+                                                           const bf16_t* v0, const bf16_t* lamp, bf16_t* q,
+                                                           bf16_t* k, bf16_t* v, int B, int L, int H, int hd,
+                                                           int hdp) {
+  const int upt = H * (hd >> 3);
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)B * L * upt) return;
+  const long tok = gid / upt;
+  const int u = (int)(gid % upt);
+  const int hq = hd >> 3, hh = u / hq, i = u % hq, half = hd >> 1;
+  const int b = (int)(tok / L), l = (int)(tok % L);
+  const int D = H * hd;
+  const bf16_t* src = qkv + tok * 3 * D + hh * hd + 4 * i;
+  const long dst = (((long)b * H + hh) * L + l) * hdp + 4 * i;
+  const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosb + (long)l * half + 4 * i);
+  const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinb + (long)l * half + 4 * i);
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(src + which * D);
+    const u32x2 hi = *reinterpret_cast<const u32x2*>(src + which * D + half);
+    const float x1[4] = {bflo(lo[0]), bfhi(lo[0]), bflo(lo[1]), bfhi(lo[1])};
+    const float x2[4] = {bflo(hi[0]), bfhi(hi[0]), bflo(hi[1]), bfhi(hi[1])};
+    float y1[4], y2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      y1[e] = x1[e] * c4[e] + x2[e] * s4[e];
+      y2[e] = x2[e] * c4[e] - x1[e] * s4[e];
+    }
+    bf16_t* o = (which == 0 ? q : k) + dst;
+    u32x2 w1 = {pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])};
+    u32x2 w2 = {pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])};
+    *reinterpret_cast<u32x2*>(o) = w1;
+    *reinterpret_cast<u32x2*>(o + half) = w2;
+  }
+  {
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(src + 2 * D);
+    const u32x2 hi = *reinterpret_cast<const u32x2*>(src + 2 * D + half);
+    u32x2 w1 = lo, w2 = hi;
+    if (v0) {
+      const float lam = bf2f(*lamp);
+      const u32x2 a = *reinterpret_cast<const u32x2*>(v0 + dst);
+      const u32x2 c = *reinterpret_cast<const u32x2*>(v0 + dst + half);
+      // reference (bf16 tensors): lam*v rounds, (1-lam) rounds, (1-lam)*v0 rounds, sum rounds
+      const float oml = bf2f(f2bf(1.0f - lam));
+      auto mix = [&](unsigned vr, unsigned v0r) {
+        const float a0 = bf2f(f2bf(lam * bflo(vr))) + bf2f(f2bf(oml * bflo(v0r)));
+        const float a1 = bf2f(f2bf(lam * bfhi(vr))) + bf2f(f2bf(oml * bfhi(v0r)));
+        return pack_bf2(a0, a1);
+      };
+      w1[0] = mix(lo[0], a[0]); w1[1] = mix(lo[1], a[1]);
+      w2[0] = mix(hi[0], c[0]); w2[1] = mix(hi[1], c[1]);
+    }
+    *reinterpret_cast<u32x2*>(v + dst) = w1;
+    *reinterpret_cast<u32x2*>(v + dst + half) = w2;
+  }
+  // zero the pad columns hd..hdp of this (token, head)
+  const int npad = (hdp - hd) >> 2;
+  if (i < npad) {
+    const long pd = (((long)b * H + hh) * L + l) * hdp + hd + 4 * i;
+    const u32x2 z = {0u, 0u};
+    *reinterpret_cast<u32x2*>(q + pd) = z;
+    *reinterpret_cast<u32x2*>(k + pd) = z;
+    *reinterpret_cast<u32x2*>(v + pd) = z;
+  }
+}
+
+// backward of the above
+__global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* dq, const bf16_t* dk, const bf16_t* dv,
+                                                           const float* cosb, const float* sinb,
+                                                           const bf16_t* qkv_raw, const bf16_t* v0,
+                                                           const bf16_t* lamp, float* dv0_acc, float* dlam,
+                                                           bf16_t* dqkv, int mix, int add_dv0, int B, int L, int H,
+                                                           int hd, int hdp) {
+  __shared__ float red[4];
+  const int upt = H * (hd >> 3);
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  float dl = 0.f;
+  if (gid < (long)B * L * upt) {
+    const long tok = gid / upt;
+    const int u = (int)(gid % upt);
+    const int hq = hd >> 3, hh = u / hq, i = u % hq, half = hd >> 1;
+    const int b = (int)(tok / L), l = (int)(tok % L);
+    const int D = H * hd;
+    bf16_t* dstp = dqkv + tok * 3 * D + hh * hd + 4 * i;
+    const long src = (((long)b * H + hh) * L + l) * hdp + 4 * i;
+    const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosb + (long)l * half + 4 * i);
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinb + (long)l * half + 4 * i);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const bf16_t* g = (which == 0 ? dq : dk) + src;
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(g);
+      const u32x2 hi = *reinterpret_cast<const u32x2*>(g + half);
+      const float g1[4] = {bflo(lo[0]), bfhi(lo[0]), bflo(lo[1]), bfhi(lo[1])};
+      const float g2[4] = {bflo(hi[0]), bfhi(hi[0]), bflo(hi[1]), bfhi(hi[1])};
+      float d1[4], d2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d1[e] = g1[e] * c4[e] - g2[e] * s4[e];
+        d2[e] = g1[e] * s4[e] + g2[e] * c4[e];
+      }
+      u32x2 w1 = {pack_bf2(d1[0], d1[1]), pack_bf2(d1[2], d1[3])};
+      u32x2 w2 = {pack_bf2(d2[0], d2[1]), pack_bf2(d2[2], d2[3])};
+      *reinterpret_cast<u32x2*>(dstp + which * D) = w1;
+      *reinterpret_cast<u32x2*>(dstp + which * D + half) = w2;
+    }
+    {
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(dv + src);
+      const u32x2 hi = *reinterpret_cast<const u32x2*>(dv + src + half);
+      float g[8] = {bflo(lo[0]), bfhi(lo[0]), bflo(lo[1]), bfhi(lo[1]), bflo(hi[0]), bfhi(hi[0]), bflo(hi[1]), bfhi(hi[1])};
+      float* acc1 = dv0_acc + src;
+      float* acc2 = dv0_acc + src + half;
+      if (mix) {
+        const float lam = bf2f(*lamp);
+        const float oml = 1.0f - lam;
+        const u32x2 r1 = *reinterpret_cast<const u32x2*>(qkv_raw + tok * 3 * D + 2 * D + hh * hd + 4 * i);
+        const u32x2 r2 = *reinterpret_cast<const u32x2*>(qkv_raw + tok * 3 * D + 2 * D + hh * hd + 4 * i + half);
+        const u32x2 a1 = *reinterpret_cast<const u32x2*>(v0 + src);
+        const u32x2 a2 = *reinterpret_cast<const u32x2*>(v0 + src + half);
+        const float vr[8] = {bflo(r1[0]), bfhi(r1[0]), bflo(r1[1]), bfhi(r1[1]), bflo(r2[0]), bfhi(r2[0]), bflo(r2[1]), bfhi(r2[1])};
+        const float vz[8] = {bflo(a1[0]), bfhi(a1[0]), bflo(a1[1]), bfhi(a1[1]), bflo(a2[0]), bfhi(a2[0]), bflo(a2[1]), bfhi(a2[1])};
+        f32x4 o1 = *reinterpret_cast<f32x4*>(acc1), o2 = *reinterpret_cast<f32x4*>(acc2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dl += g[e] * (vr[e] - vz[e]);
+          if (e < 4) o1[e] += oml * g[e]; else o2[e - 4] += oml * g[e];
+          g[e] *= lam;
+        }
+        *reinterpret_cast<f32x4*>(acc1) = o1;
+        *reinterpret_cast<f32x4*>(acc2) = o2;
+      } else if (add_dv0) {
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(acc1), o2 = *reinterpret_cast<const f32x4*>(acc2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[e] += o1[e]; g[e + 4] += o2[e]; }
+      }
+      u32x2 w1 = {pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3])};
+      u32x2 w2 = {pack_bf2(g[4], g[5]), pack_bf2(g[6], g[7])};
+      *reinterpret_cast<u32x2*>(dstp + 2 * D) = w1;
+      *reinterpret_cast<u32x2*>(dstp + 2 * D + half) = w2;
+    }
+  }
+  if (mix) {
+    dl = wave_sum(dl);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dl;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dlam, red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+// ------------------------------------------------------------------ small-M linears ------
+// y[b,n] = sum_k act(x[b,k]) W[n,k] + bias[n]; one wave per output column, M <= 16 rows.
+// (time_embed model.py:318-322, adaLN_modulation model.py:89-91, final_modulation 339-341)
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* x, const bf16_t* W, const bf16_t* bias,
+                                                               float* y, int M, int N, int K, int act_in) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) acc[b] = 0.f;
+  for (int c = lane; c < (K >> 3); c += 64) {
+    float wv[8];
+    unpack8(*reinterpret_cast<const u32x4*>(W + (long)n * K + c * 8), wv);
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+      if (b < M) {
+        float xv[8];
+        load8f(x + (long)b * K + c * 8, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[b] += (act_in ? silu_f(xv[e]) : xv[e]) * wv[e];
+      }
+  }
+  const float bs = bias ? bf2f(bias[n]) : 0.f;
+#pragma unroll
+  for (int b = 0; b < 16; ++b)
+    if (b < M) {
+      const float s = wave_sum(acc[b]);
+      if (lane == 0) y[(long)b * N + n] = s + bs;
+    }
+}
+
+// dW[n,k] = sum_b dy[b,n] act(x[b,k]);  dbias[n] = sum_b dy[b,n]   (thread per (n, k-chunk))
+__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* dy, const float* x, float* dW,
+                                                              float* dbias, int M, int N, int K, int act_in) {
+  const int kc = K >> 3;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)N * kc) return;
+  const int n = (int)(gid / kc), c = (int)(gid % kc);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  float sb = 0.f;
+  for (int b = 0; b < M; ++b) {
+    const float g = dy[(long)b * N + n];
+    sb += g;
+    float xv[8];
+    load8f(x + (long)b * K + c * 8, xv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += g * (act_in ? silu_f(xv[e]) : xv[e]);
+  }
+  float* o = dW + (long)n * K + c * 8;
+  *reinterpret_cast<f32x4*>(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+  *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  if (c == 0 && dbias) dbias[n] = sb;
+}
+
+// dx[b,k] += act'(x[b,k]) * sum_n dy[b,n] W[n,k]; block = one 64-row slab of W, thread = k-chunk
+__global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* dy, const float* x, const bf16_t* W,
+                                                              float* dx, int M, int N, int K, int act_in) {
+  const int kc = K >> 3;
+  const int n0 = blockIdx.x * 64, n1 = min(N, n0 + 64);
+  for (int c = threadIdx.x; c < kc; c += 256) {
+    for (int b0 = 0; b0 < M; b0 += 4) {
+      float acc[4][8];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[bb][e] = 0.f;
+      for (int n = n0; n < n1; ++n) {
+        float wv[8];
+        unpack8(*reinterpret_cast<const u32x4*>(W + (long)n * K + c * 8), wv);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+          if (b0 + bb < M) {
+            const float g = dy[(long)(b0 + bb) * N + n];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[bb][e] += g * wv[e];
+          }
+      }
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+        if (b0 + bb < M) {
+          float xv[8];
+          if (act_in) load8f(x + (long)(b0 + bb) * K + c * 8, xv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            atomicAdd(dx + (long)(b0 + bb) * K + c * 8 + e, act_in ? acc[bb][e] * dsilu_f(xv[e]) : acc[bb][e]);
+        }
+    }
+  }
+}
+
+// model.py:12-22 (+ the .to(bf16) of model.py:374-376)
+__global__ void timestep_embedding_kernel(const float* t, float* out, int B, int D) {
+  const int half = D >> 1;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= B * half) return;
+  const int b = gid / half, i = gid % half;
+  const float f = expf(-9.210340371976184f * (float)i / (float)half);
+  const float a = t[b] * f;
+  out[(long)b * D + i] = bf2f(f2bf(cosf(a)));
+  out[(long)b * D + half + i] = bf2f(f2bf(sinf(a)));
+}
+
+// --------------------------------------------------------------- patchify / unpatchify ---
+// model.py:182-186: token (h w t), feature (c dt dh dw). thread = one (token, c, dt, dh) -> p elements
+__global__ void patchify_kernel(const bf16_t* x, bf16_t* out, int B, int C, int T, int H, int W, int pt, int p) {
+  const int t = T / pt, h = H / p, w = W / p;
+  const int fpt = C * pt * p;  // feature groups of p elements per token
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long ntok = (long)B * h * w * t;
+  if (gid >= ntok * fpt) return;
+  const long tok = gid / fpt;
+  int f = (int)(gid % fpt);
+  const int dh = f % p; f /= p;
+  const int dt = f % pt; f /= pt;
+  const int c = f;
+  long r = tok;
+  const int ti = (int)(r % t); r /= t;
+  const int wi = (int)(r % w); r /= w;
+  const int hi = (int)(r % h); r /= h;
+  const int b = (int)r;
+  const bf16_t* src = x + ((((long)b * C + c) * T + ti * pt + dt) * H + hi * p + dh) * W + wi * p;
+  bf16_t* dst = out + tok * (fpt * p) + ((c * pt + dt) * p + dh) * p;
+  for (int dw = 0; dw < p; ++dw) dst[dw] = src[dw];
+}
+
+// model.py:392-401: y[b,(h w t),(p1 p2 p3 c)] <-> out[b,c,(t p3),(h p1),(w p2)]; thread = one out element
+template <bool BWD>
+__global__ void unpatchify_kernel(const bf16_t* in, bf16_t* outp, int B, int C, int T, int H, int W, int pt, int p) {
+  const int t = T / pt, h = H / p, w = W / p;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * C * (t * pt) * (h * p) * (w * p);
+  if (gid >= total) return;
+  long r = gid;
+  const int x = (int)(r % (w * p)); r /= (w * p);
+  const int yy = (int)(r % (h * p)); r /= (h * p);
+  const int tt = (int)(r % (t * pt)); r /= (t * pt);
+  const int c = (int)(r % C); r /= C;
+  const int b = (int)r;
+  const int wi = x / p, p2 = x % p, hi = yy / p, p1 = yy % p, ti = tt / pt, p3 = tt % pt;
+  const long tok = (((long)b * h + hi) * w + wi) * t + ti;
+  const long tokidx = tok * ((long)p * p * pt * C) + (((p1 * p + p2) * pt + p3) * C + c);
+  // image index over the full [B,C,T,H,W] tensor (T,H,W may exceed t*pt.. when not divisible)
+  const long img = ((((long)b * C + c) * T + tt) * H + yy) * W + x;
+  if (BWD) outp[tokidx] = in[img];
+  else outp[img] = in[tokidx];
+}
+
+// model.py:362: x[b, 0:R, :] = register_tokens
+__global__ void fill_registers_kernel(const bf16_t* reg, bf16_t* x, long bs, int B, int R, int D) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)B * R * D) return;
+  const int b = (int)(gid / ((long)R * D));
+  const long rd = gid % ((long)R * D);
+  x[(long)b * bs + rd] = reg[rd];
+}
+__global__ void registers_bwd_kernel(const bf16_t* dx, long bs, float* dreg, int B, int R, int D) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)R * D) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += bf2f(dx[(long)b * bs + gid]);
+  dreg[gid] += s;
+}
+
+// ---------------------------------------------------------------- noising + loss ---------
+// train.py:115-117 in bf16 with the reference's rounding points: (1-t) rounds, each product
+// rounds, the sum rounds.
+__global__ void noise_kernel(const bf16_t* x, const bf16_t* n, const float* t, bf16_t* zt, bf16_t* v, int B,
+                             long per) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)B * per) return;
+  const int b = (int)(gid / per);
+  const float tb = t[b];
+  const float omt = bf2f(f2bf(1.0f - tb));
+  const float xv = bf2f(x[gid]), nv = bf2f(n[gid]);
+  const float a = bf2f(f2bf(xv * omt)), c = bf2f(f2bf(nv * tb));
+  zt[gid] = f2bf(a + c);
+  v[gid] = f2bf(xv - nv);
+}
+
+// train.py:121-125: fp32 MSE per sample -> batch mean; also emits d(loss)/d(out) in bf16
+__global__ __launch_bounds__(256) void flow_loss_kernel(const bf16_t* v, const bf16_t* out, float* loss,
+                                                        float* per_sample, bf16_t* dout, float gscale, int B,
+                                                        long per, int blocks_per_sample) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const long base = (long)b * per;
+  const float k = 2.0f * gscale / ((float)B * (float)per);
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)blocks_per_sample * 256) {
+    const float d = bf2f(out[base + i]) - bf2f(v[base + i]);
+    s += d * d;
+    if (dout) dout[base + i] = f2bf(d * k);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = (red[0] + red[1] + red[2] + red[3]) / (float)per;
+    atomicAdd(per_sample + b, tot);
+    atomicAdd(loss, tot / (float)B);
+  }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* s, bf16_t* d, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    float f[8];
+    load8f(s + i, f);
+    *reinterpret_cast<u32x4*>(d + i) = pack8(f);
+  } else {
+    for (long j = i; j < n; ++j) d[j] = f2bf(s[j]);
+  }
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* s, float* d, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) d[i] = bf2f(s[i]);
+}
+
+inline int ok() { return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH; }
+inline int rows_per_block_for(int L) {
+  int rpb = (L + 63) / 64;  // <= 64 blocks per sample
+  return rpb < 4 ? 4 : rpb;
+}
+
+}  // namespace
+
+#define NC_DISPATCH(D, CALL)                       \
+  do {                                             \
+    const int nc_ = ((D) / 8 + 63) / 64;           \
+    if (nc_ == 1) { CALL(1); }                     \
+    else if (nc_ == 2) { CALL(2); }                \
+    else if (nc_ == 3) { CALL(3); }                \
+    else if (nc_ == 4) { CALL(4); }                \
+    else return VDS_ERR_UNSUPPORTED;               \
+  } while (0)
+
+extern "C" int vds_rmsnorm_mod_fwd(const void* x, int64_t ldx, const void* w, const float* mod, int64_t ldmod,
+                                   int32_t shift_col, int32_t scale_col, void* y, int64_t ldy, float* rstd,
+                                   int32_t B, int32_t L, int32_t D, float eps, vds_stream_t stream) {
+  if (!x || !mod || !y || !rstd || (D & 7) || (ldx & 7) || (ldy & 7) || (shift_col & 3) || (scale_col & 3) || (ldmod & 3))
+    return VDS_ERR_ARG;
+  const long rows = (long)B * L;
+  hipStream_t s = (hipStream_t)stream;
+#define CALL(NC)                                                                                              \
+  hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,          \
+                     (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, \
+                     (bf16_t*)y, (long)ldy, rstd, B, L, D, eps)
+  NC_DISPATCH(D, CALL);
+#undef CALL
+  return ok();
+}
+
+extern "C" int vds_rmsnorm_mod_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* w,
+                                   const float* mod, int64_t ldmod, int32_t shift_col, int32_t scale_col,
+                                   const float* rstd, const void* dres, int64_t lddres, void* dx, int64_t lddx,
+                                   float* dmod, float* dw, int32_t B, int32_t L, int32_t D, vds_stream_t stream) {
+  if (!dy || !x || !mod || !rstd || !dx || !dmod || (D & 7) || (lddy & 7) || (ldx & 7) || (lddx & 7)) return VDS_ERR_ARG;
+  if (w && !dw) return VDS_ERR_ARG;
+  const int rpb = rows_per_block_for(L);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((L + rpb - 1) / rpb, B);
+#define CALL(NC)                                                                                                \
+  hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NC>), grid, dim3(256), 0, s, (const bf16_t*)dy, (long)lddy,         \
+                     (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, rstd, \
+                     (const bf16_t*)dres, (long)lddres, (bf16_t*)dx, (long)lddx, dmod, w ? dw : nullptr, B, L, D, rpb)
+  NC_DISPATCH(D, CALL);
+#undef CALL
+  return ok();
+}
+
+extern "C" int vds_gate_bwd(const void* dxn, int64_t lddxn, const void* y, int64_t ldy, const float* mod,
+                            int64_t ldmod, int32_t gate_col, void* dy, int64_t lddy, float* dmod, float* dbias,
+                            int32_t B, int32_t L, int32_t D, vds_stream_t stream) {
+  if (!dxn || !y || !mod || !dy || !dmod || (D & 7)) return VDS_ERR_ARG;
+  const int rpb = rows_per_block_for(L);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((L + rpb - 1) / rpb, B);
+#define CALL(NC)                                                                                             \
+  hipLaunchKernelGGL((gate_bwd_kernel<NC>), grid, dim3(256), 0, s, (const bf16_t*)dxn, (long)lddxn,           \
+                     (const bf16_t*)y, (long)ldy, mod, (long)ldmod, gate_col, (bf16_t*)dy, (long)lddy, dmod, \
+                     dbias, B, L, D, rpb)
+  NC_DISPATCH(D, CALL);
+#undef CALL
+  return ok();
+}
+
+extern "C" int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M, int32_t N, vds_stream_t stream) {
+  if (!x || !out || (N & 7) || (ldx & 7)) return VDS_ERR_ARG;
+  const int rpb = M > 8192 ? (M + 127) / 128 : 64;
+  dim3 grid((N / 8 + 63) / 64, (M + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, out, M, N, rpb);
+  return ok();
+}
+
+extern "C" int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float* sinb, const void* v0,
+                                const void* lam, void* q, void* k, void* v, int32_t B, int32_t L, int32_t H,
+                                int32_t hd, int32_t hdp, vds_stream_t stream) {
+  if (!qkv || !cosb || !sinb || !q || !k || !v || (hd & 7) || hdp < hd || (hdp & 3)) return VDS_ERR_ARG;
+  if (v0 && !lam) return VDS_ERR_ARG;
+  if (((hdp - hd) >> 2) > (hd >> 3)) return VDS_ERR_UNSUPPORTED;
+  const long n = (long)B * L * H * (hd >> 3);
+  hipLaunchKernelGGL(qkv_rope_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (bf16_t*)q, (bf16_t*)k,
+                     (bf16_t*)v, B, L, H, hd, hdp);
+  return ok();
+}
+
+extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, const float* cosb,
+                                const float* sinb, const void* qkv_raw, const void* v0, const void* lam,
+                                float* dv0_acc, float* dlam, void* dqkv, int32_t mix, int32_t add_dv0, int32_t B,
+                                int32_t L, int32_t H, int32_t hd, int32_t hdp, vds_stream_t stream) {
+  if (!dq || !dk || !dv || !cosb || !sinb || !dqkv || (hd & 7)) return VDS_ERR_ARG;
+  if (mix && (!qkv_raw || !v0 || !lam || !dv0_acc || !dlam)) return VDS_ERR_ARG;
+  if (add_dv0 && !dv0_acc) return VDS_ERR_ARG;
+  const long n = (long)B * L * H * (hd >> 3);
+  hipLaunchKernelGGL(qkv_rope_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw,
+                     (const bf16_t*)v0, (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp);
+  return ok();
+}
+
+extern "C" int vds_small_linear_fwd(const float* x, const void* W, const void* bias, float* y, int32_t M,
+                                    int32_t N, int32_t K, int32_t act_in, vds_stream_t stream) {
+  if (!x || !W || !y || M < 1 || M > 16 || (K & 7)) return VDS_ERR_ARG;
+  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
+                     (const bf16_t*)W, (const bf16_t*)bias, y, M, N, K, act_in);
+  return ok();
+}
+
+extern "C" int vds_small_linear_bwd(const float* dy, const float* x, const void* W, float* dW, float* dbias,
+                                    float* dx, int32_t M, int32_t N, int32_t K, int32_t act_in, vds_stream_t stream) {
+  if (!dy || !x || M < 1 || M > 16 || (K & 7)) return VDS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dW) {
+    const long n = (long)N * (K >> 3);
+    hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, x, dW, dbias, M, N, K, act_in);
+  }
+  if (dx) {
+    if (!W) return VDS_ERR_ARG;
+    hipLaunchKernelGGL(small_linear_dx_kernel, dim3((N + 63) / 64), dim3(256), 0, s, dy, x, (const bf16_t*)W, dx, M, N, K, act_in);
+  }
+  return ok();
+}
+
+extern "C" int vds_timestep_embedding(const float* t, float* out, int32_t B, int32_t D, vds_stream_t stream) {
+  if (!t || !out || (D & 1)) return VDS_ERR_ARG;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * (D / 2) + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out, B, D);
+  return ok();
+}
+
+extern "C" int vds_patchify(const void* latent, void* patches, int32_t B, int32_t C, int32_t T, int32_t H,
+                            int32_t W, int32_t pt, int32_t p, vds_stream_t stream) {
+  if (!latent || !patches || pt < 1 || p < 1) return VDS_ERR_ARG;
+  const long n = (long)B * (H / p) * (W / p) * (T / pt) * C * pt * p;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)latent, (bf16_t*)patches, B, C, T, H, W, pt, p);
+  return ok();
+}
+
+extern "C" int vds_unpatchify(const void* y, void* out, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                              int32_t pt, int32_t p, vds_stream_t stream) {
+  if (!y || !out || (T % pt) || (H % p) || (W % p)) return VDS_ERR_ARG;
+  const long n = (long)B * C * T * H * W;
+  hipLaunchKernelGGL((unpatchify_kernel<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)y, (bf16_t*)out, B, C, T, H, W, pt, p);
+  return ok();
+}
+
+extern "C" int vds_unpatchify_bwd(const void* dout, void* dy, int32_t B, int32_t C, int32_t T, int32_t H,
+                                  int32_t W, int32_t pt, int32_t p, vds_stream_t stream) {
+  if (!dout || !dy || (T % pt) || (H % p) || (W % p)) return VDS_ERR_ARG;
+  const long n = (long)B * C * T * H * W;
+  hipLaunchKernelGGL((unpatchify_kernel<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dout, (bf16_t*)dy, B, C, T, H, W, pt, p);
+  return ok();
+}
+
+extern "C" int vds_fill_registers(const void* reg, void* x, int64_t batch_stride, int32_t B, int32_t R, int32_t D,
+                                  vds_stream_t stream) {
+  if (!reg || !x) return VDS_ERR_ARG;
+  const long n = (long)B * R * D;
+  hipLaunchKernelGGL(fill_registers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)reg, (bf16_t*)x, (long)batch_stride, B, R, D);
+  return ok();
+}
+
+extern "C" int vds_registers_bwd(const void* dx, int64_t batch_stride, float* dreg, int32_t B, int32_t R, int32_t D,
+                                 vds_stream_t stream) {
+  if (!dx || !dreg) return VDS_ERR_ARG;
+  const long n = (long)R * D;
+  hipLaunchKernelGGL(registers_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dx, (long)batch_stride, dreg, B, R, D);
+  return ok();
+}
+
+extern "C" int vds_noise_latents(const void* x, const void* noise, const float* t, void* z_t, void* v, int32_t B,
+                                 int64_t per_sample, vds_stream_t stream) {
+  if (!x || !noise || !t || !z_t || !v) return VDS_ERR_ARG;
+  const long n = (long)B * per_sample;
+  hipLaunchKernelGGL(noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)noise, t, (bf16_t*)z_t, (bf16_t*)v, B, (long)per_sample);
+  return ok();
+}
+
+extern "C" int vds_flow_loss(const void* v, const void* out, float* loss_out, float* per_sample, void* dout,
+                             float gscale, int32_t B, int64_t per_sample_n, vds_stream_t stream) {
+  if (!v || !out || !loss_out || !per_sample) return VDS_ERR_ARG;
+  int bps = (int)((per_sample_n + 256 * 16 - 1) / (256 * 16));
+  if (bps < 1) bps = 1;
+  if (bps > 256) bps = 256;
+  hipLaunchKernelGGL(flow_loss_kernel, dim3(bps, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v,
+                     (const bf16_t*)out, loss_out, per_sample, (bf16_t*)dout, gscale, B, (long)per_sample_n, bps);
+  return ok();
+}
+
+extern "C" int vds_cast_f32_bf16(const float* src, void* dst, int64_t n, vds_stream_t stream) {
+  if (!src || !dst) return VDS_ERR_ARG;
+  if (n == 0) return VDS_OK;
+  const long thr = (n + 7) / 8;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+  return ok();
+}
+
+extern "C" int vds_cast_bf16_f32(const void* src, float* dst, int64_t n, vds_stream_t stream) {
+  if (!src || !dst) return VDS_ERR_ARG;
+  if (n == 0) return VDS_OK;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, (long)n);
+  return ok();
+}

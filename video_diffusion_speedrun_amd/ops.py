@@ -1,0 +1,288 @@
+"""Tensor-level wrappers over the C ABI (include/vds.h).  torch is used for device memory and
+the current HIP stream only; every computation below is a hand-written gfx950 kernel.
+
+All tensors must live on the GPU; bf16 activations are torch.bfloat16, statistics / modulation
+/ gradients of parameters are torch.float32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS_GELU, EPI_DGELU, EPI_F32, EPI_GATE_RES, EPI_STORE, VDS_NN, VDS_NT, VDS_TN,
+                   AttnArgs, GemmArgs, check)
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda, "vds ops need GPU tensors (no CPU fallback)"
+    return t.data_ptr()
+
+
+def _rows(t: torch.Tensor) -> Tuple[int, int]:
+    """(ld, cols) of a 2-D row-major view whose last dim is contiguous."""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.stride(0), t.shape[1]
+
+
+# ------------------------------------------------------------------------------- GEMM ----
+def gemm(layout: int, epi: int, M: int, N: int, K: int, A, lda, B, ldb, Cp=None, ldc=0, C2=None, ldc2=0,
+         bias=None, aux=None, ldaux=0, gate=None, ldgate=0, rows_per_batch=0, split_k=1):
+    a = GemmArgs(layout, epi, M, N, K, _p(A), lda, _p(B), ldb, _p(Cp), ldc, _p(C2), ldc2, _p(bias), _p(aux),
+                 ldaux, _p(gate), ldgate, rows_per_batch, split_k)
+    check(_lib.load().vds_gemm_bf16(C.byref(a), _stream()), f"vds_gemm_bf16(layout={layout},epi={epi},M={M},N={N},K={K})")
+
+
+def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x W^T + b.  x [M,K] bf16, W [N,K] bf16 -> y [M,N] bf16."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = out if out is not None else torch.empty(M, N, dtype=bf16, device=x.device)
+    gemm(VDS_NT, EPI_STORE, M, N, K, x, x.stride(0), W, W.stride(0), y, y.stride(0), bias=bias)
+    return y
+
+
+def linear_fwd_gelu(x, W, bias):
+    """(pre, act) = (x W^T + b, gelu_erf(pre))   (model.py:84-85)."""
+    M, K = x.shape
+    N = W.shape[0]
+    pre = torch.empty(M, N, dtype=bf16, device=x.device)
+    act = torch.empty(M, N, dtype=bf16, device=x.device)
+    gemm(VDS_NT, EPI_BIAS_GELU, M, N, K, x, x.stride(0), W, W.stride(0), pre, N, act, N, bias=bias)
+    return pre, act
+
+
+def linear_fwd_gate_res(x, W, bias, mod, gate_col: int, res, rows_per_batch: int):
+    """y = x W^T + b ; x_new = res + y * gate[b]  (model.py:138-139,159-160,165).
+    mod: f32 [B, 9D] modulation table, gate at column gate_col."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, dtype=bf16, device=x.device)
+    xn = torch.empty(M, N, dtype=bf16, device=x.device)
+    gate = mod[:, gate_col:]
+    gemm(VDS_NT, EPI_GATE_RES, M, N, K, x, x.stride(0), W, W.stride(0), y, N, xn, N, bias=bias, aux=res,
+         ldaux=res.stride(0), gate=gate, ldgate=mod.stride(0), rows_per_batch=rows_per_batch)
+    return y, xn
+
+
+def linear_dgrad(dy, W, pre: Optional[torch.Tensor] = None):
+    """dx = dy W  (dy [M,N], W [N,K] -> [M,K]); with `pre`: dx *= gelu'(pre) (fused)."""
+    M, N = dy.shape
+    K = W.shape[1]
+    dx = torch.empty(M, K, dtype=bf16, device=dy.device)
+    if pre is None:
+        gemm(VDS_NN, EPI_STORE, M, K, N, dy, dy.stride(0), W, W.stride(0), dx, K)
+    else:
+        gemm(VDS_NN, EPI_DGELU, M, K, N, dy, dy.stride(0), W, W.stride(0), dx, K, aux=pre, ldaux=pre.stride(0))
+    return dx
+
+
+def linear_wgrad(dy, x, dW: torch.Tensor, n_cu: int = 256):
+    """dW[N,K] (f32, pre-zeroed) += dy^T x   (dy [M,N], x [M,K]); split-K over the tokens."""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert dW.dtype == f32 and dW.shape[0] == N and dW.shape[-1] == K or dW.numel() == N * K
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    kt = (M + 63) // 64
+    split = max(1, min((2 * n_cu) // max(tiles, 1), kt // 4))
+    gemm(VDS_TN, EPI_F32, N, K, M, dy, dy.stride(0), x, x.stride(0), dW, K, split_k=split)
+
+
+# -------------------------------------------------------------------------- attention ----
+def _st(t):
+    assert t.stride(3) == 1
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def attn_fwd(q, k, v, o, lse):
+    """q [B,H,Lq,hd], k/v [B,H,Lk,hd], o [B,H,Lq,hd] strided views (last dim contiguous); lse f32 [B,H,Lq]."""
+    B, H, Lq, hd = q.shape
+    Lk = k.shape[2]
+    a = AttnArgs()
+    a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, hd
+    a.q, (a.q_sb, a.q_sh, a.q_sl) = _p(q), _st(q)
+    a.k, (a.k_sb, a.k_sh, a.k_sl) = _p(k), _st(k)
+    a.v, (a.v_sb, a.v_sh, a.v_sl) = _p(v), _st(v)
+    a.o, (a.o_sb, a.o_sh, a.o_sl) = _p(o), _st(o)
+    a.lse = _p(lse)
+    check(_lib.load().vds_attn_fwd(C.byref(a), _stream()), f"vds_attn_fwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
+
+
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta):
+    B, H, Lq, hd = q.shape
+    Lk = k.shape[2]
+    a = AttnArgs()
+    a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, hd
+    a.q, (a.q_sb, a.q_sh, a.q_sl) = _p(q), _st(q)
+    a.k, (a.k_sb, a.k_sh, a.k_sl) = _p(k), _st(k)
+    a.v, (a.v_sb, a.v_sh, a.v_sl) = _p(v), _st(v)
+    a.o, (a.o_sb, a.o_sh, a.o_sl) = _p(o), _st(o)
+    a.lse = _p(lse)
+    a.d_o, (a.do_sb, a.do_sh, a.do_sl) = _p(do), _st(do)
+    a.dq, (a.dq_sb, a.dq_sh, a.dq_sl) = _p(dq), _st(dq)
+    a.dk, (a.dk_sb, a.dk_sh, a.dk_sl) = _p(dk), _st(dk)
+    a.dv, (a.dv_sb, a.dv_sh, a.dv_sl) = _p(dv), _st(dv)
+    a.delta = _p(delta)
+    check(_lib.load().vds_attn_bwd(C.byref(a), _stream()), f"vds_attn_bwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
+
+
+def heads_view(t: torch.Tensor, B: int, L: int, H: int, hd: int, offset: int = 0) -> torch.Tensor:
+    """[B*L, ld] token-major buffer -> [B,H,L,hd] view of columns offset + h*hd + d."""
+    ld = t.stride(0)
+    return t.as_strided((B, H, L, hd), (L * ld, hd, ld, 1), t.storage_offset() + offset)
+
+
+# ---------------------------------------------------------- norm / modulation / gates ----
+def rmsnorm_mod_fwd(x, w, mod, shift_col, scale_col, B, L, eps=1e-6):
+    D = x.shape[1]
+    y = torch.empty(B * L, D, dtype=bf16, device=x.device)
+    rstd = torch.empty(B * L, dtype=f32, device=x.device)
+    check(_lib.load().vds_rmsnorm_mod_fwd(_p(x), x.stride(0), _p(w), _p(mod), mod.stride(0), shift_col, scale_col,
+                                          _p(y), D, _p(rstd), B, L, D, eps, _stream()), "vds_rmsnorm_mod_fwd")
+    return y, rstd
+
+
+def rmsnorm_mod_bwd(dy, x, w, mod, shift_col, scale_col, rstd, dres, dmod, dw, B, L):
+    D = x.shape[1]
+    dx = torch.empty(B * L, D, dtype=bf16, device=x.device)
+    check(_lib.load().vds_rmsnorm_mod_bwd(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(w), _p(mod), mod.stride(0),
+                                          shift_col, scale_col, _p(rstd), _p(dres),
+                                          dres.stride(0) if dres is not None else 0, _p(dx), D, _p(dmod), _p(dw),
+                                          B, L, D, _stream()), "vds_rmsnorm_mod_bwd")
+    return dx
+
+
+def gate_bwd(dxn, y, mod, gate_col, dmod, dbias, B, L):
+    D = y.shape[1]
+    dy = torch.empty(B * L, D, dtype=bf16, device=y.device)
+    check(_lib.load().vds_gate_bwd(_p(dxn), dxn.stride(0), _p(y), y.stride(0), _p(mod), mod.stride(0), gate_col,
+                                   _p(dy), D, _p(dmod), _p(dbias), B, L, D, _stream()), "vds_gate_bwd")
+    return dy
+
+
+def colsum(x, out):
+    M, N = x.shape
+    check(_lib.load().vds_colsum_bf16(_p(x), x.stride(0), _p(out), M, N, _stream()), "vds_colsum_bf16")
+
+
+# ----------------------------------------------------------------- qkv / rope / res-V ----
+def qkv_rope_fwd(qkv, cos, sin, v0, lam, B, L, H, hd, hdp):
+    q = torch.empty(B, H, L, hdp, dtype=bf16, device=qkv.device)
+    k = torch.empty_like(q)
+    v = torch.empty_like(q)
+    check(_lib.load().vds_qkv_rope_fwd(_p(qkv), _p(cos), _p(sin), _p(v0), _p(lam), _p(q), _p(k), _p(v), B, L, H, hd,
+                                       hdp, _stream()), "vds_qkv_rope_fwd")
+    return q, k, v
+
+
+def qkv_rope_bwd(dq, dk, dv, cos, sin, qkv_raw, v0, lam, dv0_acc, dlam, mix, add_dv0, B, L, H, hd, hdp):
+    dqkv = torch.empty(B * L, 3 * H * hd, dtype=bf16, device=dq.device)
+    check(_lib.load().vds_qkv_rope_bwd(_p(dq), _p(dk), _p(dv), _p(cos), _p(sin), _p(qkv_raw), _p(v0), _p(lam),
+                                       _p(dv0_acc), _p(dlam), _p(dqkv), int(mix), int(add_dv0), B, L, H, hd, hdp,
+                                       _stream()), "vds_qkv_rope_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------- small linears ----
+def small_linear_fwd(x, W, bias, act_in: int):
+    M, K = x.shape
+    N = W.shape[0]
+    assert x.dtype == f32 and x.is_contiguous() and W.is_contiguous()
+    y = torch.empty(M, N, dtype=f32, device=x.device)
+    check(_lib.load().vds_small_linear_fwd(_p(x), _p(W), _p(bias), _p(y), M, N, K, act_in, _stream()),
+          "vds_small_linear_fwd")
+    return y
+
+
+def small_linear_bwd(dy, x, W, dW, dbias, dx, act_in: int):
+    M, N = dy.shape
+    K = x.shape[1]
+    assert dy.is_contiguous() and x.is_contiguous()
+    check(_lib.load().vds_small_linear_bwd(_p(dy), _p(x), _p(W), _p(dW), _p(dbias), _p(dx), M, N, K, act_in,
+                                           _stream()), "vds_small_linear_bwd")
+
+
+def timestep_embedding(t, D):
+    B = t.shape[0]
+    out = torch.empty(B, D, dtype=f32, device=t.device)
+    check(_lib.load().vds_timestep_embedding(_p(t), _p(out), B, D, _stream()), "vds_timestep_embedding")
+    return out
+
+
+# ------------------------------------------------------------- patches / registers ----
+def patchify(x, pt, p):
+    B, Cc, T, H, W = x.shape
+    n = (T // pt) * (H // p) * (W // p)
+    out = torch.empty(B * n, Cc * pt * p * p, dtype=bf16, device=x.device)
+    check(_lib.load().vds_patchify(_p(x), _p(out), B, Cc, T, H, W, pt, p, _stream()), "vds_patchify")
+    return out
+
+
+def unpatchify(y, B, Cc, T, H, W, pt, p):
+    out = torch.empty(B, Cc, T, H, W, dtype=bf16, device=y.device)
+    check(_lib.load().vds_unpatchify(_p(y), _p(out), B, Cc, T, H, W, pt, p, _stream()), "vds_unpatchify")
+    return out
+
+
+def unpatchify_bwd(dout, pt, p):
+    B, Cc, T, H, W = dout.shape
+    n = (T // pt) * (H // p) * (W // p)
+    dy = torch.empty(B * n, Cc * pt * p * p, dtype=bf16, device=dout.device)
+    check(_lib.load().vds_unpatchify_bwd(_p(dout), _p(dy), B, Cc, T, H, W, pt, p, _stream()), "vds_unpatchify_bwd")
+    return dy
+
+
+def fill_registers(reg, x, batch_stride, B, R, D):
+    check(_lib.load().vds_fill_registers(_p(reg), _p(x), batch_stride, B, R, D, _stream()), "vds_fill_registers")
+
+
+def registers_bwd(dx, batch_stride, dreg, B, R, D):
+    check(_lib.load().vds_registers_bwd(_p(dx), batch_stride, _p(dreg), B, R, D, _stream()), "vds_registers_bwd")
+
+
+# ---------------------------------------------------------------- noising / loss ----
+def noise_latents(x, noise, t):
+    B = x.shape[0]
+    per = x.numel() // B
+    zt = torch.empty_like(x)
+    v = torch.empty_like(x)
+    check(_lib.load().vds_noise_latents(_p(x), _p(noise), _p(t), _p(zt), _p(v), B, per, _stream()),
+          "vds_noise_latents")
+    return zt, v
+
+
+def flow_loss(v, out, want_grad: bool, gscale: float = 1.0):
+    B = v.shape[0]
+    per = v.numel() // B
+    acc = torch.zeros(1 + B, dtype=f32, device=v.device)
+    dout = torch.empty_like(out) if want_grad else None
+    check(_lib.load().vds_flow_loss(_p(v), _p(out), _p(acc), _p(acc[1:]), _p(dout), gscale, B, per, _stream()),
+          "vds_flow_loss")
+    return acc[0], acc[1:], dout
+
+
+def cast_f32_bf16(src, dst):
+    check(_lib.load().vds_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "vds_cast_f32_bf16")
+
+
+def cast_bf16_f32(src, dst):
+    check(_lib.load().vds_cast_bf16_f32(_p(src), _p(dst), src.numel(), _stream()), "vds_cast_bf16_f32")
+
+
+def selftest_lanemaps(device="cuda"):
+    scratch = torch.zeros(2080 // 4 + 8, dtype=torch.int32, device=device)
+    check(_lib.load().vds_selftest_lanemaps(_p(scratch), _stream()), "vds_selftest_lanemaps")
+    torch.cuda.synchronize()
+    return scratch[512:520].tolist()
