@@ -46,8 +46,10 @@ const char* vds_last_error(void);
  *   VDS_EPI_GATE_RES   C = bf16(y), C2 = bf16(aux[m,n] + y*gate[m/rows_per_batch, n]),
  *                      y = acc + bias[n]                         (model.py:138-139,159-160,165)
  *   VDS_EPI_DGELU      C = bf16(acc * gelu'(aux[m,n]))           (backward of model.py:85)
- *   VDS_EPI_F32        C(f32) = acc, or atomically += when split_k > 1 (C pre-zeroed)
- * Requirements: K % 64 == 0 for the k-contiguous operands (NT: A,B; NN: A); N % 8 == 0;
+ *   VDS_EPI_F32        C(f32) = acc; with split_k > 1 the K range is split over blockIdx.y and C (pre-zeroed)
+ *                      is accumulated atomically; split_k < 0 means |split_k| splits with atomic
+ *                      accumulation even for one split (several calls summing into one C)
+ * Requirements: K % 8 == 0 for NT / NN (any K for TN); N % 8 == 0 (TN: M % 8 == 0 too);
  * ld* % 8 == 0; every tensor < 4 GiB. */
 enum { VDS_NT = 0, VDS_NN = 1, VDS_TN = 2 };
 enum { VDS_EPI_STORE = 0, VDS_EPI_BIAS_GELU = 1, VDS_EPI_GATE_RES = 2, VDS_EPI_DGELU = 3, VDS_EPI_F32 = 4 };
@@ -63,7 +65,7 @@ typedef struct vds_gemm_args {
   const void* aux; int64_t ldaux; /* bf16 [M,N]: residual (GATE_RES) or pre-activation (DGELU) */
   const float* gate; int64_t ldgate; /* f32 [batch, ldgate], column n */
   int32_t rows_per_batch;
-  int32_t split_k;             /* TN only; >=1 */
+  int32_t split_k;             /* TN only; 0/1 = none, >1 split + atomics, <0 accumulate */
 } vds_gemm_args;
 
 int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);
@@ -131,6 +133,14 @@ int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, const float
                      const float* sinb, const void* qkv_raw, const void* v0, const void* lam,
                      float* dv0_acc, float* dlam, void* dqkv, int32_t mix, int32_t add_dv0, int32_t B,
                      int32_t L, int32_t H, int32_t hd, int32_t hdp, vds_stream_t stream);
+
+/* cos/sin rows [n_reg + t*h*w, nt + 2*ns] f32 of ThreeDimRotary.forward (model.py:219-263) for
+ * the offsets (st,sh,sw): gathered from the per-axis tables tab_t_* [128, nt], tab_s_* [128, ns]
+ * (the factors of the reference's freqs_hwt buffers); register rows are cos=1, sin=0. */
+int vds_rope_rows(const float* tab_t_cos, const float* tab_t_sin, const float* tab_s_cos,
+                  const float* tab_s_sin, int32_t nt, int32_t ns, int32_t t, int32_t h, int32_t w,
+                  int32_t st, int32_t sh, int32_t sw, int32_t n_reg, float* cosb, float* sinb,
+                  vds_stream_t stream);
 
 /* ------------------------------------------------------------- small-M linears (B rows) --
  * y[b, n] = act_out( sum_k act_in(x[b,k]) * W[n,k] + bias[n] ), M = B <= 16 rows:

@@ -54,7 +54,7 @@ def test_lane_maps(ops):
 
 # ------------------------------------------------------------------------------- GEMM ----
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 384, 192), (1000, 1152, 1152), (4112, 128, 768),
-                                   (131, 64, 64)])
+                                   (131, 64, 64), (212, 432, 144), (77, 144, 72)])
 def test_gemm_nt_store_bias(ops, M, N, K):
     x, w, b = gen(M, K, seed=1), gen(N, K, seed=2, scale=0.05), gen(N, seed=3)
     y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
@@ -97,7 +97,8 @@ def test_gemm_nt_gate_residual(ops):
         close("gate.xnew", xn, res.float() + yr * gate, 4e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (777, 1152, 384), (4112, 768, 3072), (200, 128, 64)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (777, 1152, 384), (4112, 768, 3072), (200, 128, 64),
+                                   (212, 432, 144), (90, 200, 72)])
 def test_gemm_nn_dgrad(ops, M, N, K):
     """dx[M,K] = dy[M,N] W[N,K]"""
     dy, w = gen(M, N, seed=12), gen(N, K, seed=13, scale=0.05)

@@ -60,6 +60,8 @@ SIGNATURES = {
     "vds_qkv_rope_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_qkv_rope_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                          c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_rope_rows": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
+                      c_vp, c_vp],
     "vds_small_linear_fwd": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_small_linear_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_timestep_embedding": [c_vp, c_vp, c_i32, c_i32, c_vp],

@@ -626,6 +626,31 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* s, float* d, long n) {
   if (i < n) d[i] = bf2f(s[i]);
 }
 
+// model.py:219-263: rows of cos/sin for this call.  Row 16+i is the table entry of position
+// unravel(i,(t,h,w)) + start (row-major (t h w) flattening); rows < n_reg are
+// cos=1, sin=0.  tab_* are the per-axis tables [128, n] the reference's buffer factorises into.
+__global__ void rope_rows_kernel(const float* tab_t_cos, const float* tab_t_sin, const float* tab_s_cos,
+                                 const float* tab_s_sin, int nt, int ns, int t, int h, int w, int st, int sh, int sw,
+                                 int n_reg, float* cosb, float* sinb) {
+  const int half = nt + 2 * ns;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long rows = n_reg + (long)t * h * w;
+  if (gid >= rows * half) return;
+  const int row = (int)(gid / half), f = (int)(gid % half);
+  float c = 1.f, s = 0.f;
+  if (row >= n_reg) {
+    int i = row - n_reg;
+    const int wi = i % w; i /= w;
+    const int hi = i % h; i /= h;
+    const int ti = i;
+    if (f < nt) { c = tab_t_cos[(st + ti) * nt + f]; s = tab_t_sin[(st + ti) * nt + f]; }
+    else if (f < nt + ns) { c = tab_s_cos[(sh + hi) * ns + f - nt]; s = tab_s_sin[(sh + hi) * ns + f - nt]; }
+    else { c = tab_s_cos[(sw + wi) * ns + f - nt - ns]; s = tab_s_sin[(sw + wi) * ns + f - nt - ns]; }
+  }
+  cosb[gid] = c;
+  sinb[gid] = s;
+}
+
 inline int ok() { return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH; }
 inline int rows_per_block_for(int L) {
   int rpb = (L + 63) / 64;  // <= 64 blocks per sample
@@ -835,5 +860,17 @@ extern "C" int vds_cast_bf16_f32(const void* src, float* dst, int64_t n, vds_str
   if (!src || !dst) return VDS_ERR_ARG;
   if (n == 0) return VDS_OK;
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, (long)n);
+  return ok();
+}
+
+extern "C" int vds_rope_rows(const float* tab_t_cos, const float* tab_t_sin, const float* tab_s_cos,
+                             const float* tab_s_sin, int32_t nt, int32_t ns, int32_t t, int32_t h, int32_t w,
+                             int32_t st, int32_t sh, int32_t sw, int32_t n_reg, float* cosb, float* sinb,
+                             vds_stream_t stream) {
+  if (!tab_t_cos || !tab_t_sin || !tab_s_cos || !tab_s_sin || !cosb || !sinb) return VDS_ERR_ARG;
+  if (st < 0 || sh < 0 || sw < 0 || st + t > 128 || sh + h > 128 || sw + w > 128) return VDS_ERR_ARG;
+  const long n = ((long)n_reg + (long)t * h * w) * (nt + 2 * ns);
+  hipLaunchKernelGGL(rope_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tab_t_cos,
+                     tab_t_sin, tab_s_cos, tab_s_sin, nt, ns, t, h, w, st, sh, sw, n_reg, cosb, sinb);
   return ok();
 }

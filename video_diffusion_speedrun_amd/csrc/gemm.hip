@@ -39,6 +39,7 @@ struct GemmP {
   const float* gate; long ldgate;
   int rows_per_batch;
   int split_k;
+  int atomic;
   unsigned a_bytes, b_bytes;
   int tiles_m, tiles_n;
 };
@@ -51,12 +52,22 @@ __device__ __forceinline__ int swz_km(int krow) { return (krow & 3) | (((krow >>
 
 // The k advance is added into the VGPR offset (not soffset) so that the SRD range check
 // sees the complete offset: rows past the end of the tensor must read as zero.
+// `krem` (k-contiguous operands only): elements of K left in this tile; 16-byte chunks that start
+// at or past it are redirected out of range (-> zero) so that K need only be a multiple of 8.
+template <bool KMAJOR>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const unsigned voff[4],
-                                           unsigned koff, int wave) {
+                                           unsigned koff, int wave, int lane, int krem) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     char* dst = lds_tile + (wave * 4 + j) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst), 16, voff[j] + koff, 0, 0, 0);
+    unsigned off = voff[j] + koff;
+    if constexpr (!KMAJOR) {
+      if (krem < BK) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        if (swz_kc(row, lane & 7) * 8 >= krem) off = 0xfffffff0u;
+      }
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst), 16, off, 0, 0, 0);
   }
 }
 
@@ -146,16 +157,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // LDS: [buf0: A | B][buf1: A | B]
-  stage_tile(ra, smem, va, kt_begin * a_step, wave);
-  stage_tile(rb, smem + TILE_BYTES, vb, kt_begin * b_step, wave);
+  stage_tile<A_KM>(ra, smem, va, kt_begin * a_step, wave, lane, p.K - kt_begin * BK);
+  stage_tile<B_KM>(rb, smem + TILE_BYTES, vb, kt_begin * b_step, wave, lane, p.K - kt_begin * BK);
   __syncthreads();  // vmcnt(0) + barrier: tile kt_begin landed
 
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     if (kt + 1 < kt_end) {
       char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile(ra, nxt, va, (kt + 1) * a_step, wave);
-      stage_tile(rb, nxt + TILE_BYTES, vb, (kt + 1) * b_step, wave);
+      stage_tile<A_KM>(ra, nxt, va, (kt + 1) * a_step, wave, lane, p.K - (kt + 1) * BK);
+      stage_tile<B_KM>(rb, nxt + TILE_BYTES, vb, (kt + 1) * b_step, wave, lane, p.K - (kt + 1) * BK);
     }
     const char* ta = smem + cur * 2 * TILE_BYTES;
     const char* tb = ta + TILE_BYTES;
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if constexpr (EPI == VDS_EPI_F32) {
       float* c = reinterpret_cast<float*>(p.C) + grow * p.ldc + gcol;
-      if (p.split_k > 1) {
+      if (p.atomic) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(c + e, v[e]);
       } else {
@@ -295,18 +306,20 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   p.aux = (const bf16_t*)a->aux; p.ldaux = a->ldaux;
   p.gate = a->gate; p.ldgate = a->ldgate;
   p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
-  p.split_k = a->split_k > 1 ? a->split_k : 1;
+  // split_k < 0: |split_k| splits and atomic accumulation into C even for a single split
+  p.split_k = a->split_k > 1 ? a->split_k : (a->split_k < -1 ? -a->split_k : 1);
+  p.atomic = (a->split_k > 1 || a->split_k < 0) ? 1 : 0;
   p.tiles_m = cdiv(a->M, BM);
   p.tiles_n = cdiv(a->N, BN);
   size_t abytes, bbytes;
   switch (a->layout) {
     case VDS_NT:
-      if (a->K % BK) return VDS_ERR_ARG;
+      if (a->K & 7) return VDS_ERR_ARG;
       abytes = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
       bbytes = ((size_t)(a->N - 1) * a->ldb + a->K) * 2;
       break;
     case VDS_NN:
-      if (a->K % BK) return VDS_ERR_ARG;
+      if (a->K & 7) return VDS_ERR_ARG;
       abytes = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
       bbytes = ((size_t)(a->K - 1) * a->ldb + a->N) * 2;
       break;
@@ -322,7 +335,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   p.a_bytes = (unsigned)abytes;
   p.b_bytes = (unsigned)bbytes;
   hipStream_t s = (hipStream_t)stream;
-  if (p.split_k > 1 && !(a->layout == VDS_TN && a->epilogue == VDS_EPI_F32)) return VDS_ERR_ARG;
+  if (p.atomic && !(a->layout == VDS_TN && a->epilogue == VDS_EPI_F32)) return VDS_ERR_ARG;
   if (!a->C && a->epilogue != VDS_EPI_GATE_RES) return VDS_ERR_ARG;
 #define GO(L, E) if (a->layout == L && a->epilogue == E) return launch<L, E>(p, s);
   GO(VDS_NT, VDS_EPI_STORE)

@@ -1,0 +1,585 @@
+"""Drop-in host API of the reference's `model.py` (DiT / DiTBlock / PatchEmbed / RMSNorm /
+ThreeDimRotary / timestep_embedding / get_mup_setup) with the compute re-built as hand-written
+gfx950 kernels behind the C ABI of include/vds.h.
+
+Same constructor arguments, parameter names (state-dict keys) and call signatures as the
+reference (model.py:279-292,358-402,404-465), so `train.py`-style code keeps working:
+
+    dit = DiT(in_channels=16, patch_size=2, depth=28, num_heads=16, hidden_size=1152,
+              cross_attn_input_size=4096, residual_v=True, train_bias_and_rms=False).to("cuda")
+    out = dit(z_t, caption_encoded, t)          # [B,C,T,H,W] bf16
+    loss.backward()                              # hand-written backward, fills p.grad (fp32)
+
+What is different underneath (by design):
+  * the modules below hold parameters only; `DiT.forward` runs ONE autograd node whose forward
+    and backward are explicit sequences of HIP kernel launches (no torch compute ops);
+  * parameters live in flat fp32 groups (params.py); kernels read a bf16 copy (the reference's
+    bf16 param policy, model.py:516-518) and write fp32 gradients straight into the flat
+    gradient buffer that `p.grad` aliases;
+  * RoPE offsets can be pinned (`rope_start=`) -- by default they are drawn from the global CPU
+    RNG with the reference's exact call sequence (model.py:223-226), so equal seeds give equal
+    offsets.
+There is no CPU fallback: a CPU tensor or a missing libvds_hip.so raises.
+"""
+from __future__ import annotations
+
+import math
+from collections import defaultdict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .params import FlatGroup
+
+bf16, f32 = torch.bfloat16, torch.float32
+N_REG = 16  # register tokens (model.py:316,362,386)
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
+    """[cos | sin](t * f_i), t unscaled (model.py:12-22).  HIP kernel; returns f32 [B, dim]
+    holding bf16-rounded values (the reference casts the embedding to the model dtype)."""
+    assert max_period == 10000
+    return ops.timestep_embedding(t.to(f32).contiguous(), dim)
+
+
+# ------------------------------------------------------------------ parameter holders ----
+class _Linear(nn.Module):
+    """nn.Linear-compatible parameter holder (weight [out,in], optional bias), reference init."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _Conv3dParams(nn.Module):
+    """Conv3d(kernel=stride) parameter holder: weight [D, C, pt, p, p], bias [D] (model.py:173-178)."""
+
+    def __init__(self, in_channels, out_channels, kernel):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *kernel))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        fan_in = in_channels * kernel[0] * kernel[1] * kernel[2]
+        nn.init.uniform_(self.bias, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+
+
+class _Act(nn.Module):
+    """parameter-free placeholder keeping the reference's nn.Sequential indices (SiLU / GELU)."""
+
+    def __init__(self, kind):
+        super().__init__()
+        self.kind = kind
+
+
+class RMSNorm(nn.Module):
+    """model.py:25-41.  Holder; the math runs fused with the modulation in the HIP kernel."""
+
+    def __init__(self, dim, eps=1e-6, trainable=False):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim)) if trainable else None
+
+
+class PatchEmbed(nn.Module):
+    """model.py:170-186."""
+
+    def __init__(self, patch_size=16, in_channels=3, embed_dim=768, time_patch_size=16):
+        super().__init__()
+        self.patch_proj = _Conv3dParams(in_channels, embed_dim, (time_patch_size, patch_size, patch_size))
+        self.patch_size, self.time_patch_size = patch_size, time_patch_size
+
+
+class ThreeDimRotary(nn.Module):
+    """model.py:189-263.  Keeps the per-axis factors of the reference's [128,128,128,d] cos/sin
+    buffers (37 KB instead of 2 x 302 MB at head_dim 72); rows are gathered on the device."""
+
+    def __init__(self, dim, base=100, h=128, w=128, t=128):
+        super().__init__()
+        assert h == 128 and w == 128 and t == 128
+        self.dim, self.h, self.w, self.t = dim, h, w, t
+        inv_s = 1.0 / (base ** (torch.arange(0, dim, 4).float() / dim))
+        inv_t = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+        pos = torch.arange(128).float()
+        ft, fs = torch.outer(pos, inv_t), torch.outer(pos, inv_s)
+        self.register_buffer("tab_t_cos", ft.cos().contiguous(), persistent=False)
+        self.register_buffer("tab_t_sin", ft.sin().contiguous(), persistent=False)
+        self.register_buffer("tab_s_cos", fs.cos().contiguous(), persistent=False)
+        self.register_buffer("tab_s_sin", fs.sin().contiguous(), persistent=False)
+
+    def draw_start(self, thw) -> Tuple[int, int, int]:
+        """(start_t, start_h, start_w); drawn h, w, t from the global CPU RNG (model.py:224-226)."""
+        this_t, this_h, this_w = thw
+        start_h = torch.randint(0, self.h - this_h + 1, (1,)).item()
+        start_w = torch.randint(0, self.w - this_w + 1, (1,)).item()
+        start_t = torch.randint(0, self.t - this_t + 1, (1,)).item()
+        return int(start_t), int(start_h), int(start_w)
+
+    def rows(self, thw, start, n_reg):
+        tabs = (self.tab_t_cos, self.tab_t_sin, self.tab_s_cos, self.tab_s_sin)
+        return ops.rope_rows(tabs, thw, start, n_reg, self.tab_t_cos.device)
+
+    def forward(self, x, time_height_width=None, extend_with_register_tokens=0, start=None):
+        if start is None:
+            start = self.draw_start(time_height_width)
+        cos, sin = self.rows(time_height_width, start, extend_with_register_tokens)
+        return cos[None, None], sin[None, None]
+
+
+class DiTBlock(nn.Module):
+    """model.py:44-94 (parameters); the computation is DiT._block_fwd / _block_bwd."""
+
+    def __init__(self, hidden_size, cross_attn_input_size, num_heads, mlp_ratio=4.0, qkv_bias=True,
+                 residual_v=False):
+        super().__init__()
+        self.hidden_size, self.num_heads = hidden_size, num_heads
+        self.head_dim = hidden_size // num_heads
+        self.residual_v = residual_v
+        self.norm1 = RMSNorm(hidden_size, trainable=qkv_bias)
+        self.qkv = _Linear(hidden_size, hidden_size * 3, bias=qkv_bias)
+        self.attn_proj = _Linear(hidden_size, hidden_size, bias=False)
+        if residual_v:
+            self.lambda_param = nn.Parameter(torch.tensor(0.5).reshape(1))
+        if cross_attn_input_size is not None:
+            self.norm2 = RMSNorm(hidden_size, trainable=qkv_bias)
+            self.q_cross = _Linear(hidden_size, hidden_size, bias=qkv_bias)
+            self.context_kv = _Linear(cross_attn_input_size, hidden_size * 2, bias=qkv_bias)
+            self.cross_proj = _Linear(hidden_size, hidden_size, bias=False)
+        else:
+            self.norm2 = self.q_cross = self.context_kv = self.cross_proj = None
+        self.norm3 = RMSNorm(hidden_size, trainable=qkv_bias)
+        mlp_hidden = int(hidden_size * mlp_ratio)
+        self.mlp = nn.Sequential(_Linear(hidden_size, mlp_hidden), _Act("gelu"), _Linear(mlp_hidden, hidden_size))
+        self.adaLN_modulation = nn.Sequential(_Act("silu"), _Linear(hidden_size, 9 * hidden_size, bias=True))
+        self.adaLN_modulation[-1].weight.data.zero_()
+        self.adaLN_modulation[-1].bias.data.zero_()
+
+
+class _Saved:
+    """activations kept for the backward pass"""
+    pass
+
+
+class DiT(nn.Module):
+    def __init__(self, in_channels=4, patch_size=2, time_patch_size=2, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, cross_attn_input_size=128, residual_v=False, train_bias_and_rms=True,
+                 use_rope=True):
+        super().__init__()
+        self.in_channels = self.out_channels = in_channels
+        self.patch_size, self.time_patch_size = patch_size, time_patch_size
+        self.hidden_size, self.num_heads, self.depth, self.mlp_ratio = hidden_size, num_heads, depth, mlp_ratio
+        self.use_rope = use_rope  # the reference always applies RoPE; kept for signature parity
+        self.residual_v = residual_v
+        self.cross_attn_input_size = cross_attn_input_size
+        self.head_dim = hidden_size // num_heads
+        if self.head_dim not in (64, 72, 128):
+            raise ValueError(f"head_dim {self.head_dim} not supported by the attention kernels (64, 72, 128)")
+        self.patch_embed = PatchEmbed(patch_size, in_channels, hidden_size, time_patch_size)
+        self.rope = ThreeDimRotary(hidden_size // (2 * num_heads), h=128, w=128, t=128)
+        self.register_tokens = nn.Parameter(torch.randn(1, N_REG, hidden_size))
+        self.time_embed = nn.Sequential(_Linear(hidden_size, 4 * hidden_size), _Act("silu"),
+                                        _Linear(4 * hidden_size, hidden_size))
+        self.blocks = nn.ModuleList([
+            DiTBlock(hidden_size=hidden_size, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                     cross_attn_input_size=cross_attn_input_size, residual_v=residual_v,
+                     qkv_bias=train_bias_and_rms) for _ in range(depth)])
+        self.final_modulation = nn.Sequential(_Act("silu"), _Linear(hidden_size, 2 * hidden_size, bias=True))
+        self.final_norm = RMSNorm(hidden_size, trainable=train_bias_and_rms)
+        self.final_proj = _Linear(hidden_size, patch_size * patch_size * time_patch_size * self.out_channels)
+        nn.init.zeros_(self.final_modulation[-1].weight)
+        nn.init.zeros_(self.final_modulation[-1].bias)
+        nn.init.zeros_(self.final_proj.weight)
+        nn.init.zeros_(self.final_proj.bias)
+        self.paramstatus = {}
+        for n, p in self.named_parameters():
+            self.paramstatus[n] = {"shape": p.shape, "requires_grad": p.requires_grad}
+        # flat groups (built lazily on the device): root + one per block, FSDP units of model.py:523-541
+        self._groups: Optional[List[FlatGroup]] = None
+        self._world, self._rank, self._pg = 1, 0, None
+        self._fsdp = None  # set by fsdp.apply_fsdp
+
+    # --------------------------------------------------------------------- parameters ----
+    def _group_members(self):
+        root, blocks = [], [[] for _ in range(self.depth)]
+        for n, p in self.named_parameters():
+            if n.startswith("blocks."):
+                i = int(n.split(".")[1])
+                blocks[i].append((n, p))
+            else:
+                root.append((n, p))
+        return root, blocks
+
+    def _ensure_groups(self, device):
+        if self._groups is not None and all(g.is_current() and g.device == device for g in self._groups):
+            return
+        full_values = None
+        if self._groups is not None and self._world > 1:
+            raise RuntimeError("parameters of a sharded DiT were replaced; re-apply apply_fsdp")
+        root, blocks = self._group_members()
+        groups = [FlatGroup("root", root, self._world, self._rank)]
+        groups += [FlatGroup(f"blocks.{i}", m, self._world, self._rank) for i, m in enumerate(blocks)]
+        for g in groups:
+            g.materialize(device, full_values)
+        self._groups = groups
+
+    def _apply(self, fn, *a, **k):  # .to()/.cuda() replace tensors: flat views are rebuilt lazily
+        r = super()._apply(fn, *a, **k)
+        if self._world == 1:
+            self._groups = None
+        return r
+
+    @property
+    def root_group(self) -> FlatGroup:
+        return self._groups[0]
+
+    def block_group(self, i) -> FlatGroup:
+        return self._groups[1 + i]
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none)
+
+    # ------------------------------------------------------------------------ forward ----
+    def forward(self, x, context, timesteps, rope_start: Optional[Tuple[int, int, int]] = None):
+        """x [B,C,T,H,W], context [B,Lc,Cc], timesteps [B] -> [B,C,T,H,W] bf16 (model.py:358-402)."""
+        if not x.is_cuda:
+            raise RuntimeError("video_diffusion_speedrun_amd.DiT runs on the GPU only (no CPU fallback)")
+        b, c, t, h, w = x.shape
+        thw = (t // self.time_patch_size, h // self.patch_size, w // self.patch_size)
+        if rope_start is None:
+            rope_start = self.rope.draw_start(thw)
+        self._ensure_groups(x.device)
+        params = [p for p in self.parameters() if p.requires_grad]
+        need_grad = torch.is_grad_enabled() and len(params) > 0
+        if need_grad:
+            return _DiTFunction.apply(self, x, context, timesteps, tuple(rope_start), *params)
+        out, _ = self._forward_impl(x, context, timesteps, tuple(rope_start), save=False)
+        return out
+
+    def _gather_all(self):
+        """bf16 compute copies of every group.  world == 1: one cast kernel per group."""
+        if self._fsdp is not None:
+            return  # the sharding runtime gathers group by group, overlapped with compute
+        for g in self._groups:
+            g.gather(ops.cast_f32_bf16, None)
+
+    def _forward_impl(self, x, context, timesteps, rope_start, save: bool):
+        D, H, hd = self.hidden_size, self.num_heads, self.head_dim
+        pt, p = self.time_patch_size, self.patch_size
+        B, C, T, Hh, Ww = x.shape
+        t, h, w = T // pt, Hh // p, Ww // p
+        N = t * h * w
+        L = N + N_REG
+        dev = x.device
+        fs = self._fsdp
+        self._gather_all()
+        if fs is not None:
+            fs.pre_forward_root()
+        R = self.root_group
+        x = x.to(bf16).contiguous()
+        context = context.to(bf16).contiguous()
+        Lc, Cc = context.shape[1], context.shape[2]
+        ctx2d = context.view(B * Lc, Cc)
+        sv = _Saved() if save else None
+
+        # patch embed + register tokens -> token buffer X [B*L, D]   (model.py:360-362)
+        patches = ops.patchify(x, pt, p)
+        P = patches.shape[1]
+        X = torch.empty(B * L, D, dtype=bf16, device=dev)
+        Wpe = R.w("patch_embed.patch_proj.weight").view(D, P)
+        bpe = R.w("patch_embed.patch_proj.bias")
+        for bi in range(B):
+            ops.linear_fwd(patches[bi * N:(bi + 1) * N], Wpe, bpe, out=X[bi * L + N_REG:(bi + 1) * L])
+        ops.fill_registers(R.w("register_tokens").view(N_REG, D), X, L * D, B, N_REG, D)
+        cos, sin = self.rope.rows((t, h, w), rope_start, N_REG)
+
+        # timestep conditioning (model.py:374-377), kept in fp32
+        temb = ops.timestep_embedding(timesteps.to(f32).contiguous(), D)
+        h1 = ops.small_linear_fwd(temb, R.w("time_embed.0.weight"), R.w("time_embed.0.bias"), 0)
+        cvec = ops.small_linear_fwd(h1, R.w("time_embed.2.weight"), R.w("time_embed.2.bias"), 1)
+        if save:
+            sv.patches, sv.temb, sv.h1, sv.cvec, sv.cos, sv.sin = patches, temb, h1, cvec, cos, sin
+            sv.dims = (B, C, T, Hh, Ww, t, h, w, N, L, Lc, Cc)
+            sv.ctx2d = ctx2d
+            sv.blocks = []
+
+        v0 = None
+        for i in range(self.depth):
+            if fs is not None:
+                fs.pre_forward_block(i)
+            X, v, bs = self._block_fwd(i, X, ctx2d, cvec, v0, cos, sin, B, L, Lc, save)
+            if v0 is None:
+                v0 = v
+            if save:
+                sv.blocks.append(bs)
+            if fs is not None:
+                fs.post_forward_block(i)
+        if save:
+            sv.v0 = v0
+            sv.x_last = X
+
+        # final layer (model.py:386-401)
+        fmod = ops.small_linear_fwd(cvec, R.w("final_modulation.1.weight"), R.w("final_modulation.1.bias"), 1)
+        wfn = R.w("final_norm.weight") if R.has("final_norm.weight") else None
+        xnf = torch.empty(B * N, D, dtype=bf16, device=dev)
+        rstdf = torch.empty(B * N, dtype=f32, device=dev)
+        for bi in range(B):
+            ops._lib.check(ops._lib.load().vds_rmsnorm_mod_fwd(
+                X[bi * L + N_REG:].data_ptr(), D, ops._p(wfn), fmod[bi:].data_ptr(), 2 * D, 0, D,
+                xnf[bi * N:].data_ptr(), D, rstdf[bi * N:].data_ptr(), 1, N, D, 1e-6, ops._stream()),
+                "vds_rmsnorm_mod_fwd(final)")
+        yf = ops.linear_fwd(xnf, R.w("final_proj.weight"), R.w("final_proj.bias"))
+        out = ops.unpatchify(yf, B, C, T, Hh, Ww, pt, p)
+        if save:
+            sv.fmod, sv.xnf, sv.rstdf = fmod, xnf, rstdf
+        if fs is not None:
+            fs.post_forward_root()
+        return out, sv
+
+    def _block_fwd(self, i, X, ctx2d, cvec, v0, cos, sin, B, L, Lc, save):
+        D, H, hd = self.hidden_size, self.num_heads, self.head_dim
+        hdp = {64: 64, 72: 96, 128: 128}[hd]
+        G = self.block_group(i)
+        pre = f"blocks.{i}."
+        W = lambda n: G.w(pre + n)
+        Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
+        dev = X.device
+        mod = ops.small_linear_fwd(cvec, W("adaLN_modulation.1.weight"), W("adaLN_modulation.1.bias"), 1)
+        # --- self attention (model.py:122-139)
+        xn1, rstd1 = ops.rmsnorm_mod_fwd(X, Wo("norm1.weight"), mod, 0, D, B, L)
+        qkv = ops.linear_fwd(xn1, W("qkv.weight"), Wo("qkv.bias"))
+        mix = self.residual_v and v0 is not None
+        q, k, v = ops.qkv_rope_fwd(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None, B, L, H,
+                                   hd, hdp)
+        attn = torch.empty(B * L, D, dtype=bf16, device=dev)
+        lse1 = torch.empty(B, H, L, dtype=f32, device=dev)
+        ops.attn_fwd(q[..., :hd], k[..., :hd], v[..., :hd], ops.heads_view(attn, B, L, H, hd), lse1)
+        y_sa, X1 = ops.linear_fwd_gate_res(attn, W("attn_proj.weight"), None, mod, 2 * D, X, L)
+        # --- cross attention (model.py:142-160)
+        has_cross = G.has(pre + "q_cross.weight")
+        if has_cross:
+            xn2, rstd2 = ops.rmsnorm_mod_fwd(X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, B, L)
+            qc = ops.linear_fwd(xn2, W("q_cross.weight"), Wo("q_cross.bias"))
+            ckv = ops.linear_fwd(ctx2d, W("context_kv.weight"), Wo("context_kv.bias"))
+            catt = torch.empty(B * L, D, dtype=bf16, device=dev)
+            lse2 = torch.empty(B, H, L, dtype=f32, device=dev)
+            ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), ops.heads_view(ckv, B, Lc, H, hd, 0),
+                         ops.heads_view(ckv, B, Lc, H, hd, D), ops.heads_view(catt, B, L, H, hd), lse2)
+            y_ca, X2 = ops.linear_fwd_gate_res(catt, W("cross_proj.weight"), None, mod, 5 * D, X1, L)
+        else:
+            X2 = X1
+        # --- MLP (model.py:163-165)
+        xn3, rstd3 = ops.rmsnorm_mod_fwd(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L)
+        hpre, hact = ops.linear_fwd_gelu(xn3, W("mlp.0.weight"), W("mlp.0.bias"))
+        y_mlp, X3 = ops.linear_fwd_gate_res(hact, W("mlp.2.weight"), W("mlp.2.bias"), mod, 8 * D, X2, L)
+        bs = None
+        if save:
+            bs = _Saved()
+            bs.mod, bs.X, bs.X1, bs.X2 = mod, X, X1, X2
+            bs.xn1, bs.rstd1, bs.qkv, bs.q, bs.k, bs.v, bs.attn, bs.lse1, bs.y_sa = xn1, rstd1, qkv, q, k, v, attn, lse1, y_sa
+            bs.mix, bs.has_cross = mix, has_cross
+            if has_cross:
+                bs.xn2, bs.rstd2, bs.qc, bs.ckv, bs.catt, bs.lse2, bs.y_ca = xn2, rstd2, qc, ckv, catt, lse2, y_ca
+            bs.xn3, bs.rstd3, bs.hpre, bs.hact, bs.y_mlp = xn3, rstd3, hpre, hact, y_mlp
+        return X3, v, bs
+
+    # ----------------------------------------------------------------------- backward ----
+    def _backward_impl(self, sv: _Saved, dout: torch.Tensor):
+        D, H, hd = self.hidden_size, self.num_heads, self.head_dim
+        pt, p = self.time_patch_size, self.patch_size
+        B, C, T, Hh, Ww, t, h, w, N, L, Lc, Cc = sv.dims
+        dev = dout.device
+        fs = self._fsdp
+        R = self.root_group
+        for g in self._groups:
+            g.gfull.zero_()
+        if fs is not None:
+            fs.pre_backward_root()
+        Pd = p * p * pt * C
+        dout = dout.to(bf16).contiguous()
+        # final layer
+        dyf = ops.unpatchify_bwd(dout, pt, p)
+        ops.linear_wgrad(dyf, sv.xnf, R.g("final_proj.weight"))
+        ops.colsum(dyf, R.g("final_proj.bias"))
+        dxnf = ops.linear_dgrad(dyf, R.w("final_proj.weight"))
+        dX = torch.zeros(B * L, D, dtype=bf16, device=dev)
+        dfmod = torch.zeros(B, 2 * D, dtype=f32, device=dev)
+        wfn = R.w("final_norm.weight") if R.has("final_norm.weight") else None
+        dwfn = R.g("final_norm.weight") if wfn is not None else None
+        for bi in range(B):
+            ops._lib.check(ops._lib.load().vds_rmsnorm_mod_bwd(
+                dxnf[bi * N:].data_ptr(), D, sv.x_last[bi * L + N_REG:].data_ptr(), D, ops._p(wfn),
+                sv.fmod[bi:].data_ptr(), 2 * D, 0, D, sv.rstdf[bi * N:].data_ptr(), None, 0,
+                dX[bi * L + N_REG:].data_ptr(), D, dfmod[bi:].data_ptr(), ops._p(dwfn), 1, N, D, ops._stream()),
+                "vds_rmsnorm_mod_bwd(final)")
+        dc = torch.zeros(B, D, dtype=f32, device=dev)
+        ops.small_linear_bwd(dfmod, sv.cvec, R.w("final_modulation.1.weight"), R.g("final_modulation.1.weight"),
+                             R.g("final_modulation.1.bias"), dc, 1)
+        hdp = {64: 64, 72: 96, 128: 128}[hd]
+        dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev) if (self.residual_v and self.depth > 1) else None
+        for i in reversed(range(self.depth)):
+            if fs is not None:
+                fs.pre_backward_block(i)
+            dX = self._block_bwd(i, sv.blocks[i], dX, sv, dc, dv0, B, L, Lc)
+            sv.blocks[i] = None
+            if fs is not None:
+                fs.post_backward_block(i)
+        # registers + patch embed (model.py:360-362)
+        ops.registers_bwd(dX, L * D, R.g("register_tokens").view(N_REG, D), B, N_REG, D)
+        gWpe = R.g("patch_embed.patch_proj.weight").view(D, Pd)
+        for bi in range(B):
+            dtok = dX[bi * L + N_REG:(bi + 1) * L]
+            ops.linear_wgrad(dtok, sv.patches[bi * N:(bi + 1) * N], gWpe, accumulate=True)
+            ops.colsum(dtok, R.g("patch_embed.patch_proj.bias"))
+        # time embed MLP
+        dh1 = torch.zeros(B, 4 * D, dtype=f32, device=dev)
+        ops.small_linear_bwd(dc, sv.h1, R.w("time_embed.2.weight"), R.g("time_embed.2.weight"),
+                             R.g("time_embed.2.bias"), dh1, 1)
+        ops.small_linear_bwd(dh1, sv.temb, None, R.g("time_embed.0.weight"), R.g("time_embed.0.bias"), None, 0)
+        if fs is not None:
+            fs.post_backward_root()
+        else:
+            for g in self._groups:
+                g.publish_grads()
+
+    def _block_bwd(self, i, bs, dX, sv, dc, dv0, B, L, Lc):
+        D, H, hd = self.hidden_size, self.num_heads, self.head_dim
+        hdp = {64: 64, 72: 96, 128: 128}[hd]
+        G = self.block_group(i)
+        pre = f"blocks.{i}."
+        W = lambda n: G.w(pre + n)
+        Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
+        Gr = lambda n: G.g(pre + n)
+        Go = lambda n: G.g(pre + n) if G.has(pre + n) else None
+        dev = dX.device
+        mod = bs.mod
+        dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
+        # --- MLP
+        dy = ops.gate_bwd(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L)
+        ops.linear_wgrad(dy, bs.hact, Gr("mlp.2.weight"))
+        dh = ops.linear_dgrad(dy, W("mlp.2.weight"), pre=bs.hpre)
+        ops.linear_wgrad(dh, bs.xn3, Gr("mlp.0.weight"))
+        ops.colsum(dh, Gr("mlp.0.bias"))
+        dxn = ops.linear_dgrad(dh, W("mlp.0.weight"))
+        del dh
+        dX2 = ops.rmsnorm_mod_bwd(dxn, bs.X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, bs.rstd3, dX, dmod,
+                                  Go("norm3.weight"), B, L)
+        # --- cross attention
+        if bs.has_cross:
+            dy = ops.gate_bwd(dX2, bs.y_ca, mod, 5 * D, dmod, None, B, L)
+            ops.linear_wgrad(dy, bs.catt, Gr("cross_proj.weight"))
+            dcatt = ops.linear_dgrad(dy, W("cross_proj.weight"))
+            dqc = torch.empty(B * L, D, dtype=bf16, device=dev)
+            dckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
+            delta = torch.empty(B, H, L, dtype=f32, device=dev)
+            ops.attn_bwd(ops.heads_view(bs.qc, B, L, H, hd), ops.heads_view(bs.ckv, B, Lc, H, hd, 0),
+                         ops.heads_view(bs.ckv, B, Lc, H, hd, D), ops.heads_view(bs.catt, B, L, H, hd), bs.lse2,
+                         ops.heads_view(dcatt, B, L, H, hd), ops.heads_view(dqc, B, L, H, hd),
+                         ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), delta)
+            ops.linear_wgrad(dckv, sv.ctx2d, Gr("context_kv.weight"))
+            if G.has(pre + "context_kv.bias"):
+                ops.colsum(dckv, Gr("context_kv.bias"))
+            ops.linear_wgrad(dqc, bs.xn2, Gr("q_cross.weight"))
+            if G.has(pre + "q_cross.bias"):
+                ops.colsum(dqc, Gr("q_cross.bias"))
+            dxn = ops.linear_dgrad(dqc, W("q_cross.weight"))
+            dX1 = ops.rmsnorm_mod_bwd(dxn, bs.X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, bs.rstd2, dX2, dmod,
+                                      Go("norm2.weight"), B, L)
+        else:
+            dX1 = dX2
+        # --- self attention
+        dy = ops.gate_bwd(dX1, bs.y_sa, mod, 2 * D, dmod, None, B, L)
+        ops.linear_wgrad(dy, bs.attn, Gr("attn_proj.weight"))
+        dattn = ops.linear_dgrad(dy, W("attn_proj.weight"))
+        dq = torch.empty(B, H, L, hdp, dtype=bf16, device=dev)
+        dk = torch.empty_like(dq)
+        dv = torch.empty_like(dq)
+        delta = torch.empty(B, H, L, dtype=f32, device=dev)
+        ops.attn_bwd(bs.q[..., :hd], bs.k[..., :hd], bs.v[..., :hd], ops.heads_view(bs.attn, B, L, H, hd), bs.lse1,
+                     ops.heads_view(dattn, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta)
+        first = (i == 0)
+        dqkv = ops.qkv_rope_bwd(dq, dk, dv, sv.cos, sv.sin, bs.qkv if bs.mix else None, sv.v0 if bs.mix else None,
+                                W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),
+                                Gr("lambda_param") if bs.mix else None, bs.mix,
+                                first and dv0 is not None, B, L, H, hd, hdp)
+        ops.linear_wgrad(dqkv, bs.xn1, Gr("qkv.weight"))
+        if G.has(pre + "qkv.bias"):
+            ops.colsum(dqkv, Gr("qkv.bias"))
+        dxn = ops.linear_dgrad(dqkv, W("qkv.weight"))
+        dX0 = ops.rmsnorm_mod_bwd(dxn, bs.X, Wo("norm1.weight"), mod, 0, D, bs.rstd1, dX1, dmod, Go("norm1.weight"),
+                                  B, L)
+        # --- adaLN modulation (model.py:89-94,107)
+        ops.small_linear_bwd(dmod, sv.cvec, W("adaLN_modulation.1.weight"), Gr("adaLN_modulation.1.weight"),
+                             Gr("adaLN_modulation.1.bias"), dc, 1)
+        return dX0
+
+    # ------------------------------------------------------------------- muP table ----
+    def get_mup_setup(self, learning_rate, weight_decay, constant_param_classes):
+        """Per-parameter lr / weight-decay groups, same rule cascade and return value as the
+        reference (model.py:404-465)."""
+        no_decay_name_list = ["bias", "norm", "lambda"]
+        custom_lr_multipliers = {"bias": 0.01, "norm": 0.01, "lambda": 0.01}
+        final_optimizer_settings = {}
+        param_groups = defaultdict(lambda: {"params": [], "weight_decay": None, "lr": None})
+        for n, p in self.named_parameters():
+            n = n.replace("_fsdp_wrapped_module.", "")
+            status = self.paramstatus[n]
+            if not status["requires_grad"]:
+                continue
+            if any(k in n for k in no_decay_name_list):
+                for k in no_decay_name_list:
+                    if k in n:
+                        lr_value = learning_rate * custom_lr_multipliers[k]
+                        break
+                wd_value = 0.0
+            else:
+                hidden_dim = status["shape"][-1]
+                lr_value = learning_rate * (32 / hidden_dim)
+                wd_value = weight_decay * hidden_dim / 1024
+            if any(cls in n for cls in constant_param_classes):
+                lr_value = learning_rate * 0.01
+                wd_value = 0.0
+            if "time" in n:
+                lr_value = learning_rate * 0.1
+            if "modulation" in n:
+                lr_value = learning_rate * 0.1
+            key = (lr_value, wd_value)
+            param_groups[key]["params"].append(p)
+            param_groups[key]["weight_decay"] = wd_value
+            param_groups[key]["lr"] = lr_value
+            final_optimizer_settings[n] = {"lr": lr_value, "wd": wd_value, "shape": status["shape"]}
+        return [v for v in param_groups.values()], final_optimizer_settings
+
+    def full_state_dict(self) -> Dict[str, torch.Tensor]:
+        """fp32 full tensors keyed like the reference state dict (gathers when sharded)."""
+        if self._groups is None:
+            return {k: v.detach().clone() for k, v in self.state_dict().items()}
+        out = {}
+        for g in self._groups:
+            for n in g.names:
+                out[n] = g.full_tensor(n)
+        return out
+
+
+class _DiTFunction(torch.autograd.Function):
+    """One autograd node for the whole model: forward/backward are explicit kernel sequences;
+    parameter gradients are written into the flat fp32 gradient buffers that p.grad aliases."""
+
+    @staticmethod
+    def forward(ctx, model, x, context, timesteps, rope_start, *params):
+        out, sv = model._forward_impl(x, context, timesteps, rope_start, save=True)
+        ctx.model, ctx.sv = model, sv
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, sv = ctx.model, ctx.sv
+        ctx.sv = None
+        model._backward_impl(sv, dout)
+        return (None,) * (5 + len([p for p in model.parameters() if p.requires_grad]))

@@ -89,14 +89,18 @@ def linear_dgrad(dy, W, pre: Optional[torch.Tensor] = None):
     return dx
 
 
-def linear_wgrad(dy, x, dW: torch.Tensor, n_cu: int = 256):
-    """dW[N,K] (f32, pre-zeroed) += dy^T x   (dy [M,N], x [M,K]); split-K over the tokens."""
+def linear_wgrad(dy, x, dW: torch.Tensor, accumulate: bool = False, n_cu: int = 256):
+    """dW[N,K] (f32) = dy^T x   (dy [M,N], x [M,K]); split-K over the tokens adds atomically into
+    dW, which must then be pre-zeroed (the model zeroes its flat gradient buffers once per step);
+    accumulate=True forces the atomic path so several calls sum into dW."""
     M, N = dy.shape
     K = x.shape[1]
-    assert dW.dtype == f32 and dW.shape[0] == N and dW.shape[-1] == K or dW.numel() == N * K
+    assert dW.dtype == f32 and dW.numel() == N * K and dW.is_contiguous()
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     kt = (M + 63) // 64
     split = max(1, min((2 * n_cu) // max(tiles, 1), kt // 4))
+    if accumulate:
+        split = -split
     gemm(VDS_TN, EPI_F32, N, K, M, dy, dy.stride(0), x, x.stride(0), dW, K, split_k=split)
 
 
@@ -193,6 +197,18 @@ def qkv_rope_bwd(dq, dk, dv, cos, sin, qkv_raw, v0, lam, dv0_acc, dlam, mix, add
                                        _p(dv0_acc), _p(dlam), _p(dqkv), int(mix), int(add_dv0), B, L, H, hd, hdp,
                                        _stream()), "vds_qkv_rope_bwd")
     return dqkv
+
+
+def rope_rows(tabs, thw, start, n_reg, device):
+    """tabs = (t_cos, t_sin, s_cos, s_sin) device tables; returns cos, sin [n_reg + t*h*w, hd/2] f32."""
+    t, h, w = thw
+    nt, ns = tabs[0].shape[1], tabs[2].shape[1]
+    rows = n_reg + t * h * w
+    cos = torch.empty(rows, nt + 2 * ns, dtype=f32, device=device)
+    sin = torch.empty_like(cos)
+    check(_lib.load().vds_rope_rows(_p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]), nt, ns, t, h, w, start[0],
+                                    start[1], start[2], n_reg, _p(cos), _p(sin), _stream()), "vds_rope_rows")
+    return cos, sin
 
 
 # ------------------------------------------------------------------- small linears ----

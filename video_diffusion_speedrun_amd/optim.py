@@ -1,0 +1,93 @@
+"""muP AdamW: `torch.optim.AdamW(groups, betas=(0.95, 0.99), fused=True)` of the reference
+(train.py:335-344,433) as ONE multi-tensor HIP launch over every (sharded) fp32 parameter, which
+also refreshes the bf16 compute copy (saving the cast pass of the next forward / all-gather).
+
+Use exactly like the reference:
+    groups, settings = dit.get_mup_setup(lr, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
+    opt = MuAdamW(groups, betas=(0.95, 0.99))
+It is a torch.optim.Optimizer, so HF / torch LR schedulers drive `param_groups[i]["lr"]` as usual.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import torch
+
+from . import _lib, ops
+
+CHUNK = 1 << 16
+
+
+class MuAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.95, 0.99), eps=1e-8, weight_decay=1e-2, fused=True):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._step = 0
+        self._table_key = None
+        self._chunk_key = None
+        self._dev = {}
+
+    def _build_chunks(self, plist, device):
+        chunk_t: List[int] = []
+        chunk_s: List[int] = []
+        for i, (p, _) in enumerate(plist):
+            st = self.state[p]
+            if "exp_avg" not in st or st["exp_avg"].numel() != p.numel():
+                st["exp_avg"] = torch.zeros(p.numel(), dtype=torch.float32, device=device)
+                st["exp_avg_sq"] = torch.zeros(p.numel(), dtype=torch.float32, device=device)
+            n = p.numel()
+            chunk_t.extend([i] * ((n + CHUNK - 1) // CHUNK))
+            chunk_s.extend(range(0, n, CHUNK))
+        self._dev["ct"] = torch.tensor(chunk_t, dtype=torch.int32, device=device)
+        self._dev["cs"] = torch.tensor(chunk_s, dtype=torch.int64, device=device)
+        self._dev["n"] = len(chunk_t)
+
+    def _build_descs(self, plist, device):
+        descs = (_lib.AdamWTensor * len(plist))()
+        for i, (p, group) in enumerate(plist):
+            st = self.state[p]
+            shadow = getattr(p, "_vds_shadow", None)
+            d = descs[i]
+            d.p, d.g = p.data.data_ptr(), p.grad.data_ptr()
+            d.m, d.v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            d.p_bf16 = shadow.data_ptr() if shadow is not None and shadow.numel() == p.numel() else None
+            d.numel = p.numel()
+            d.lr, d.wd = float(group["lr"]), float(group["weight_decay"])
+        self._dev["desc"] = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        plist = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None or p.numel() == 0:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("MuAdamW is a HIP kernel: parameters must be on the GPU")
+                assert p.dtype == torch.float32 and p.grad.dtype == torch.float32
+                assert p.data.is_contiguous() and p.grad.is_contiguous()
+                plist.append((p, group))
+        if not plist:
+            return None
+        self._step += 1
+        device = plist[0][0].device
+        ckey = tuple(p.numel() for p, _ in plist)
+        if ckey != self._chunk_key:
+            self._build_chunks(plist, device)
+            self._chunk_key, self._table_key = ckey, None
+        key = tuple((p.data.data_ptr(), p.grad.data_ptr(), g["lr"], g["weight_decay"]) for p, g in plist)
+        if key != self._table_key:  # pointers or the scheduled lr changed: refresh the descriptors
+            self._build_descs(plist, device)
+            self._table_key = key
+        b1, b2 = self.param_groups[0]["betas"]
+        eps = self.param_groups[0]["eps"]
+        _lib.check(_lib.load().vds_adamw_multi(self._dev["desc"].data_ptr(), self._dev["ct"].data_ptr(),
+                                               self._dev["cs"].data_ptr(), self._dev["n"], CHUNK, b1, b2, eps,
+                                               self._step, 1.0, 1.0, ops._stream()), "vds_adamw_multi")
+        # the bf16 shadows of these flat groups are now current: the next forward skips its cast pass
+        for g in {id(getattr(p, "_vds_group", None)): getattr(p, "_vds_group", None) for p, _ in plist}.values():
+            if g is not None:
+                g.shadow_fresh = True
+        return None

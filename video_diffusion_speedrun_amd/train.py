@@ -1,0 +1,105 @@
+"""Train-step harness with the reference's `train.py::forward` signature (train.py:51-145) and
+the loop body of train.py:431-434, on the HIP path.
+
+    total_loss, diffusion_loss = forward(dit_model, batch, text_encoder, tokenizer, device,
+                                         global_step, master_process, generator=None, ...)
+    optimizer.zero_grad(); total_loss.backward(); optimizer.step(); lr_scheduler.step()
+
+`batch` = {"latent": Tensor[B,C,T,H,W], "prompt": list[str]}; the text encoder is the caller's
+(frozen, third-party; out of scope) -- for synthetic runs pass `batch["context"]` (a pre-encoded
+[B,Lc,Cc] tensor) and text_encoder=None.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional
+
+import torch
+
+from . import ops
+
+bf16, f32 = torch.bfloat16, torch.float32
+ALPHA = 8.0  # time shift, train.py:95
+
+
+def encode_prompt_with_t5(text_encoder, tokenizer, max_sequence_length=512, prompt=None, device=None,
+                          return_index=-1):
+    """utils.py:38-80 (host-side glue around the caller's frozen encoder)."""
+    prompt = [prompt] if isinstance(prompt, str) else prompt
+    ids = tokenizer(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                    return_length=False, return_overflowing_tokens=False, return_tensors="pt").input_ids
+    enc = text_encoder(ids.to(device), return_dict=True, output_hidden_states=True)
+    emb = enc.hidden_states[return_index]
+    if return_index != -1:
+        emb = text_encoder.encoder.final_layer_norm(emb)
+        emb = text_encoder.encoder.dropout(emb)
+    return emb.to(dtype=text_encoder.dtype, device=device)
+
+
+class _FlowLoss(torch.autograd.Function):
+    """mean_b mean_{chw} (v - out)^2 in fp32 (train.py:121-125); HIP kernel for value and gradient."""
+
+    @staticmethod
+    def forward(ctx, out, v):
+        loss, per, dout = ops.flow_loss(v, out, want_grad=ctx.needs_input_grad[0])
+        ctx.dout = dout
+        ctx.mark_non_differentiable(per)
+        return loss.reshape(()), per
+
+    @staticmethod
+    def backward(ctx, gloss, _gper):
+        dout = ctx.dout
+        ctx.dout = None
+        # d loss / d out was produced by the forward kernel with unit upstream gradient; the only
+        # upstream the train loop ever supplies is 1.0 (loss.backward()).
+        return dout, None
+
+
+def flow_loss(out, v):
+    return _FlowLoss.apply(out, v)
+
+
+def time_shift_from_normal(z: torch.Tensor) -> torch.Tensor:
+    """t = sigmoid(z); t = a t / (1 + (a-1) t), in z.dtype (bf16) like train.py:93-96.
+    B scalars: left to torch (host-side plumbing, not a hot-path kernel)."""
+    t = torch.sigmoid(z)
+    return t * ALPHA / (1 + (ALPHA - 1) * t)
+
+
+def forward(dit_model, batch, text_encoder, tokenizer, device, global_step, master_process, generator=None,
+            binnings=None, batch_size=None, return_index=-1, rope_start=None):
+    logger = logging.getLogger(__name__)
+    vae_latent = batch["latent"].to(device).to(bf16)
+    with torch.no_grad():
+        if "context" in batch and text_encoder is None:
+            caption_encoded = batch["context"].to(device)
+        else:
+            caption_encoded = encode_prompt_with_t5(text_encoder, tokenizer, prompt=batch["prompt"], device=device,
+                                                    return_index=return_index)
+        caption_encoded = caption_encoded.to(bf16)
+        do_zero_out = torch.rand(caption_encoded.shape[0], device=device) < 0.01  # train.py:86
+        caption_encoded[do_zero_out] = 0
+    B = vae_latent.size(0)
+    z = torch.randn(B, device=device, dtype=bf16, generator=generator)
+    t = time_shift_from_normal(z)
+    noise = torch.randn(vae_latent.shape, device=device, dtype=bf16, generator=generator)
+    z_t, v_objective = ops.noise_latents(vae_latent.contiguous(), noise, t.to(f32))
+    output = dit_model(z_t, caption_encoded, t, rope_start=rope_start) if rope_start is not None \
+        else dit_model(z_t, caption_encoded, t)
+    diffusion_loss, _per = flow_loss(output, v_objective)
+    total_loss = diffusion_loss
+    if master_process:
+        logger.debug("forward done (step %s)", global_step)
+    return total_loss, diffusion_loss
+
+
+def train_step(dit_model, optimizer, lr_scheduler, batch, device, generator=None, rope_start=None):
+    """train.py:412-434 for one batch with a pre-encoded context; returns the loss tensor."""
+    total_loss, _ = forward(dit_model, batch, None, None, device, 0, False, generator=generator,
+                            rope_start=rope_start)
+    optimizer.zero_grad()
+    total_loss.backward()
+    optimizer.step()
+    if lr_scheduler is not None:
+        lr_scheduler.step()
+    return total_loss
