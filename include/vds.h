@@ -205,6 +205,19 @@ int vds_cast_f32_bf16(const float* src, void* dst, int64_t n, vds_stream_t strea
 /* bf16 -> f32 */
 int vds_cast_bf16_f32(const void* src, float* dst, int64_t n, vds_stream_t stream);
 
+/* ------------------------------------------------------------------ live profiling ----
+ * Per-kernel-class timing with HIP events recorded on the launch stream around each launch of
+ * an enabled class (bench.py's roofline leg).  Off by default (no events, no overhead).
+ * vds_prof_collect synchronises the recorded events, sums them per class and resets.
+ * flops / bytes are the ALGORITHMIC work of the recorded launches (per kernel). */
+enum { VDS_PROF_GEMM_NT = 0, VDS_PROF_GEMM_NN, VDS_PROF_GEMM_TN, VDS_PROF_ATTN_FWD, VDS_PROF_ATTN_BWD_DELTA,
+       VDS_PROF_ATTN_BWD_DKV, VDS_PROF_ATTN_BWD_DQ, VDS_PROF_RMSNORM_FWD, VDS_PROF_RMSNORM_BWD, VDS_PROF_ADAMW,
+       VDS_PROF_QKV_ROPE_FWD, VDS_PROF_QKV_ROPE_BWD, VDS_PROF_GATE_BWD, VDS_PROF_NCLASS };
+typedef struct vds_prof_stat { int64_t launches; double ms; double flops; double bytes; } vds_prof_stat;
+int vds_prof_enable(uint32_t class_mask);
+int vds_prof_collect(vds_prof_stat* out /* [VDS_PROF_NCLASS] */);
+const char* vds_prof_class_name(int cls);
+
 /* hardware self-test of the MFMA / LDS-transpose / LDS-DMA lane maps the kernels rely on.
  * scratch_dev: >= 2080 bytes of device memory; int32[8] mismatch counts are left at byte
  * offset 2048 (all zero = every map as assumed). */

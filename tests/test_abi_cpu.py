@@ -1,0 +1,74 @@
+"""The C-ABI boundary without a GPU: libvds_hip.so loads and exports every symbol that
+include/vds.h declares; the ctypes table binds exactly that set; argument checks that run
+on the host reject bad calls with VDS_ERR_* (no kernel is launched here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from video_diffusion_speedrun_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "vds.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(vds_[a-z0-9_]+)\s*\(", src))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_header_and_ctypes_table_agree():
+    assert declared_symbols() == set(_lib.SIGNATURES), declared_symbols() ^ set(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(raw, name), name
+    assert lib.vds_version() >= 1
+
+
+def test_struct_layouts_match_header():
+    # vds_gemm_args / vds_attn_args / vds_adamw_tensor: field counts and sizes as declared
+    assert C.sizeof(_lib.AdamWTensor) == 5 * 8 + 8 + 4 + 4
+    assert C.sizeof(_lib.GemmArgs) == 5 * 4 + 4 + 8 * 13 + 4 + 4  # 5 int32 + pad, 13 pointer/int64, 2 int32
+    assert C.sizeof(_lib.AttnArgs) == 5 * 4 + 4 + 8 * (4 * 4 + 1 + 4 * 4 + 1)
+    assert C.sizeof(_lib.ProfStat) == 32
+
+
+def test_host_side_argument_checks(lib):
+    a = _lib.GemmArgs()
+    assert lib.vds_gemm_bf16(C.byref(a), None) == -1  # null operands
+    b = _lib.AttnArgs()
+    assert lib.vds_attn_fwd(C.byref(b), None) == -1
+    assert lib.vds_rmsnorm_mod_fwd(None, 0, None, None, 0, 0, 0, None, 0, None, 1, 1, 8, 1e-6, None) == -1
+    assert lib.vds_adamw_multi(None, None, None, 1, 1024, 0.9, 0.99, 1e-8, 1, 1.0, 1.0, None) == -1
+    assert lib.vds_prof_collect(None) == -1
+    assert lib.vds_prof_class_name(0) == b"gemm_nt"
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "video_diffusion_speedrun_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_model_refuses_cpu_tensors():
+    import torch
+    from video_diffusion_speedrun_amd.model import DiT
+    m = DiT(in_channels=16, hidden_size=128, depth=1, num_heads=2, cross_attn_input_size=64)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 16, 2, 4, 4), torch.zeros(1, 4, 64), torch.zeros(1))

@@ -38,6 +38,13 @@ class AttnArgs(C.Structure):
                 ("delta", c_vp)]
 
 
+class ProfStat(C.Structure):
+    _fields_ = [("launches", c_i64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+PROF_NCLASS = 13
+
+
 class AdamWTensor(C.Structure):
     _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("p_bf16", c_vp),
                 ("numel", c_i64), ("lr", c_f32), ("wd", c_f32)]
@@ -76,6 +83,9 @@ SIGNATURES = {
     "vds_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
     "vds_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
     "vds_selftest_lanemaps": [c_vp, c_vp],
+    "vds_prof_enable": [C.c_uint32],
+    "vds_prof_collect": [c_vp],
+    "vds_prof_class_name": [c_i32],
 }
 
 _lib = None
@@ -98,7 +108,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "vds_last_error" else C.c_int
+        fn.restype = C.c_char_p if name in ("vds_last_error", "vds_prof_class_name") else C.c_int
     _lib = lib
     return lib
 

@@ -22,6 +22,7 @@
 // K/V (or Q/dO) tiles are staged HBM -> VGPR -> LDS with the loads issued one tile ahead
 // (issue-early / write-late), double-buffered, one barrier per tile.
 #include "common.h"
+#include "prof.h"
 #include "../../include/vds.h"
 
 namespace {
@@ -518,6 +519,8 @@ int run_fwd(AttnP p, hipStream_t s) {
   if (!once) { set_lds(attn_fwd_kernel<HDP, HDQ>, LDS); once = true; }
   p.n_rt = cdiv(p.Lq, 128);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
+  const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
+  vdsprof::Scope ps(VDS_PROF_ATTN_FWD, s, fl, 2.0 * p.B * p.H * p.hd * (2.0 * p.Lq + 2.0 * p.Lk));
   hipLaunchKernelGGL((attn_fwd_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
@@ -533,13 +536,25 @@ int run_bwd(AttnP p, hipStream_t s) {
     once = true;
   }
   const long rows = (long)p.B * p.H * p.Lq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
+  // algorithmic backward = 5 products of 2*Lq*Lk*hd (S, dP, dV, dK, dQ): dkv carries 3 of them, dq 2
+  const double prod = 2.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
+  const double qb = 2.0 * p.B * p.H * p.hd * (double)p.Lq, kb = 2.0 * p.B * p.H * p.hd * (double)p.Lk;
+  {
+    vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DELTA, s, 2.0 * rows * p.hd, 2.0 * qb);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
+  }
   p.n_rt = cdiv(p.Lk, 128);
   int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS_DKV, s, p);
+  {
+    vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DKV, s, 3.0 * prod, 2.0 * qb + 4.0 * kb);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS_DKV, s, p);
+  }
   p.n_rt = cdiv(p.Lq, 128);
   grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS_DQ, s, p);
+  {
+    vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DQ, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS_DQ, s, p);
+  }
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 

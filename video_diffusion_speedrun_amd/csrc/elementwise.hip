@@ -4,6 +4,7 @@
 // patchify / unpatchify, register tokens, noising, flow-matching loss, casts.
 // Reference call sites are cited per kernel (file:line of the reference repo).
 #include "common.h"
+#include "prof.h"
 #include "../../include/vds.h"
 
 namespace {
@@ -676,6 +677,7 @@ extern "C" int vds_rmsnorm_mod_fwd(const void* x, int64_t ldx, const void* w, co
     return VDS_ERR_ARG;
   const long rows = (long)B * L;
   hipStream_t s = (hipStream_t)stream;
+  vdsprof::Scope ps(VDS_PROF_RMSNORM_FWD, s, 0.0, 4.0 * rows * D + 4.0 * rows);
 #define CALL(NC)                                                                                              \
   hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,          \
                      (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, \
@@ -694,6 +696,7 @@ extern "C" int vds_rmsnorm_mod_bwd(const void* dy, int64_t lddy, const void* x, 
   const int rpb = rows_per_block_for(L);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((L + rpb - 1) / rpb, B);
+  vdsprof::Scope ps(VDS_PROF_RMSNORM_BWD, s, 0.0, (dres ? 8.0 : 6.0) * B * L * D + 4.0 * B * L);
 #define CALL(NC)                                                                                                \
   hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NC>), grid, dim3(256), 0, s, (const bf16_t*)dy, (long)lddy,         \
                      (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, rstd, \
@@ -710,6 +713,7 @@ extern "C" int vds_gate_bwd(const void* dxn, int64_t lddxn, const void* y, int64
   const int rpb = rows_per_block_for(L);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((L + rpb - 1) / rpb, B);
+  vdsprof::Scope ps(VDS_PROF_GATE_BWD, s, 0.0, 6.0 * B * L * D);
 #define CALL(NC)                                                                                             \
   hipLaunchKernelGGL((gate_bwd_kernel<NC>), grid, dim3(256), 0, s, (const bf16_t*)dxn, (long)lddxn,           \
                      (const bf16_t*)y, (long)ldy, mod, (long)ldmod, gate_col, (bf16_t*)dy, (long)lddy, dmod, \
@@ -734,6 +738,7 @@ extern "C" int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float*
   if (v0 && !lam) return VDS_ERR_ARG;
   if (((hdp - hd) >> 2) > (hd >> 3)) return VDS_ERR_UNSUPPORTED;
   const long n = (long)B * L * H * (hd >> 3);
+  vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, (hipStream_t)stream, 0.0, (v0 ? 14.0 : 12.0) * B * L * H * hd);
   hipLaunchKernelGGL(qkv_rope_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (bf16_t*)q, (bf16_t*)k,
                      (bf16_t*)v, B, L, H, hd, hdp);
@@ -748,6 +753,7 @@ extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, 
   if (mix && (!qkv_raw || !v0 || !lam || !dv0_acc || !dlam)) return VDS_ERR_ARG;
   if (add_dv0 && !dv0_acc) return VDS_ERR_ARG;
   const long n = (long)B * L * H * (hd >> 3);
+  vdsprof::Scope ps(VDS_PROF_QKV_ROPE_BWD, (hipStream_t)stream, 0.0, (mix ? 24.0 : 12.0) * B * L * H * hd);
   hipLaunchKernelGGL(qkv_rope_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw,
                      (const bf16_t*)v0, (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp);

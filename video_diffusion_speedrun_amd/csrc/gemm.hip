@@ -18,6 +18,7 @@
 //     that every global store / aux load is a 16-byte row segment;
 //   * 1-D grid with an XCD-aware, grouped tile order (8 XCDs, private L2s).
 #include "common.h"
+#include "prof.h"
 #include "../../include/vds.h"
 
 namespace {
@@ -288,6 +289,8 @@ int launch(const GemmP& p, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.split_k > 1 ? p.split_k : 1, 1);
+  vdsprof::Scope ps(LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : LAYOUT == VDS_NN ? VDS_PROF_GEMM_NN : VDS_PROF_GEMM_TN, s,
+                    2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
   hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI>), grid, dim3(256), LDS_BYTES, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }

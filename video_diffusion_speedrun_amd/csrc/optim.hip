@@ -6,6 +6,7 @@
 // that no separate cast pass runs.  Also the library-level helpers (version, last error, lane-map
 // self test).
 #include "common.h"
+#include "prof.h"
 #include "../../include/vds.h"
 
 namespace {
@@ -197,6 +198,8 @@ extern "C" int vds_adamw_multi(const vds_adamw_tensor* desc_dev, const int32_t* 
   static_assert(sizeof(vds_adamw_tensor) == sizeof(AdamT), "descriptor layout");
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2 = 1.0f - powf(beta2, (float)step);
+  // upper bound of the elements touched (last chunk of a tensor may be short): 16 B read + 14 B written each
+  vdsprof::Scope ps(VDS_PROF_ADAMW, (hipStream_t)stream, 0.0, 30.0 * (double)n_chunks * chunk_elems);
   hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamT*)desc_dev,
                      chunk_tensor_dev, (const long*)chunk_start_dev, chunk_elems, beta1, beta2, eps, bc1,
                      1.0f / sqrtf(bc2), lr_mult, grad_scale);

@@ -1,0 +1,164 @@
+"""Parameter / gradient sharding over the GPUs of one node: the build's `apply_fsdp`
+(reference: model.py:468-542, FSDP2 `fully_shard` per DiTBlock + root, bf16 all-gather,
+fp32 reduce-scatter-average; call site train.py:323-325).
+
+MI355X-first re-design of the same contract:
+
+  * one flat buffer per shard group (params.FlatGroup) => ONE RCCL all-gather (bf16) and ONE
+    reduce-scatter (fp32, avg) per group per step: 29 + 29 large contiguous collectives for
+    DiT-XL instead of per-parameter copy-in/copy-out.  xGMI is point-to-point; few, large
+    messages are what it wants;
+  * 288 GB of HBM per GPU: the gathered bf16 copy of EVERY group (2.3 GB for DiT-XL) stays
+    resident from forward to backward, so the reference's backward re-all-gather
+    (`reshard_after_forward`, model.py:525) is not needed at all -- all-gather traffic is halved;
+  * all gathers of a step are issued up-front, in use order, on a dedicated communication
+    stream; the compute stream waits on the per-group event right before the first kernel that
+    reads the group (prefetch depth = everything);
+  * each group's reduce-scatter is issued on the communication stream as soon as that group's
+    last weight-gradient kernel is queued, overlapping with the backward of the next block;
+  * world_size == 1 works (no communication, no streams) -- the reference cannot
+    (model.py:489).
+
+On CPU tensors (gloo; tests only) the same choreography runs synchronously without streams.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .params import FlatGroup
+
+
+def get_device_mesh(world_size: Optional[int] = None):
+    """Shape of the reference's mesh (model.py:475-498): dp_replicate 1 x dp_shard W, tp 1.
+    There is no DeviceMesh object here: one process group spans the shard dimension."""
+    w = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+    return {"dp_replicate": 1, "dp_shard": w, "tp": 1}
+
+
+class ShardRuntime:
+    """Stream / event choreography of the per-group collectives around DiT's explicit
+    forward / backward kernel sequences (model.py hooks `pre_forward_*` ... `post_backward_*`)."""
+
+    def __init__(self, model, cast_fn, process_group=None):
+        self.model = model
+        self.cast_fn = cast_fn
+        self.pg = process_group
+        self.cuda = model._groups[0].device.type == "cuda"
+        self.comm = torch.cuda.Stream(device=model._groups[0].device) if self.cuda else None
+        self.gather_ev = [None] * len(model._groups)
+        self.n_all_gather = 0
+        self.n_reduce_scatter = 0
+
+    # ---- helpers --------------------------------------------------------------------------
+    def _on_comm(self):
+        return torch.cuda.stream(self.comm) if self.cuda else _Null()
+
+    def _comm_waits_compute(self):
+        if self.cuda:
+            self.comm.wait_stream(torch.cuda.current_stream())
+
+    def _compute_waits(self, gi: int):
+        ev = self.gather_ev[gi]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self.gather_ev[gi] = None
+
+    def _reduce(self, gi: int):
+        g: FlatGroup = self.model._groups[gi]
+        self._comm_waits_compute()  # every gradient kernel of this group is queued before here
+        with self._on_comm():
+            g.reduce_grads(self.pg)
+        self.n_reduce_scatter += 1
+
+    # ---- forward --------------------------------------------------------------------------
+    def pre_forward_root(self):
+        """issue the bf16 cast + all-gather of every group, in use order, on the comm stream"""
+        self._comm_waits_compute()  # the optimizer step that wrote master / shadow is done
+        with self._on_comm():
+            for gi, g in enumerate(self.model._groups):
+                g.gather(self.cast_fn, self.pg)
+                self.n_all_gather += 1
+                if self.cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(self.comm)
+                    self.gather_ev[gi] = ev
+        self._compute_waits(0)
+
+    def pre_forward_block(self, i: int):
+        self._compute_waits(1 + i)
+
+    def post_forward_block(self, i: int):
+        pass  # gathered copies stay resident (288 GB HBM): nothing to reshard
+
+    def post_forward_root(self):
+        pass
+
+    # ---- backward -------------------------------------------------------------------------
+    def pre_backward_root(self):
+        for gi in range(len(self.model._groups)):  # no-grad forwards may have left events unconsumed
+            self._compute_waits(gi)
+
+    def pre_backward_block(self, i: int):
+        pass  # no re-gather: see the module docstring
+
+    def post_backward_block(self, i: int):
+        self._reduce(1 + i)
+
+    def post_backward_root(self):
+        self._reduce(0)
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.comm)
+        for g in self.model._groups:
+            g.publish_grads()
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32, process_group=None,
+               device=None, cast_fn=None):
+    """Shard `dit_model` over the ranks of `process_group` (default: the world) and return it
+    -- the same object, still callable, still exposing get_mup_setup / named_parameters
+    (model.py:512-542).  After this call every nn.Parameter is this rank's 1-D fp32 piece of
+    its tensor (possibly empty), which is what the element-wise optimizer consumes.
+
+    param_dtype / reduce_dtype: the reference passes bf16 / fp32 (train.py:323-325); those
+    are the only values the kernels implement."""
+    if param_dtype != torch.bfloat16 or reduce_dtype != torch.float32:
+        raise ValueError("apply_fsdp: the HIP path implements param_dtype=bf16, reduce_dtype=fp32 only")
+    if dist.is_initialized():
+        world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+    else:
+        world, rank = 1, 0
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device(device)
+    if dit_model._fsdp is not None:
+        raise RuntimeError("apply_fsdp was already applied to this model")
+    if cast_fn is None:
+        if device.type == "cuda":
+            from . import ops
+            cast_fn = ops.cast_f32_bf16
+        else:  # gloo / CPU tests of the host logic only (the model itself never computes on CPU)
+            cast_fn = lambda src, dst: dst.copy_(src)
+    full_values = {n: p.data.detach().clone() for n, p in dit_model.named_parameters()}
+    dit_model._world, dit_model._rank, dit_model._pg = world, rank, process_group
+    root, blocks = dit_model._group_members()
+    groups = [FlatGroup("root", root, world, rank)]
+    groups += [FlatGroup(f"blocks.{i}", m, world, rank) for i, m in enumerate(blocks)]
+    for g in groups:
+        g.materialize(device, full_values)
+    for name, buf in dit_model.named_buffers():
+        buf.data = buf.data.to(device)
+    dit_model._groups = groups
+    if world > 1:
+        dit_model._fsdp = ShardRuntime(dit_model, cast_fn, process_group)
+    return dit_model

@@ -302,3 +302,22 @@ def selftest_lanemaps(device="cuda"):
     check(_lib.load().vds_selftest_lanemaps(_p(scratch), _stream()), "vds_selftest_lanemaps")
     torch.cuda.synchronize()
     return scratch[512:520].tolist()
+
+
+# ------------------------------------------------------------------ live profiling ----
+def prof_enable(mask: int = 0xFFFFFFFF):
+    """record HIP event pairs (on the launch stream) around every launch of the enabled kernel classes"""
+    check(_lib.load().vds_prof_enable(mask & 0xFFFFFFFF), "vds_prof_enable")
+
+
+def prof_collect():
+    """-> {class name: dict(launches, ms, flops, bytes)} of the launches since prof_enable; resets."""
+    lib = _lib.load()
+    arr = (_lib.ProfStat * _lib.PROF_NCLASS)()
+    check(lib.vds_prof_collect(C.cast(arr, C.c_void_p)), "vds_prof_collect")
+    out = {}
+    for i in range(_lib.PROF_NCLASS):
+        if arr[i].launches:
+            out[lib.vds_prof_class_name(i).decode()] = dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops,
+                                                            bytes=arr[i].bytes)
+    return out

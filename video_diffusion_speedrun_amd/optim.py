@@ -43,7 +43,27 @@ class MuAdamW(torch.optim.Optimizer):
         self._dev["cs"] = torch.tensor(chunk_s, dtype=torch.int64, device=device)
         self._dev["n"] = len(chunk_t)
 
-    def _build_descs(self, plist, device):
+    def _lr_plan(self, plist):
+        """(per-param base lr list, common multiplier): LR schedulers scale every group's lr by the same
+        factor of its `initial_lr` (train.py:349-364), so the descriptor table keeps the base lr and the
+        factor travels as a kernel argument -- no table rebuild / H2D copy per step."""
+        mult = None
+        for _, g in plist:
+            base = g.get("initial_lr", None)
+            if base is None or base == 0.0:
+                mult = None
+                break
+            r = g["lr"] / base
+            if mult is None:
+                mult = r
+            elif abs(r - mult) > 1e-9 * max(abs(mult), 1e-30):
+                mult = None
+                break
+        if mult is None:
+            return [float(g["lr"]) for _, g in plist], 1.0
+        return [float(g["initial_lr"]) for _, g in plist], float(mult)
+
+    def _build_descs(self, plist, device, lrs):
         descs = (_lib.AdamWTensor * len(plist))()
         for i, (p, group) in enumerate(plist):
             st = self.state[p]
@@ -53,7 +73,7 @@ class MuAdamW(torch.optim.Optimizer):
             d.m, d.v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             d.p_bf16 = shadow.data_ptr() if shadow is not None and shadow.numel() == p.numel() else None
             d.numel = p.numel()
-            d.lr, d.wd = float(group["lr"]), float(group["weight_decay"])
+            d.lr, d.wd = lrs[i], float(group["weight_decay"])
         self._dev["desc"] = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
 
     @torch.no_grad()
@@ -77,15 +97,16 @@ class MuAdamW(torch.optim.Optimizer):
         if ckey != self._chunk_key:
             self._build_chunks(plist, device)
             self._chunk_key, self._table_key = ckey, None
-        key = tuple((p.data.data_ptr(), p.grad.data_ptr(), g["lr"], g["weight_decay"]) for p, g in plist)
-        if key != self._table_key:  # pointers or the scheduled lr changed: refresh the descriptors
-            self._build_descs(plist, device)
+        lrs, mult = self._lr_plan(plist)
+        key = tuple((p.data.data_ptr(), p.grad.data_ptr(), lr, g["weight_decay"]) for (p, g), lr in zip(plist, lrs))
+        if key != self._table_key:  # pointers or the base lr changed: refresh the descriptors
+            self._build_descs(plist, device, lrs)
             self._table_key = key
         b1, b2 = self.param_groups[0]["betas"]
         eps = self.param_groups[0]["eps"]
         _lib.check(_lib.load().vds_adamw_multi(self._dev["desc"].data_ptr(), self._dev["ct"].data_ptr(),
                                                self._dev["cs"].data_ptr(), self._dev["n"], CHUNK, b1, b2, eps,
-                                               self._step, 1.0, 1.0, ops._stream()), "vds_adamw_multi")
+                                               self._step, mult, 1.0, ops._stream()), "vds_adamw_multi")
         # the bf16 shadows of these flat groups are now current: the next forward skips its cast pass
         for g in {id(getattr(p, "_vds_group", None)): getattr(p, "_vds_group", None) for p, _ in plist}.values():
             if g is not None:

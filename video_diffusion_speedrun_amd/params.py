@@ -176,7 +176,7 @@ def all_gather_flat(out: torch.Tensor, inp: torch.Tensor, group=None):
     if dist.get_backend(group) == "gloo":
         parts = list(out.view(dist.get_world_size(group), -1).unbind(0))
         if inp.dtype == torch.bfloat16:  # gloo has no bf16: move the raw bits
-            dist.all_gather([p.view(torch.int16) for p in parts], inp.view(torch.int16), group=group)
+            dist.all_gather([p.view(torch.uint8) for p in parts], inp.view(torch.uint8), group=group)
         else:
             dist.all_gather(parts, inp, group=group)
     else:

@@ -93,6 +93,29 @@ def forward(dit_model, batch, text_encoder, tokenizer, device, global_step, mast
     return total_loss, diffusion_loss
 
 
+def lr_lambda(step: int, kind: str, warmup: int, total: int) -> float:
+    """multiplier of HF get_{cosine,linear}_schedule_with_warmup; "constant" is the reference's
+    linear schedule with 1e10 total steps (train.py:349-364)."""
+    if kind == "constant":
+        kind, total = "linear", 10_000_000_000
+    if step < warmup:
+        return step / max(1, warmup)
+    if kind == "linear":
+        return max(0.0, (total - step) / max(1, total - warmup))
+    if kind != "cosine":
+        raise ValueError(f"unknown lr_scheduler_type {kind}")
+    import math
+    prog = (step - warmup) / max(1, total - warmup)
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+
+
+def get_schedule(optimizer, lr_scheduler_type: str = "cosine", num_warmup_steps: int = 20,
+                 num_training_steps: int = 10000):
+    """the LR scheduler of train.py:349-364 as a torch LambdaLR (no transformers import needed)"""
+    return torch.optim.lr_scheduler.LambdaLR(
+        optimizer, lambda s: lr_lambda(s, lr_scheduler_type, num_warmup_steps, num_training_steps))
+
+
 def train_step(dit_model, optimizer, lr_scheduler, batch, device, generator=None, rope_start=None):
     """train.py:412-434 for one batch with a pre-encoded context; returns the loss tensor."""
     total_loss, _ = forward(dit_model, batch, None, None, device, 0, False, generator=generator,
