@@ -87,8 +87,8 @@ def cpu_baseline(kw, latent_shape, flops_per_sample):
     workload: ONE DiT block of the model (+ embed / final layers) at the full token count, B=1,
     forward + backward + AdamW; the per-sample rate is extrapolated x depth."""
     from oracle import dit_oracle as O
-    n_threads = os.cpu_count() or 1
-    n_threads = min(n_threads, len(os.sched_getaffinity(0)))
+    # a 1-GPU box's CPU share is 16 cores: more threads than that only oversubscribe the host
+    n_threads = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(n_threads)
     depth = kw["depth"]
     cfg = O.DiTConfig(in_channels=16, patch_size=2, time_patch_size=kw["time_patch_size"],

@@ -104,6 +104,7 @@ def load():
         raise VdsError(
             f"{LIB_PATH} not found: build the gfx950 kernels first (python -c 'import __graft_entry__ as g; "
             "g.build()' or make -C video_diffusion_speedrun_amd/csrc).  This package has no CPU/eager fallback.")
+    import torch  # noqa: F401  -- first: libvds_hip.so must bind to the HIP runtime torch has loaded
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

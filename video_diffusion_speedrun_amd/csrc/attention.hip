@@ -360,17 +360,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 }
 
 // ===================================== dK, dV ===============================================
-// Workgroup = 128 keys (4 waves x 32); K and V of those keys stay in LDS for the whole sweep
-// over 64-row Q/dO tiles.  S and dP have the key on the lane; LSE and delta are per register row.
+// Workgroup = 128 keys (4 waves x 32).  Each wave keeps the K and V rows of its 32 keys as MFMA
+// B-operand fragments in registers for the whole sweep over 64-row Q/dO tiles, so LDS holds only
+// the double-buffered Q/dO tiles (2 workgroups per CU = 2 waves per SIMD: one wave's softmax
+// VALU work overlaps the other's MFMAs).  S and dP have the key on the lane; LSE and delta are
+// per register row.
 template <int HDP, int HDQ>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnP p) {
-  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, KV_TILE = 128 * HDP * 2, Q_TILE = 64 * HDP * 2;
+__global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(AttnP p) {
+  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, Q_TILE = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS: [K 128 rows][V 128 rows][buf0: Q | dO][buf1: Q | dO][stats: 2 bufs x (lse2[64], delta[64])]
-  char* ktile = smem;
-  char* vtile = smem + KV_TILE;
-  char* qbuf = smem + 2 * KV_TILE;
-  float* stats = reinterpret_cast<float*>(smem + 2 * KV_TILE + 4 * Q_TILE);
+  // LDS: [buf0: Q | dO][buf1: Q | dO][stats: 2 bufs x (lse2[64], delta[64])]
+  char* qbuf = smem;
+  float* stats = reinterpret_cast<float*>(smem + 4 * Q_TILE);
   int bh, kt_idx;
   if (!decode_block(p.n_rt, p.B * p.H, bh, kt_idx)) return;
   const int b = bh / p.H, hh = bh % p.H;
@@ -386,13 +387,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnP p) {
   const float* dl_g = p.delta + ((long)b * p.H + hh) * p.Lq;
   const float c = p.scale * LOG2E;
 
-  {
-    Stage<128, HDP> s0;
-    s0.issue(rk, key0, p.k_sl, p.hd, tid);
-    s0.commit(ktile, tid);
-    s0.issue(rv, key0, p.v_sl, p.hd, tid);
-    s0.commit(vtile, tid);
+  // this lane's key row as B-operand fragments (rows past Lk / columns past hd read as zero)
+  bf16x8 kf[KSQ], vf[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    const int e = ks * 16 + 8 * h;
+    unsigned offk = (unsigned)(((long)krow * p.k_sl + e) * 2);
+    unsigned offv = (unsigned)(((long)krow * p.v_sl + e) * 2);
+    if (e >= p.hd) { offk = 0xfffffff0u; offv = 0xfffffff0u; }
+    kf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, offk, 0, 0));
+    vf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, offv, 0, 0));
   }
+
   Stage<64, HDP> sq, sd;
   float st_l = 0.f, st_d = 0.f;  // threads 0..63 stage the row statistics of the next tile
   auto issue_stats = [&](int q0) {
@@ -437,8 +443,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnP p) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < KSQ; ++ks) {
-        s = mfma32(frag_row<HDP>(qt, qb * 32, ks, lane), frag_row<HDP>(ktile, wave * 32, ks, lane), s);
-        dp = mfma32(frag_row<HDP>(dot, qb * 32, ks, lane), frag_row<HDP>(vtile, wave * 32, ks, lane), dp);
+        s = mfma32(frag_row<HDP>(qt, qb * 32, ks, lane), kf[ks], s);
+        dp = mfma32(frag_row<HDP>(dot, qb * 32, ks, lane), vf[ks], dp);
       }
       f32x16 pm;
 #pragma unroll
@@ -528,7 +534,7 @@ int run_fwd(AttnP p, hipStream_t s) {
 template <int HDP, int HDQ>
 int run_bwd(AttnP p, hipStream_t s) {
   constexpr int LDS_DQ = 4 * 64 * HDP * 2;
-  constexpr int LDS_DKV = 2 * 128 * HDP * 2 + 4 * 64 * HDP * 2 + 2 * 128 * 4;
+  constexpr int LDS_DKV = 4 * 64 * HDP * 2 + 2 * 128 * 4;
   static bool once = false;
   if (!once) {
     set_lds(attn_bwd_dq_kernel<HDP, HDQ>, LDS_DQ);

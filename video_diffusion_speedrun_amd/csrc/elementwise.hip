@@ -653,9 +653,12 @@ __global__ void rope_rows_kernel(const float* tab_t_cos, const float* tab_t_sin,
 }
 
 inline int ok() { return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH; }
-inline int rows_per_block_for(int L) {
-  int rpb = (L + 63) / 64;  // <= 64 blocks per sample
-  return rpb < 4 ? 4 : rpb;
+// rows of one sample per workgroup: ~768 workgroups in total (3 per CU, enough waves to stream HBM)
+// while every workgroup still folds >= 8 rows into its column sums before the atomics
+inline int rows_per_block_for(int L, int B) {
+  const long total = (long)L * B;
+  int rpb = (int)((total + 767) / 768);
+  return rpb < 8 ? 8 : rpb;
 }
 
 }  // namespace
@@ -693,7 +696,7 @@ extern "C" int vds_rmsnorm_mod_bwd(const void* dy, int64_t lddy, const void* x, 
                                    float* dmod, float* dw, int32_t B, int32_t L, int32_t D, vds_stream_t stream) {
   if (!dy || !x || !mod || !rstd || !dx || !dmod || (D & 7) || (lddy & 7) || (ldx & 7) || (lddx & 7)) return VDS_ERR_ARG;
   if (w && !dw) return VDS_ERR_ARG;
-  const int rpb = rows_per_block_for(L);
+  const int rpb = rows_per_block_for(L, B);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((L + rpb - 1) / rpb, B);
   vdsprof::Scope ps(VDS_PROF_RMSNORM_BWD, s, 0.0, (dres ? 8.0 : 6.0) * B * L * D + 4.0 * B * L);
@@ -710,7 +713,7 @@ extern "C" int vds_gate_bwd(const void* dxn, int64_t lddxn, const void* y, int64
                             int64_t ldmod, int32_t gate_col, void* dy, int64_t lddy, float* dmod, float* dbias,
                             int32_t B, int32_t L, int32_t D, vds_stream_t stream) {
   if (!dxn || !y || !mod || !dy || !dmod || (D & 7)) return VDS_ERR_ARG;
-  const int rpb = rows_per_block_for(L);
+  const int rpb = rows_per_block_for(L, B);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((L + rpb - 1) / rpb, B);
   vdsprof::Scope ps(VDS_PROF_GATE_BWD, s, 0.0, 6.0 * B * L * D);

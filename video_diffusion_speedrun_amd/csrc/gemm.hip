@@ -206,6 +206,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own wave's region only, no barrier needed
   __builtin_amdgcn_wave_barrier();
 
+  if constexpr (EPI == VDS_EPI_F32) {
+    if (p.atomic) {
+      // split-K / accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256
+      // contiguous bytes, the full-rate shape of global_atomic_add_f32 on gfx950)
+      const int acol = n0 + wn * 64 + lane;
+      if (acol < p.N) {
+        float* cbase = reinterpret_cast<float*>(p.C) + (long)(m0 + wm * 64) * p.ldc + acol;
+        const int rmax = min(64, p.M - (m0 + wm * 64));
+        for (int row = 0; row < rmax; ++row) atomicAdd(cbase + (long)row * p.ldc, stg[row * EPI_LD + lane]);
+      }
+      return;
+    }
+  }
   const int c8 = lane & 7, rin = lane >> 3;
   const int gcol = n0 + wn * 64 + c8 * 8;
   if (gcol >= p.N) return;
@@ -229,13 +242,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if constexpr (EPI == VDS_EPI_F32) {
       float* c = reinterpret_cast<float*>(p.C) + grow * p.ldc + gcol;
-      if (p.atomic) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(c + e, v[e]);
-      } else {
-        *reinterpret_cast<f32x4*>(c) = lo;
-        *reinterpret_cast<f32x4*>(c + 4) = hi;
-      }
+      *reinterpret_cast<f32x4*>(c) = lo;
+      *reinterpret_cast<f32x4*>(c + 4) = hi;
     } else if constexpr (EPI == VDS_EPI_STORE) {
       u32x4 o;
 #pragma unroll

@@ -89,6 +89,21 @@ def linear_dgrad(dy, W, pre: Optional[torch.Tensor] = None):
     return dx
 
 
+def _wgrad_split(tiles: int, kt: int, slots: int) -> int:
+    """split-K factor of a weight-gradient GEMM: minimise (rounds of `slots` co-resident workgroups) x
+    (K tiles per workgroup) plus the fp32-atomic traffic of the partial tiles (64 KB each at the
+    chip-wide ~1.3 TB/s atomic rate, priced in units of one K-tile step ~1.5 us)."""
+    best, best_cost = 1, None
+    for s in range(1, 17):
+        if s > 1 and kt // s < 8:
+            break
+        rounds = -(-(tiles * s) // slots)
+        cost = rounds * -(-kt // s) + (tiles * s * 0.034 if s > 1 else 0.0)
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = s, cost
+    return best
+
+
 def linear_wgrad(dy, x, dW: torch.Tensor, accumulate: bool = False, n_cu: int = 256):
     """dW[N,K] (f32) = dy^T x   (dy [M,N], x [M,K]); split-K over the tokens adds atomically into
     dW, which must then be pre-zeroed (the model zeroes its flat gradient buffers once per step);
@@ -98,7 +113,7 @@ def linear_wgrad(dy, x, dW: torch.Tensor, accumulate: bool = False, n_cu: int = 
     assert dW.dtype == f32 and dW.numel() == N * K and dW.is_contiguous()
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     kt = (M + 63) // 64
-    split = max(1, min((2 * n_cu) // max(tiles, 1), kt // 4))
+    split = _wgrad_split(tiles, kt, 2 * n_cu)
     if accumulate:
         split = -split
     gemm(VDS_TN, EPI_F32, N, K, M, dy, dy.stride(0), x, x.stride(0), dW, K, split_k=split)
