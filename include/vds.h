@@ -87,7 +87,7 @@ typedef struct vds_attn_args {
   void* dq; int64_t dq_sb, dq_sh, dq_sl;
   void* dk; int64_t dk_sb, dk_sh, dk_sl;
   void* dv; int64_t dv_sb, dv_sh, dv_sl;
-  float* delta;                /* workspace [B,H,Lq] f32 */
+  float* delta;                /* workspace [2,B,H,Lq] f32: -rowsum(dO*O), then lse*log2(e) */
 } vds_attn_args;
 
 int vds_attn_fwd(const vds_attn_args* args, vds_stream_t stream);

@@ -177,7 +177,7 @@ def test_attention_fwd_bwd(ops, hd, Lq, Lk):
     close("attn.o", o_tok.reshape(B, Lq, H, hd).permute(0, 2, 1, 3), o_ref, 6e-3)
     close("attn.lse", lse, lse_ref, 1e-3)
     dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
-    delta = torch.zeros(B, H, Lq, dtype=f32, device="cuda")
+    delta = torch.zeros(2, B, H, Lq, dtype=f32, device="cuda")
     dod = do.reshape(B * Lq, H * hd).cuda()
     ops.attn_bwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ov, lse, ops.heads_view(dod, B, Lq, H, hd),
                  dq[..., :hd], dk[..., :hd], dv[..., :hd], delta)
@@ -208,7 +208,7 @@ def test_attention_token_major_cross(ops):
     close("cross.o", o.reshape(B, L, H, hd).permute(0, 2, 1, 3), o_ref, 6e-3)
     dqb = torch.zeros_like(qd)
     dkvb = torch.zeros_like(kvd)
-    delta = torch.zeros(B, H, L, dtype=f32, device="cuda")
+    delta = torch.zeros(2, B, H, L, dtype=f32, device="cuda")
     ops.attn_bwd(qv, kv_k, kv_v, ops.heads_view(o, B, L, H, hd), lse, ops.heads_view(do.cuda(), B, L, H, hd),
                  ops.heads_view(dqb, B, L, H, hd), ops.heads_view(dkvb, B, Lc, H, hd, 0),
                  ops.heads_view(dkvb, B, Lc, H, hd, D), delta)

@@ -268,3 +268,47 @@ def test_full_size_properties_dit_xl_block(vds):
         m.final_proj.bias.zero_()
         o0 = m(x1, c1, t1, rope_start=start)
     assert o0.abs().max().item() == 0
+
+
+def test_shard_runtime_on_one_gpu_matches_unsharded(vds):
+    """the stream / event / RCCL choreography of fsdp.ShardRuntime, forced on at world_size 1
+    (1-rank nccl group): three optimizer steps give the same losses and parameters as the
+    unsharded model (same kernels, same order; the collectives are exact copies at W=1; the only
+    difference allowed is the summation order of the fp32 atomic accumulations)."""
+    import torch.distributed as dist
+    from video_diffusion_speedrun_amd.fsdp import apply_fsdp
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = O.DiTConfig(in_channels=16, hidden_size=128, depth=3, num_heads=2, cross_attn_input_size=64,
+                          residual_v=True, train_bias_and_rms=False)
+        P = O.init_params(cfg, seed=31, randomize_zero_init=True, init_std_factor=1.0)
+        g = torch.Generator().manual_seed(3)
+        batch = {"latent": torch.randn(2, 16, 4, 8, 8, generator=g), "context": torch.randn(2, 16, 64, generator=g),
+                 "prompt": ["", ""]}
+        results = []
+        for sharded in (False, True):
+            m = build(vds, cfg, P)
+            if sharded:
+                m = apply_fsdp(m, torch.bfloat16, torch.float32, force_runtime=True)
+                assert m._fsdp is not None
+            groups, _ = m.get_mup_setup(3e-3, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
+            opt = vds["optim"].MuAdamW(groups, betas=(0.95, 0.99))
+            losses = []
+            for s in range(3):
+                gen = torch.Generator(device="cuda").manual_seed(100 + s)
+                torch.manual_seed(0)
+                loss = vds["train"].train_step(m, opt, None, batch, "cuda", generator=gen, rope_start=(1, 2, 3))
+                losses.append(loss.item())
+            torch.cuda.synchronize()
+            if sharded:
+                assert m._fsdp.n_all_gather == 3 * (1 + cfg.depth) and m._fsdp.n_reduce_scatter == 3 * (1 + cfg.depth)
+            results.append((losses, {k: v.clone() for k, v in m.full_state_dict().items()}))
+        (l0, p0), (l1, p1) = results
+        assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+        for k in p0:
+            assert rel(p1[k], p0[k]) <= 1e-5, (k, rel(p1[k], p0[k]))
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,50 @@
+"""Attention-only micro-benchmark at the DiT-XL / seq-8k shape (HIP events, random data).
+VDS_ATTN_VARIANT selects the forward variant (read once per process)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from video_diffusion_speedrun_amd import ops
+
+bf16, f32 = torch.bfloat16, torch.float32
+dev = "cuda"
+
+
+def timeit(fn, iters=8, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+B = int(os.environ.get("B", 2))
+tag = f"variant={os.environ.get('VDS_ATTN_VARIANT', 'default')}"
+for hd, H, hdp in ((72, 16, 96), (64, 12, 64), (128, 16, 128)):
+    Lq = 8208
+    g = torch.Generator(device=dev).manual_seed(0)
+    q, k, v = (torch.zeros(B, H, Lq, hdp, dtype=bf16, device=dev) for _ in range(3))
+    for t_ in (q, k, v):
+        t_[..., :hd] = torch.randn(B, H, Lq, hd, device=dev, generator=g).to(bf16)
+    o = torch.empty(B * Lq, H * hd, dtype=bf16, device=dev)
+    lse = torch.empty(B, H, Lq, dtype=f32, device=dev)
+    ov = ops.heads_view(o, B, Lq, H, hd)
+    fl = 4 * B * H * Lq * Lq * hd
+    t = timeit(lambda: ops.attn_fwd(q[..., :hd], k[..., :hd], v[..., :hd], ov, lse))
+    print(f"{tag} fwd hd{hd}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TF/s")
+    do = torch.randn(B * Lq, H * hd, device=dev, generator=g).to(bf16)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(2, B, H, Lq, dtype=f32, device=dev)
+    dov = ops.heads_view(do, B, Lq, H, hd)
+    ops.prof_enable()
+    for _ in range(4):
+        ops.attn_bwd(q[..., :hd], k[..., :hd], v[..., :hd], ov, lse, dov, dq[..., :hd], dk[..., :hd], dv[..., :hd], delta)
+    st = ops.prof_collect()
+    ops.prof_enable(0)
+    for kname in ("attn_bwd_dkv", "attn_bwd_dq", "attn_bwd_delta"):
+        r = st[kname]
+        print(f"{tag} {kname} hd{hd}: {r['ms']/r['launches']:8.3f} ms {r['flops']/r['ms']/1e9:7.1f} TF/s")

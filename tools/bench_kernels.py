@@ -57,7 +57,7 @@ for hd, H, hdp in ((72, 16, 96), (64, 12, 64), (128, 16, 128)):
     res.append((f"attn fwd hd{hd} H{H} L{Lq}", t, fl / t / 1e12))
     do = rnd(B * Lq, H * hd)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    delta = torch.empty(B, H, Lq, dtype=f32, device=dev)
+    delta = torch.empty(2, B, H, Lq, dtype=f32, device=dev)
     dov = ops.heads_view(do, B, Lq, H, hd)
     t = timeit(lambda: ops.attn_bwd(q[..., :hd], k[..., :hd], v[..., :hd], ov, lse, dov, dq[..., :hd], dk[..., :hd],
                                     dv[..., :hd], delta), iters=5, warm=2)

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "prof.h"
 #include "../../include/vds.h"
+#include <cstdlib>
 
 namespace {
 
@@ -255,29 +256,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   }
 }
 
-// delta[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per row group; HBM-bound preprocess)
-__global__ void attn_delta_kernel(AttnP p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long row = (long)blockIdx.x * 4 + wave;  // over B*H*Lq
-  if (row >= (long)p.B * p.H * p.Lq) return;
-  const int q = row % p.Lq;
-  const int bh = row / p.Lq;
-  const int b = bh / p.H, hh = bh % p.H;
-  const bf16_t* o = p.o + b * p.o_sb + hh * p.o_sh + (long)q * p.o_sl;
-  const bf16_t* d = p.d_o + b * p.do_sb + hh * p.do_sh + (long)q * p.do_sl;
-  float acc = 0.f;
-  for (int e = lane * 2; e < p.hd; e += 128) {
-    const unsigned a = *reinterpret_cast<const unsigned*>(o + e);
-    const unsigned g = *reinterpret_cast<const unsigned*>(d + e);
-    acc += bflo(a) * bflo(g) + bfhi(a) * bfhi(g);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) p.delta[row] = acc;
+// ---- forward, variant 2: lazy-rescale online softmax per 32-key sub-block --------------------
+// The running maximum is only raised (and O, l rescaled) when some row's sub-block maximum exceeds
+// it by more than 2^LAZY_THR (wave-uniform, rare after the first tile), so each 32-key sub-block is
+// an independent chain  S (MFMA) -> exp2 (VALU) -> P V (MFMA): the S products of sub-block kb+1
+// can issue under the VALU work of sub-block kb inside ONE wave, on top of the overlap between
+// the waves that share a SIMD.  P <= 2^LAZY_THR keeps bf16's relative precision; sums are fp32.
+constexpr float LAZY_THR = 8.0f;
+__device__ __forceinline__ float max_with_other_half(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float add_with_other_half(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// ===================================== dQ ===================================================
-template <int HDP, int HDQ>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
+template <int HDP, int HDQ, int WPS>
+__global__ __launch_bounds__(256, WPS) void attn_fwd2_kernel(AttnP p) {
   constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
@@ -287,28 +283,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   const int qrow = qt * 128 + wave * 32 + (lane & 31);
 
   const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
-  const __amdgpu_buffer_rsrc_t rdo = slice_rsrc(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
   const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
   const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
 
-  bf16x8 qf[KSQ], dof[KSQ];
+  bf16x8 qf[KSQ];
 #pragma unroll
   for (int ks = 0; ks < KSQ; ++ks) {
     const int e = ks * 16 + 8 * h;
     unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
-    unsigned off2 = (unsigned)(((long)qrow * p.do_sl + e) * 2);
-    if (e >= p.hd) { off = 0xfffffff0u; off2 = 0xfffffff0u; }
+    if (e >= p.hd) off = 0xfffffff0u;
     qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
-    dof[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdo, off2, 0, 0));
   }
-  const long srow = ((long)b * p.H + hh) * p.Lq + min(qrow, p.Lq - 1);
-  const float lse2 = p.lse[srow] * LOG2E;
-  const float dl = p.delta[srow];
-  const float c = p.scale * LOG2E;
 
-  f32x16 dq[NDB];
+  f32x16 o[NDB];
 #pragma unroll
-  for (int i = 0; i < NDB; ++i) dq[i] = zero16();
+  for (int i = 0; i < NDB; ++i) o[i] = zero16();
+  float m = -1e30f, l = 0.f;  // l: this lane-half's partial row sum
+  const float c = p.scale * LOG2E;
   const int nkt = (p.Lk + 63) / 64;
 
   Stage<64, HDP> sk, sv;
@@ -326,26 +317,45 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     }
     const char* kt = smem + (j & 1) * 2 * TILE;
     const char* vt = kt + TILE;
+    const bool ragged = (j == nkt - 1) && (p.Lk & 63);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s = zero16(), dp = zero16();
+      f32x16 s = zero16();
 #pragma unroll
-      for (int ks = 0; ks < KSQ; ++ks) {
-        s = mfma32(frag_row<HDP>(kt, kb * 32, ks, lane), qf[ks], s);
-        dp = mfma32(frag_row<HDP>(vt, kb * 32, ks, lane), dof[ks], dp);
+      for (int ks = 0; ks < KSQ; ++ks) s = mfma32(frag_row<HDP>(kt, kb * 32, ks, lane), qf[ks], s);
+      if (ragged) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (j * 64 + kb * 32 + acc_row(r, h) >= p.Lk) s[r] = -INFINITY;
       }
+      float mx = fmaxf(s[0], s[1]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pr = __builtin_amdgcn_exp2f(s[r] * c - lse2);
-        if (j * 64 + kb * 32 + acc_row(r, h) >= p.Lk) pr = 0.f;
-        s[r] = pr * (dp[r] - dl);  // dS^T (unscaled)
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 df = acc_frag(s, s2);
+      for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+      mx = max_with_other_half(mx) * c;
+      if (__builtin_amdgcn_ballot_w64(mx > m + LAZY_THR) != 0) {  // wave-uniform, rare
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        l *= alpha;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
-          dq[db] = mfma32(frag_tr<HDP>(kt, kb * 32 + 16 * s2, db * 32, lane), df, dq[db]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[r] * c - m);
+        s[r] = e;
+        ls += e;
+      }
+      l += ls;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s, s2);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+          o[db] = mfma32(frag_tr<HDP>(vt, kb * 32 + 16 * s2, db * 32, lane), pf, o[db]);
       }
     }
     if (more) {
@@ -355,27 +365,425 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     }
     __syncthreads();
   }
+
+  const float lt = add_with_other_half(l);
+  if (qrow < p.Lq) {
+    store_rows<NDB>(p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, o, 1.0f / lt, p.hd, h);
+    if (h == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m + __builtin_amdgcn_logf(lt)) * LN2;
+  }
+}
+
+// ---- forward, variant 3: variant 2 + explicit software pipeline of the LDS fragment reads -----
+// All operand fragments of a 32-key sub-block are read from LDS one phase before the MFMAs that
+// consume them (K fragments of both sub-blocks at the top of the tile, the V^T fragments of a
+// sub-block while the S products / the other sub-block's softmax run), so no MFMA waits on an
+// LDS round trip, and each sub-block's VALU softmax runs under the other sub-block's MFMAs.
+template <int HDP, int KSQ>
+__device__ __forceinline__ void load_kfrags(bf16x8 (&kf)[KSQ], const char* tile, int row0, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) kf[ks] = frag_row<HDP>(tile, row0, ks, lane);
+}
+template <int HDP, int NDB>
+__device__ __forceinline__ void load_vfrags(bf16x8 (&vf)[2][NDB], const char* tile, int row0, int lane) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) vf[s2][db] = frag_tr<HDP>(tile, row0 + 16 * s2, db * 32, lane);
+}
+
+// one 32-key sub-block of the lazy online softmax: s (scores, fp32) -> P fragments (bf16)
+template <int NDB>
+__device__ __forceinline__ void lazy_softmax(f32x16& s, float c, float& m, float& l, f32x16 (&o)[NDB],
+                                             bf16x8 (&pf)[2]) {
+  float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+  for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+  mx = max_with_other_half(mx) * c;
+  if (__builtin_amdgcn_ballot_w64(mx > m + LAZY_THR) != 0) {  // wave-uniform, rare
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    m = m_new;
+    l *= alpha;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+  }
+  float ls = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float e = __builtin_amdgcn_exp2f(s[r] * c - m);
+    s[r] = e;
+    ls += e;
+  }
+  l += ls;
+  pf[0] = acc_frag(s, 0);
+  pf[1] = acc_frag(s, 1);
+}
+
+template <int HDP, int HDQ>
+__global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnP p) {
+  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int qrow = qt * 128 + wave * 32 + (lane & 31);
+
+  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
+  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+
+  bf16x8 qf[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    const int e = ks * 16 + 8 * h;
+    unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
+    if (e >= p.hd) off = 0xfffffff0u;
+    qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+  }
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) o[i] = zero16();
+  float m = -1e30f, l = 0.f;
+  const float c = p.scale * LOG2E;
+  const int nkt = (p.Lk + 63) / 64;
+
+  Stage<64, HDP> sk, sv;
+  sk.issue(rk, 0, p.k_sl, p.hd, tid);
+  sv.issue(rv, 0, p.v_sl, p.hd, tid);
+  sk.commit(smem, tid);
+  sv.commit(smem + TILE, tid);
+  __syncthreads();
+
+  for (int j = 0; j < nkt; ++j) {
+    const bool more = (j + 1 < nkt);
+    if (more) {
+      sk.issue(rk, (j + 1) * 64, p.k_sl, p.hd, tid);
+      sv.issue(rv, (j + 1) * 64, p.v_sl, p.hd, tid);
+    }
+    const char* kt = smem + (j & 1) * 2 * TILE;
+    const char* vt = kt + TILE;
+    const bool ragged = (j == nkt - 1) && (p.Lk & 63);
+
+    bf16x8 k0[KSQ], k1[KSQ];
+    load_kfrags<HDP, KSQ>(k0, kt, 0, lane);
+    load_kfrags<HDP, KSQ>(k1, kt, 32, lane);
+    f32x16 s0 = zero16(), s1 = zero16();
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) s0 = mfma32(k0[ks], qf[ks], s0);
+    bf16x8 v0[2][NDB];
+    load_vfrags<HDP, NDB>(v0, vt, 0, lane);
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) s1 = mfma32(k1[ks], qf[ks], s1);
+    if (ragged) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (j * 64 + acc_row(r, h) >= p.Lk) s0[r] = -INFINITY;
+        if (j * 64 + 32 + acc_row(r, h) >= p.Lk) s1[r] = -INFINITY;
+      }
+    }
+    bf16x8 pf[2];
+    lazy_softmax<NDB>(s0, c, m, l, o, pf);
+    bf16x8 v1[2][NDB];
+    load_vfrags<HDP, NDB>(v1, vt, 32, lane);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) o[db] = mfma32(v0[s2][db], pf[s2], o[db]);
+    bf16x8 pg[2];
+    lazy_softmax<NDB>(s1, c, m, l, o, pg);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) o[db] = mfma32(v1[s2][db], pg[s2], o[db]);
+
+    if (more) {
+      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
+      sk.commit(nk, tid);
+      sv.commit(nk + TILE, tid);
+    }
+    __syncthreads();
+  }
+
+  const float lt = add_with_other_half(l);
+  if (qrow < p.Lq) {
+    store_rows<NDB>(p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, o, 1.0f / lt, p.hd, h);
+    if (h == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m + __builtin_amdgcn_logf(lt)) * LN2;
+  }
+}
+
+// ---- LDS-DMA staging of a ROWS x HDP tile in image (a) ---------------------------------------
+// buffer_load ... lds writes 64 lanes x 16 B = 1 KiB contiguously, so the image's swizzle is applied
+// to the per-lane SOURCE address (guide rule 21): lane i of piece q fills LDS bytes q*1024 + 16 i,
+// i.e. chunk `ch` of row `row` with img_off(row, ch) == that offset.  No staging VGPRs, no
+// ds_write traffic (a ds_write_b128 costs 13 LDS-path cycles per KiB, the DMA 4).
+template <int ROWS, int HDP>
+struct DmaStage {
+  static constexpr int PIECES = ROWS * HDP * 2 / 1024;  // 1-KiB pieces per tile
+  static constexpr int PER_WAVE = PIECES / 4;
+  unsigned voff[PER_WAVE];  // byte offset of this lane's 16-B chunk relative to the tile's first row
+  bool valid[PER_WAVE];
+  __device__ __forceinline__ void init(long sl, int hd, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int q = wave * PER_WAVE + i;
+      const int st = 2 * q + (lane >> 5);
+      const int w = lane & 31, r7 = w >> 2, cs = w & 3;
+      const int row = (st / (HDP / 32)) * 8 + r7;
+      const int ch = (st % (HDP / 32)) * 4 + (cs ^ ((row >> 2) & 3));
+      voff[i] = (unsigned)(((long)row * sl + ch * 8) * 2);
+      valid[i] = ch * 8 < hd;
+    }
+  }
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, char* tile, unsigned row0_bytes, int wave) const {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const unsigned off = valid[i] ? voff[i] + row0_bytes : 0xfffffff0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (wave * PER_WAVE + i) * 1024), 16, off, 0, 0, 0);
+    }
+  }
+};
+
+// ---- forward, variant 4/5: lazy softmax + LDS-DMA staging (PIPE: explicit fragment prefetch) ---
+template <int HDP, int HDQ, int WPS, bool PIPE>
+__global__ __launch_bounds__(256, WPS) void attn_fwd4_kernel(AttnP p) {
+  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qrow = qt * 128 + wave * 32 + (lane & 31);
+
+  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
+  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+
+  DmaStage<64, HDP> dk, dv;
+  dk.init(p.k_sl, p.hd, wave, lane);
+  dv.init(p.v_sl, p.hd, wave, lane);
+  const unsigned k_step = (unsigned)(64 * p.k_sl * 2), v_step = (unsigned)(64 * p.v_sl * 2);
+  dk.issue(rk, smem, 0, wave);
+  dv.issue(rv, smem + TILE, 0, wave);
+
+  bf16x8 qf[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    const int e = ks * 16 + 8 * h;
+    unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
+    if (e >= p.hd) off = 0xfffffff0u;
+    qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+  }
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) o[i] = zero16();
+  float m = -1e30f, l = 0.f;
+  const float c = p.scale * LOG2E;
+  const int nkt = (p.Lk + 63) / 64;
+  __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
+
+  for (int j = 0; j < nkt; ++j) {
+    if (j + 1 < nkt) {
+      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
+      dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
+      dv.issue(rv, nk + TILE, (unsigned)(j + 1) * v_step, wave);
+    }
+    const char* kt = smem + (j & 1) * 2 * TILE;
+    const char* vt = kt + TILE;
+    const bool ragged = (j == nkt - 1) && (p.Lk & 63);
+    if constexpr (PIPE) {
+      bf16x8 k0[KSQ], k1[KSQ];
+      load_kfrags<HDP, KSQ>(k0, kt, 0, lane);
+      load_kfrags<HDP, KSQ>(k1, kt, 32, lane);
+      f32x16 s0 = zero16(), s1 = zero16();
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) s0 = mfma32(k0[ks], qf[ks], s0);
+      bf16x8 v0[2][NDB];
+      load_vfrags<HDP, NDB>(v0, vt, 0, lane);
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) s1 = mfma32(k1[ks], qf[ks], s1);
+      if (ragged) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (j * 64 + acc_row(r, h) >= p.Lk) s0[r] = -INFINITY;
+          if (j * 64 + 32 + acc_row(r, h) >= p.Lk) s1[r] = -INFINITY;
+        }
+      }
+      bf16x8 pf[2];
+      lazy_softmax<NDB>(s0, c, m, l, o, pf);
+      bf16x8 v1[2][NDB];
+      load_vfrags<HDP, NDB>(v1, vt, 32, lane);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) o[db] = mfma32(v0[s2][db], pf[s2], o[db]);
+      bf16x8 pg[2];
+      lazy_softmax<NDB>(s1, c, m, l, o, pg);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) o[db] = mfma32(v1[s2][db], pg[s2], o[db]);
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 s = zero16();
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) s = mfma32(frag_row<HDP>(kt, kb * 32, ks, lane), qf[ks], s);
+        if (ragged) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (j * 64 + kb * 32 + acc_row(r, h) >= p.Lk) s[r] = -INFINITY;
+        }
+        bf16x8 pf[2];
+        lazy_softmax<NDB>(s, c, m, l, o, pf);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int db = 0; db < NDB; ++db)
+            o[db] = mfma32(frag_tr<HDP>(vt, kb * 32 + 16 * s2, db * 32, lane), pf[s2], o[db]);
+      }
+    }
+    __syncthreads();  // vmcnt(0) + barrier: next tile landed, everyone done reading this one
+  }
+
+  const float lt = add_with_other_half(l);
+  if (qrow < p.Lq) {
+    store_rows<NDB>(p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, o, 1.0f / lt, p.hd, h);
+    if (h == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m + __builtin_amdgcn_logf(lt)) * LN2;
+  }
+}
+
+// ndelta[b,h,q] = -sum_d dO[q,d] * O[q,d] and lse2 = lse * log2(e) (one wave per row; HBM-bound
+// preprocess).  Workspace layout: ndelta[0 .. rows) | lse2[rows .. 2 rows).  The NEGATED delta is
+// what the backward kernels load straight into the dP accumulators (dP - delta for free).
+__global__ void attn_delta_kernel(AttnP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long rows = (long)p.B * p.H * p.Lq;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int q = row % p.Lq;
+  const int bh = row / p.Lq;
+  const int b = bh / p.H, hh = bh % p.H;
+  const bf16_t* o = p.o + b * p.o_sb + hh * p.o_sh + (long)q * p.o_sl;
+  const bf16_t* d = p.d_o + b * p.do_sb + hh * p.do_sh + (long)q * p.do_sl;
+  float acc = 0.f;
+  for (int e = lane * 2; e < p.hd; e += 128) {
+    const unsigned a = *reinterpret_cast<const unsigned*>(o + e);
+    const unsigned g = *reinterpret_cast<const unsigned*>(d + e);
+    acc += bflo(a) * bflo(g) + bfhi(a) * bfhi(g);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    p.delta[row] = -acc;
+    p.delta[rows + row] = p.lse[row] * LOG2E;
+  }
+}
+
+// ===================================== dQ ===================================================
+template <int HDP, int HDQ>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
+  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qrow = qt * 128 + wave * 32 + (lane & 31);
+
+  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rdo = slice_rsrc(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
+  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+
+  DmaStage<64, HDP> dk, dv;
+  dk.init(p.k_sl, p.hd, wave, lane);
+  dv.init(p.v_sl, p.hd, wave, lane);
+  const unsigned k_step = (unsigned)(64 * p.k_sl * 2), v_step = (unsigned)(64 * p.v_sl * 2);
+  dk.issue(rk, smem, 0, wave);
+  dv.issue(rv, smem + TILE, 0, wave);
+
+  bf16x8 qf[KSQ], dof[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    const int e = ks * 16 + 8 * h;
+    unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
+    unsigned off2 = (unsigned)(((long)qrow * p.do_sl + e) * 2);
+    if (e >= p.hd) { off = 0xfffffff0u; off2 = 0xfffffff0u; }
+    qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+    dof[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdo, off2, 0, 0));
+  }
+  const long nrows = (long)p.B * p.H * p.Lq;
+  const long srow = ((long)b * p.H + hh) * p.Lq + min(qrow, p.Lq - 1);
+  const float ndl = p.delta[srow];  // -delta of this lane's query
+  const float lse2 = p.delta[nrows + srow];
+  const float c = p.scale * LOG2E;
+
+  f32x16 dq[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) dq[i] = zero16();
+  const int nkt = (p.Lk + 63) / 64;
+  __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
+
+  for (int j = 0; j < nkt; ++j) {
+    if (j + 1 < nkt) {
+      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
+      dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
+      dv.issue(rv, nk + TILE, (unsigned)(j + 1) * v_step, wave);
+    }
+    const char* kt = smem + (j & 1) * 2 * TILE;
+    const char* vt = kt + TILE;
+    // keys past Lk need no mask: their K rows are zero-filled, so whatever dS they get multiplies a
+    // zero row of K in dQ^T += K^T dS^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s = zero16(), dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = ndl;  // accumulator starts at -delta: dP - delta for free
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) {
+        s = mfma32(frag_row<HDP>(kt, kb * 32, ks, lane), qf[ks], s);
+        dp = mfma32(frag_row<HDP>(vt, kb * 32, ks, lane), dof[ks], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * c - lse2) * dp[r];  // dS^T (unscaled)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 df = acc_frag(s, s2);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+          dq[db] = mfma32(frag_tr<HDP>(kt, kb * 32 + 16 * s2, db * 32, lane), df, dq[db]);
+      }
+    }
+    __syncthreads();  // vmcnt(0) + barrier
+  }
   if (qrow < p.Lq)
     store_rows<NDB>(p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl, dq, p.scale, p.hd, h);
 }
 
 // ===================================== dK, dV ===============================================
 // Workgroup = 128 keys (4 waves x 32).  Each wave keeps the K and V rows of its 32 keys as MFMA
-// B-operand fragments in registers for the whole sweep over 64-row Q/dO tiles, so LDS holds only
-// the double-buffered Q/dO tiles (2 workgroups per CU = 2 waves per SIMD: one wave's softmax
-// VALU work overlaps the other's MFMAs).  S and dP have the key on the lane; LSE and delta are
-// per register row.
+// B-operand fragments in registers for the whole sweep over 64-row Q/dO tiles; LDS holds only the
+// double-buffered Q/dO tiles and their row statistics (lse2, delta), all filled by LDS-DMA.
+// Rows past Lq arrive as zeros (SRD bounds): Q = dO = 0 makes their contribution to dV and dK
+// vanish whatever P evaluates to.  S and dP have the key on the lane.
 template <int HDP, int HDQ>
 __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(AttnP p) {
   constexpr int KSQ = HDQ / 16, NDB = HDP / 32, Q_TILE = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS: [buf0: Q | dO][buf1: Q | dO][stats: 2 bufs x (lse2[64], delta[64])]
   char* qbuf = smem;
-  float* stats = reinterpret_cast<float*>(smem + 4 * Q_TILE);
+  char* stats = smem + 4 * Q_TILE;
   int bh, kt_idx;
   if (!decode_block(p.n_rt, p.B * p.H, bh, kt_idx)) return;
   const int b = bh / p.H, hh = bh % p.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int key0 = kt_idx * 128;
   const int krow = key0 + wave * 32 + (lane & 31);
 
@@ -383,9 +791,28 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
   const __amdgpu_buffer_rsrc_t rdo = slice_rsrc(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
   const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
   const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
-  const float* lse_g = p.lse + ((long)b * p.H + hh) * p.Lq;
-  const float* dl_g = p.delta + ((long)b * p.H + hh) * p.Lq;
+  const long nrows = (long)p.B * p.H * p.Lq;
+  const long srow0 = ((long)b * p.H + hh) * p.Lq;
+  // statistics of this head: delta rows then lse2 rows, each bounded to the head's Lq entries
+  const __amdgpu_buffer_rsrc_t rdl = make_rsrc(p.delta + srow0, (unsigned)(p.Lq * 4));
+  const __amdgpu_buffer_rsrc_t rl2 = make_rsrc(p.delta + nrows + srow0, (unsigned)(p.Lq * 4));
   const float c = p.scale * LOG2E;
+
+  DmaStage<64, HDP> dq_, dd_;
+  dq_.init(p.q_sl, p.hd, wave, lane);
+  dd_.init(p.do_sl, p.hd, wave, lane);
+  const unsigned q_step = (unsigned)(64 * p.q_sl * 2), do_step = (unsigned)(64 * p.do_sl * 2);
+  auto issue_tile = [&](int j) {
+    char* nb = qbuf + (j & 1) * 2 * Q_TILE;
+    dq_.issue(rq, nb, (unsigned)j * q_step, wave);
+    dd_.issue(rdo, nb + Q_TILE, (unsigned)j * do_step, wave);
+    if (wave == 0) {  // 64 rows x 4 B each: lse2 then delta
+      char* st = stats + (j & 1) * 512;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rl2, LDS_PTR(st), 4, (unsigned)((j * 64 + lane) * 4), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdl, LDS_PTR(st + 256), 4, (unsigned)((j * 64 + lane) * 4), 0, 0, 0);
+    }
+  };
+  issue_tile(0);
 
   // this lane's key row as B-operand fragments (rows past Lk / columns past hd read as zero)
   bf16x8 kf[KSQ], vf[KSQ];
@@ -399,48 +826,28 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
     vf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, offv, 0, 0));
   }
 
-  Stage<64, HDP> sq, sd;
-  float st_l = 0.f, st_d = 0.f;  // threads 0..63 stage the row statistics of the next tile
-  auto issue_stats = [&](int q0) {
-    if (tid < 64) {
-      const int qq = q0 + tid;
-      const bool ok = qq < p.Lq;
-      st_l = ok ? lse_g[qq] * LOG2E : 1e30f;  // rows past Lq: P = exp2(-inf) = 0
-      st_d = ok ? dl_g[qq] : 0.f;
-    }
-  };
-  auto commit_stats = [&](int buf) {
-    if (tid < 64) {
-      stats[buf * 128 + tid] = st_l;
-      stats[buf * 128 + 64 + tid] = st_d;
-    }
-  };
-  sq.issue(rq, 0, p.q_sl, p.hd, tid);
-  sd.issue(rdo, 0, p.do_sl, p.hd, tid);
-  issue_stats(0);
-  sq.commit(qbuf, tid);
-  sd.commit(qbuf + Q_TILE, tid);
-  commit_stats(0);
-  __syncthreads();
-
   f32x16 dk[NDB], dv[NDB];
 #pragma unroll
   for (int i = 0; i < NDB; ++i) { dk[i] = zero16(); dv[i] = zero16(); }
   const int nqt = (p.Lq + 63) / 64;
+  __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
 
   for (int j = 0; j < nqt; ++j) {
-    const bool more = (j + 1 < nqt);
-    if (more) {
-      sq.issue(rq, (j + 1) * 64, p.q_sl, p.hd, tid);
-      sd.issue(rdo, (j + 1) * 64, p.do_sl, p.hd, tid);
-      issue_stats((j + 1) * 64);
-    }
+    if (j + 1 < nqt) issue_tile(j + 1);
     const char* qt = qbuf + (j & 1) * 2 * Q_TILE;
     const char* dot = qt + Q_TILE;
-    const float* stl = stats + (j & 1) * 128;
+    const float* stl = reinterpret_cast<const float*>(stats + (j & 1) * 512);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      f32x16 s = zero16(), dp = zero16();
+      f32x16 s = zero16(), dp;
+      // the dP accumulator starts at -delta of its rows (register r <-> row (r&3) + 8 (r>>2) + 4 h:
+      // four 16-byte LDS reads land exactly on registers 4 rg .. 4 rg + 3)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qb * 32 + 8 * rg + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[4 * rg + e] = d4[e];
+      }
 #pragma unroll
       for (int ks = 0; ks < KSQ; ++ks) {
         s = mfma32(frag_row<HDP>(qt, qb * 32, ks, lane), kf[ks], s);
@@ -450,13 +857,12 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + qb * 32 + 8 * rg + 4 * h);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qb * 32 + 8 * rg + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * rg + e;
           const float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[e]);
           pm[r] = pr;
-          s[r] = pr * (dp[r] - d4[e]);  // dS (unscaled)
+          s[r] = pr * dp[r];  // dS (unscaled)
         }
       }
 #pragma unroll
@@ -470,13 +876,7 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
         }
       }
     }
-    if (more) {
-      char* nb = qbuf + ((j + 1) & 1) * 2 * Q_TILE;
-      sq.commit(nb, tid);
-      sd.commit(nb + Q_TILE, tid);
-      commit_stats((j + 1) & 1);
-    }
-    __syncthreads();
+    __syncthreads();  // vmcnt(0) + barrier
   }
   if (krow < p.Lk) {
     store_rows<NDB>(p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl, dk, p.scale, p.hd, h);
@@ -518,16 +918,40 @@ void set_lds(K kern, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+int attn_variant() {  // experimentation switch: VDS_ATTN_VARIANT=0 legacy forward, 1 lazy 2 waves/SIMD, 2 lazy 3 waves/SIMD
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VDS_ATTN_VARIANT");
+    v = e ? atoi(e) : 5;
+  }
+  return v;
+}
+
 template <int HDP, int HDQ>
 int run_fwd(AttnP p, hipStream_t s) {
   constexpr int LDS = 4 * 64 * HDP * 2;
+  constexpr int WPS3 = HDP <= 96 ? 3 : 2;
   static bool once = false;
-  if (!once) { set_lds(attn_fwd_kernel<HDP, HDQ>, LDS); once = true; }
+  if (!once) {
+    set_lds(attn_fwd_kernel<HDP, HDQ>, LDS);
+    set_lds(attn_fwd2_kernel<HDP, HDQ, 2>, LDS);
+    set_lds(attn_fwd2_kernel<HDP, HDQ, WPS3>, LDS);
+    set_lds(attn_fwd3_kernel<HDP, HDQ>, LDS);
+    set_lds(attn_fwd4_kernel<HDP, HDQ, 2, true>, LDS);
+    set_lds(attn_fwd4_kernel<HDP, HDQ, WPS3, false>, LDS);
+    once = true;
+  }
   p.n_rt = cdiv(p.Lq, 128);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
   vdsprof::Scope ps(VDS_PROF_ATTN_FWD, s, fl, 2.0 * p.B * p.H * p.hd * (2.0 * p.Lq + 2.0 * p.Lk));
-  hipLaunchKernelGGL((attn_fwd_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS, s, p);
+  const int var = attn_variant();
+  if (var == 0) hipLaunchKernelGGL((attn_fwd_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS, s, p);
+  else if (var == 1) hipLaunchKernelGGL((attn_fwd2_kernel<HDP, HDQ, 2>), dim3(grid), dim3(256), LDS, s, p);
+  else if (var == 2) hipLaunchKernelGGL((attn_fwd2_kernel<HDP, HDQ, WPS3>), dim3(grid), dim3(256), LDS, s, p);
+  else if (var == 3) hipLaunchKernelGGL((attn_fwd3_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS, s, p);
+  else if (var == 4) hipLaunchKernelGGL((attn_fwd4_kernel<HDP, HDQ, 2, true>), dim3(grid), dim3(256), LDS, s, p);
+  else hipLaunchKernelGGL((attn_fwd4_kernel<HDP, HDQ, WPS3, false>), dim3(grid), dim3(256), LDS, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 

@@ -124,7 +124,7 @@ class _Null:
 
 
 def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32, process_group=None,
-               device=None, cast_fn=None):
+               device=None, cast_fn=None, force_runtime=False):
     """Shard `dit_model` over the ranks of `process_group` (default: the world) and return it
     -- the same object, still callable, still exposing get_mup_setup / named_parameters
     (model.py:512-542).  After this call every nn.Parameter is this rank's 1-D fp32 piece of
@@ -154,11 +154,14 @@ def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32
     root, blocks = dit_model._group_members()
     groups = [FlatGroup("root", root, world, rank)]
     groups += [FlatGroup(f"blocks.{i}", m, world, rank) for i, m in enumerate(blocks)]
+    run = world > 1 or (force_runtime and dist.is_initialized())
     for g in groups:
-        g.materialize(device, full_values)
+        g.materialize(device, full_values, separate=run)  # W=1 + runtime: real collectives into separate buffers
     for name, buf in dit_model.named_buffers():
         buf.data = buf.data.to(device)
     dit_model._groups = groups
-    if world > 1:
+    # force_runtime: run the stream / event / collective choreography even at world_size 1 (a 1-rank
+    # process group must be initialised) -- used to test it on a single GPU
+    if run:
         dit_model._fsdp = ShardRuntime(dit_model, cast_fn, process_group)
     return dit_model

@@ -477,7 +477,7 @@ class DiT(nn.Module):
             dcatt = ops.linear_dgrad(dy, W("cross_proj.weight"))
             dqc = torch.empty(B * L, D, dtype=bf16, device=dev)
             dckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
-            delta = torch.empty(B, H, L, dtype=f32, device=dev)
+            delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
             ops.attn_bwd(ops.heads_view(bs.qc, B, L, H, hd), ops.heads_view(bs.ckv, B, Lc, H, hd, 0),
                          ops.heads_view(bs.ckv, B, Lc, H, hd, D), ops.heads_view(bs.catt, B, L, H, hd), bs.lse2,
                          ops.heads_view(dcatt, B, L, H, hd), ops.heads_view(dqc, B, L, H, hd),
@@ -500,7 +500,7 @@ class DiT(nn.Module):
         dq = torch.empty(B, H, L, hdp, dtype=bf16, device=dev)
         dk = torch.empty_like(dq)
         dv = torch.empty_like(dq)
-        delta = torch.empty(B, H, L, dtype=f32, device=dev)
+        delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
         ops.attn_bwd(bs.q[..., :hd], bs.k[..., :hd], bs.v[..., :hd], ops.heads_view(bs.attn, B, L, H, hd), bs.lse1,
                      ops.heads_view(dattn, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta)
         first = (i == 0)

@@ -140,7 +140,10 @@ def attn_fwd(q, k, v, o, lse):
 
 
 def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta):
+    """delta: f32 workspace of 2*B*H*Lq elements (rowsum(dO*O), then lse*log2 e)."""
     B, H, Lq, hd = q.shape
+    assert delta.numel() >= 2 * B * H * Lq and delta.is_contiguous(), "attn_bwd: delta workspace is [2,B,H,Lq] f32"
+    assert lse.is_contiguous()
     Lk = k.shape[2]
     a = AttnArgs()
     a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, hd

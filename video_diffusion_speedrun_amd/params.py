@@ -69,7 +69,7 @@ class FlatGroup:
             return 0, 0
         return lo - s0, hi - s0
 
-    def materialize(self, device, full_values: Optional[Dict[str, torch.Tensor]] = None):
+    def materialize(self, device, full_values: Optional[Dict[str, torch.Tensor]] = None, separate: bool = False):
         """Allocate the flat buffers on `device`, move the current parameter values into the fp32
         master chunk and re-point every nn.Parameter at its slice.  `full_values` supplies the
         full tensors when the parameters are already sharded pieces."""
@@ -94,7 +94,7 @@ class FlatGroup:
         self.master = new_master
         self.shadow = torch.zeros(self.shard, dtype=torch.bfloat16, device=device)
         self.gfull = torch.zeros(self.padded, dtype=torch.float32, device=device)
-        if self.world == 1:
+        if self.world == 1 and not separate:
             self.full, self.gshard = self.shadow, self.gfull
         else:
             self.full = torch.zeros(self.padded, dtype=torch.bfloat16, device=device)
@@ -137,13 +137,13 @@ class FlatGroup:
         if not (skip_cast or self.shadow_fresh):
             cast_fn(self.master, self.shadow)
         self.shadow_fresh = False
-        if self.world > 1:
+        if self.world > 1 or (self.full is not self.shadow):
             all_gather_flat(self.full, self.shadow, group)
         self.gathered = True
 
     def reduce_grads(self, group=None):
         """fp32 reduce-scatter(avg) of the group's gradients into the local shard (C4)."""
-        if self.world > 1:
+        if self.world > 1 or (self.gshard is not self.gfull):
             reduce_scatter_avg(self.gshard, self.gfull, group)
 
     def publish_grads(self):
