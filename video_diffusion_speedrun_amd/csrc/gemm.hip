@@ -20,6 +20,7 @@
 #include "common.h"
 #include "prof.h"
 #include "../../include/vds.h"
+#include <cstdlib>
 
 namespace {
 
@@ -107,6 +108,90 @@ __device__ __forceinline__ bf16x8 frag_km(const char* tile, int col0, int ks, in
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 4 * 256));
   s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, r);
+}
+
+// Shared epilogue: a wave's staged 64x64 fp32 sub-tile (stg, EPI_LD floats per row) -> global memory
+// with the fused elementwise work.  (row0, col0) = global coordinates of the sub-tile.
+template <int EPI>
+__device__ __forceinline__ void epilogue_64x64(const GemmP& p, const float* stg, int row0, int col0, int lane) {
+  if constexpr (EPI == VDS_EPI_F32) {
+    if (p.atomic) {
+      // split-K / accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256
+      // contiguous bytes, the full-rate shape of global_atomic_add_f32 on gfx950)
+      const int acol = col0 + lane;
+      if (acol < p.N) {
+        float* cbase = reinterpret_cast<float*>(p.C) + (long)row0 * p.ldc + acol;
+        const int rmax = min(64, p.M - row0);
+        for (int row = 0; row < rmax; ++row) atomicAdd(cbase + (long)row * p.ldc, stg[row * EPI_LD + lane]);
+      }
+      return;
+    }
+  }
+  const int c8 = lane & 7, rin = lane >> 3;
+  const int gcol = col0 + c8 * 8;
+  if (gcol >= p.N) return;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  if constexpr (EPI != VDS_EPI_F32 && EPI != VDS_EPI_DGELU) {
+    if (p.bias) {
+      u32x4 bv = *reinterpret_cast<const u32x4*>(p.bias + gcol);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias8[2 * e] = bflo(bv[e]); bias8[2 * e + 1] = bfhi(bv[e]); }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + rin;
+    const long grow = row0 + row;
+    if (grow >= p.M) continue;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + c8 * 8);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + c8 * 8 + 4);
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if constexpr (EPI == VDS_EPI_F32) {
+      float* c = reinterpret_cast<float*>(p.C) + grow * p.ldc + gcol;
+      *reinterpret_cast<f32x4*>(c) = lo;
+      *reinterpret_cast<f32x4*>(c + 4) = hi;
+    } else if constexpr (EPI == VDS_EPI_STORE) {
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e] + bias8[2 * e], v[2 * e + 1] + bias8[2 * e + 1]);
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
+    } else if constexpr (EPI == VDS_EPI_BIAS_GELU) {
+      u32x4 o, o2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = v[2 * e] + bias8[2 * e], b = v[2 * e + 1] + bias8[2 * e + 1];
+        o[e] = pack_bf2(a, b);
+        o2[e] = pack_bf2(gelu_f(a), gelu_f(b));
+      }
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + grow * p.ldc2 + gcol) = o2;
+    } else if constexpr (EPI == VDS_EPI_GATE_RES) {
+      const int b = (int)(grow / p.rows_per_batch);
+      const float* gp = p.gate + (long)b * p.ldgate + gcol;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+      const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+      const u32x4 xr = *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol);
+      u32x4 o, o2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = v[2 * e] + bias8[2 * e], bb = v[2 * e + 1] + bias8[2 * e + 1];
+        o[e] = pack_bf2(a, bb);
+        o2[e] = pack_bf2(bflo(xr[e]) + a * g[2 * e], bfhi(xr[e]) + bb * g[2 * e + 1]);
+      }
+      if (p.C) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + grow * p.ldc2 + gcol) = o2;
+    } else if constexpr (EPI == VDS_EPI_DGELU) {
+      const u32x4 pr = *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = pack_bf2(v[2 * e] * dgelu_f(bflo(pr[e])), v[2 * e + 1] * dgelu_f(bfhi(pr[e])));
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
+    }
+  }
 }
 
 template <int LAYOUT, int EPI>
@@ -206,85 +291,247 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own wave's region only, no barrier needed
   __builtin_amdgcn_wave_barrier();
 
-  if constexpr (EPI == VDS_EPI_F32) {
-    if (p.atomic) {
-      // split-K / accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256
-      // contiguous bytes, the full-rate shape of global_atomic_add_f32 on gfx950)
-      const int acol = n0 + wn * 64 + lane;
-      if (acol < p.N) {
-        float* cbase = reinterpret_cast<float*>(p.C) + (long)(m0 + wm * 64) * p.ldc + acol;
-        const int rmax = min(64, p.M - (m0 + wm * 64));
-        for (int row = 0; row < rmax; ++row) atomicAdd(cbase + (long)row * p.ldc, stg[row * EPI_LD + lane]);
-      }
-      return;
-    }
-  }
-  const int c8 = lane & 7, rin = lane >> 3;
-  const int gcol = n0 + wn * 64 + c8 * 8;
-  if (gcol >= p.N) return;
-  float bias8[8];
+  epilogue_64x64<EPI>(p, stg, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// =====================================================================================
+// 256 x 256 x 64 tile, 8 waves (2 x 4), one workgroup per CU: the large-problem kernel.
+//
+//   * each wave owns 128 x 64 outputs = 2 x 2 quadrants of 64 x 32 (16 v_mfma_f32_16x16x32_bf16
+//     per quadrant and K tile, 128 accumulator VGPRs);
+//   * a K tile is staged as FOUR 16-KiB half-tiles (A0, A1, B0, B1): half h of A holds the rows
+//     of quadrant-row h of EVERY wave (64-row groups alternate), half h of B the columns of
+//     quadrant-column h of every wave (32-column groups alternate), so a K tile is consumed
+//     half-tile by half-tile in 4 phases  (A0,B0) -> B1 -> A1 -> (B0 kept in registers)  and each
+//     half-tile's LDS slot is recycled for the K tile two ahead as soon as it has been read;
+//   * half-tiles arrive by LDS-DMA (2 x buffer_load ... lds per thread and half-tile), one
+//     half-tile issued per phase, ~7 phases before its first use; the only waits in the loop
+//     are counted (s_waitcnt vmcnt(10) = "all but the 5 youngest half-tiles have landed") and
+//     raw s_barrier -- never vmcnt(0), never __syncthreads();
+//   * every phase is a LOAD segment (fragment ds_reads, one half-tile issue, waits) and an MFMA
+//     segment separated by barriers; waves 4-7 (the SIMD partners of waves 0-3) run one segment
+//     behind, so on every SIMD one wave's MFMA cluster overlaps its partner's LDS reads / DMA issue.
+// K tiles past the end of the contraction (and the K tail) are fetched as zeros through the SRD
+// bounds, which keeps the wait counts uniform to the last iteration.
+namespace big {
+constexpr int BM = 256, BN = 256;
+constexpr int HALF = 16384;                                 // one half-tile
+constexpr int SLOT_A0 = 0, SLOT_A1 = HALF, SLOT_B0 = 2 * HALF, SLOT_B1 = 3 * HALF, BUF = 4 * HALF;
+constexpr int LDS_BYTES = 8 * 64 * EPI_LD * 4;               // 139264 >= 2 * BUF (131072)
+
+// local index (row of a k-contiguous half-tile, or 8-column chunk base of a k-major one) -> offset
+// inside the 256-wide tile: groups of G consecutive indices alternate between the two halves
+template <int G>
+__device__ __forceinline__ int to_tile(int local, int half) { return (local / G) * (2 * G) + half * G + (local % G); }
+
+// per-lane source byte offsets of the two 1-KiB pieces this wave stages of one half-tile
+template <bool KMAJOR, int G>
+__device__ __forceinline__ void half_offsets(unsigned (&voff)[2], int (&kchunk)[2], int wave, int lane, long ld,
+                                             int origin, int half) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-  if constexpr (EPI != VDS_EPI_F32 && EPI != VDS_EPI_DGELU) {
-    if (p.bias) {
-      u32x4 bv = *reinterpret_cast<const u32x4*>(p.bias + gcol);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bias8[2 * e] = bflo(bv[e]); bias8[2 * e + 1] = bfhi(bv[e]); }
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 8 + rin;
-    const long grow = m0 + wm * 64 + row;
-    if (grow >= p.M) continue;
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + c8 * 8);
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + c8 * 8 + 4);
-    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    if constexpr (EPI == VDS_EPI_F32) {
-      float* c = reinterpret_cast<float*>(p.C) + grow * p.ldc + gcol;
-      *reinterpret_cast<f32x4*>(c) = lo;
-      *reinterpret_cast<f32x4*>(c + 4) = hi;
-    } else if constexpr (EPI == VDS_EPI_STORE) {
-      u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e] + bias8[2 * e], v[2 * e + 1] + bias8[2 * e + 1]);
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
-    } else if constexpr (EPI == VDS_EPI_BIAS_GELU) {
-      u32x4 o, o2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = v[2 * e] + bias8[2 * e], b = v[2 * e + 1] + bias8[2 * e + 1];
-        o[e] = pack_bf2(a, b);
-        o2[e] = pack_bf2(gelu_f(a), gelu_f(b));
-      }
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + grow * p.ldc2 + gcol) = o2;
-    } else if constexpr (EPI == VDS_EPI_GATE_RES) {
-      const int b = (int)(grow / p.rows_per_batch);
-      const float* gp = p.gate + (long)b * p.ldgate + gcol;
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-      const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-      const u32x4 xr = *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol);
-      u32x4 o, o2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = v[2 * e] + bias8[2 * e], bb = v[2 * e + 1] + bias8[2 * e + 1];
-        o[e] = pack_bf2(a, bb);
-        o2[e] = pack_bf2(bflo(xr[e]) + a * g[2 * e], bfhi(xr[e]) + bb * g[2 * e + 1]);
-      }
-      if (p.C) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + grow * p.ldc2 + gcol) = o2;
-    } else if constexpr (EPI == VDS_EPI_DGELU) {
-      const u32x4 pr = *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol);
-      u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        o[e] = pack_bf2(v[2 * e] * dgelu_f(bflo(pr[e])), v[2 * e + 1] * dgelu_f(bfhi(pr[e])));
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
+  for (int j = 0; j < 2; ++j) {
+    const int q = wave * 2 + j;
+    if constexpr (!KMAJOR) {
+      const int row = q * 8 + (lane >> 3);
+      const int chunk = swz_kc(row, lane & 7);
+      kchunk[j] = chunk * 8;
+      voff[j] = (unsigned)(((long)(origin + to_tile<G>(row, half)) * ld + chunk * 8) * 2);
+    } else {
+      const int krow = q * 4 + (lane >> 4);
+      const int pc = lane & 15;
+      const int chunk = (((pc >> 1) ^ swz_km(krow)) << 1) | (pc & 1);
+      kchunk[j] = 0;
+      voff[j] = (unsigned)(((long)krow * ld + origin + to_tile<G>(chunk * 8, half)) * 2);
     }
   }
 }
+
+template <bool KMAJOR>
+__device__ __forceinline__ void issue_half(__amdgpu_buffer_rsrc_t rsrc, char* slot, const unsigned (&voff)[2],
+                                           const int (&kchunk)[2], unsigned koff, int krem, int wave) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    unsigned off = voff[j] + koff;
+    if constexpr (!KMAJOR) {
+      if (kchunk[j] >= krem) off = 0xfffffff0u;  // K tail / tiles past the range: zeros
+    } else {
+      if (krem <= 0) off = 0xfffffff0u;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(slot + (wave * 2 + j) * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+#define VDS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define VDS_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int LAYOUT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool A_KM = (LAYOUT == VDS_TN);
+  constexpr bool B_KM = (LAYOUT != VDS_NT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- tile id: XCD-aware + grouped order (as the 128^2 kernel) ---------------------------
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int group = GROUP_M * p.tiles_n;
+  const int first_m = (pid / group) * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tile_m = first_m + (pid % group) % gsz;
+  const int tile_n = (pid % group) / gsz;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int kt_total = (p.K + BK - 1) / BK;
+  int kt_begin = 0, kt_end = kt_total;
+  if (p.split_k > 1) {
+    int per = (kt_total + p.split_k - 1) / p.split_k;
+    kt_begin = blockIdx.y * per;
+    kt_end = min(kt_total, kt_begin + per);
+    if (kt_begin >= kt_end) return;
+  }
+
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+  unsigned va[2][2], vb[2][2];
+  int ca[2][2], cb[2][2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    half_offsets<A_KM, 64>(va[hf], ca[hf], wave, lane, p.lda, m0, hf);
+    half_offsets<B_KM, 32>(vb[hf], cb[hf], wave, lane, p.ldb, n0, hf);
+  }
+  const unsigned a_step = A_KM ? (unsigned)(BK * p.lda * 2) : BK * 2;
+  const unsigned b_step = B_KM ? (unsigned)(BK * p.ldb * 2) : BK * 2;
+
+  // issue half-tile `which` (0 A0, 1 B0, 2 B1, 3 A1) of K tile T into its slot of buffer T & 1
+  auto issue = [&](int T, int which) {
+    const int krem = (T < kt_end) ? p.K - T * BK : 0;
+    char* buf = smem + (T & 1) * BUF;
+    if (which == 0) issue_half<A_KM>(ra, buf + SLOT_A0, va[0], ca[0], (unsigned)T * a_step, krem, wave);
+    else if (which == 3) issue_half<A_KM>(ra, buf + SLOT_A1, va[1], ca[1], (unsigned)T * a_step, krem, wave);
+    else if (which == 1) issue_half<B_KM>(rb, buf + SLOT_B0, vb[0], cb[0], (unsigned)T * b_step, krem, wave);
+    else issue_half<B_KM>(rb, buf + SLOT_B1, vb[1], cb[1], (unsigned)T * b_step, krem, wave);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: 7 half-tiles in flight, A0 / B0 of the first tile landed -------------------
+  issue(kt_begin, 0); issue(kt_begin, 1); issue(kt_begin, 2); issue(kt_begin, 3);
+  issue(kt_begin + 1, 0); issue(kt_begin + 1, 1); issue(kt_begin + 1, 2);
+  VDS_WAIT_VM(10);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
+
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  auto read_a = [&](const char* slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (A_KM) fa[i][ks] = frag_km(slot, wr * 64 + i * 16, ks, lane);
+        else fa[i][ks] = frag_kc(slot, wr * 64 + i * 16, ks, lane);
+      }
+  };
+  auto read_b = [&](const char* slot, bf16x8 (&fb)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (B_KM) fb[j][ks] = frag_km(slot, wc * 32 + j * 16, ks, lane);
+        else fb[j][ks] = frag_kc(slot, wc * 32 + j * 16, ks, lane);
+      }
+  };
+#define VDS_QUADRANT(QA, QB, FB)                                                                      \
+  do {                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+          acc[(QA) * 4 + i][(QB) * 2 + j] =                                                           \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[j][ks], acc[(QA) * 4 + i][(QB) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+  } while (0)
+
+  for (int T = kt_begin; T < kt_end; ++T) {
+    const char* buf = smem + (T & 1) * BUF;
+    // ---- phase 0: quadrant (0,0) <- A0, B0 ----
+    read_a(buf + SLOT_A0);
+    read_b(buf + SLOT_B0, fb0);
+    issue(T + 1, 3);
+    VDS_WAIT_LGKM0();
+    VDS_WAIT_VM(10);  // B1(T) landed
+    __builtin_amdgcn_s_barrier();
+    VDS_QUADRANT(0, 0, fb0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: quadrant (0,1) <- B1 ----
+    read_b(buf + SLOT_B1, fb1);
+    issue(T + 2, 0);
+    VDS_WAIT_LGKM0();
+    VDS_WAIT_VM(10);  // A1(T) landed
+    __builtin_amdgcn_s_barrier();
+    VDS_QUADRANT(0, 1, fb1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: quadrant (1,1) <- A1 ----
+    read_a(buf + SLOT_A1);
+    issue(T + 2, 1);
+    VDS_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    VDS_QUADRANT(1, 1, fb1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: quadrant (1,0) <- B0 (registers) ----
+    issue(T + 2, 2);
+    VDS_WAIT_VM(10);  // A0(T+1), B0(T+1) landed
+    __builtin_amdgcn_s_barrier();
+    VDS_QUADRANT(1, 0, fb0);
+    __builtin_amdgcn_s_barrier();
+  }
+#undef VDS_QUADRANT
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
+  VDS_WAIT_VM(0);                              // the zero-fill tail DMAs target LDS the epilogue reuses
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: two 64-row quadrant rows per wave through the wave's private staging area ----
+  float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
+#pragma unroll
+  for (int qa = 0; qa < 2; ++qa) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stg[(i * 16 + 4 * (lane >> 4) + r) * EPI_LD + j * 16 + (lane & 15)] = acc[qa * 4 + i][j][r];
+    VDS_WAIT_LGKM0();
+    __builtin_amdgcn_wave_barrier();
+    epilogue_64x64<EPI>(p, stg, m0 + wr * 128 + qa * 64, n0 + wc * 64, lane);
+    __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
+  }
+}
+
+template <int LAYOUT, int EPI>
+int launch(const GemmP& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, p.split_k > 1 ? p.split_k : 1, 1);
+  vdsprof::Scope ps(LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : LAYOUT == VDS_NN ? VDS_PROF_GEMM_NN : VDS_PROF_GEMM_TN, s,
+                    2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI>), grid, dim3(512), LDS_BYTES, s, p);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+}  // namespace big
 
 thread_local char g_err[256] = "";
 
@@ -348,6 +595,34 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (p.atomic && !(a->layout == VDS_TN && a->epilogue == VDS_EPI_F32)) return VDS_ERR_ARG;
   if (!a->C && a->epilogue != VDS_EPI_GATE_RES) return VDS_ERR_ARG;
+  // tile choice: 256^2 (one workgroup per CU, deep LDS-DMA pipeline) for problems that fill the chip
+  // with such tiles; 128^2 otherwise.  VDS_GEMM_TILE=128|256 forces one (experiments).
+  static int force_tile = -1;
+  if (force_tile < 0) {
+    const char* e = getenv("VDS_GEMM_TILE");
+    force_tile = e ? atoi(e) : 0;
+  }
+  // model: a 256^2 workgroup (alone on its CU) sustains ~1.24x the rate of two co-resident 128^2
+  // workgroups; compare the number of rounds each tiling needs (wave quantisation dominates at
+  // these sizes).  Weight gradients (TN, split-K + atomics) stay on the 128^2 kernel.
+  const int tm = cdiv(a->M, 256), tn = cdiv(a->N, 256);
+  const long rounds_big = ((long)tm * tn + 255) / 256;
+  const long rounds_small = ((long)p.tiles_m * p.tiles_n + 511) / 512;
+  bool use_big = a->layout != VDS_TN && a->K >= 256 && (double)rounds_big * (2.0 / 1.24) < (double)rounds_small;
+  if (force_tile == 128) use_big = false;
+  if (force_tile == 256) use_big = true;
+  if (use_big) {
+    p.tiles_m = tm;
+    p.tiles_n = tn;
+#define GOB(L, E) if (a->layout == L && a->epilogue == E) return big::launch<L, E>(p, s);
+    GOB(VDS_NT, VDS_EPI_STORE)
+    GOB(VDS_NT, VDS_EPI_BIAS_GELU)
+    GOB(VDS_NT, VDS_EPI_GATE_RES)
+    GOB(VDS_NN, VDS_EPI_STORE)
+    GOB(VDS_NN, VDS_EPI_DGELU)
+    GOB(VDS_TN, VDS_EPI_F32)
+#undef GOB
+  }
 #define GO(L, E) if (a->layout == L && a->epilogue == E) return launch<L, E>(p, s);
   GO(VDS_NT, VDS_EPI_STORE)
   GO(VDS_NT, VDS_EPI_BIAS_GELU)
