@@ -120,6 +120,15 @@ struct Stage {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const bf16_t* base, long sl, int L, int hd) {
   return make_rsrc(base, (unsigned)((((long)(L - 1)) * sl + hd) * 2));
 }
+__device__ __forceinline__ srd_t slice_srd(const bf16_t* base, long sl, int L, int hd) {
+  return make_srd(base, (unsigned)((((long)(L - 1)) * sl + hd) * 2));
+}
+
+// Make the compiler retire a prologue load HERE (a use it can see): otherwise its s_waitcnt vmcnt(0)
+// for the first use sits inside the main loop, where it also drains the LDS-DMA prefetch of the
+// next tile (vmcnt counts every outstanding vector-memory operation, in order).
+__device__ __forceinline__ void retire(const bf16x8& f) { asm volatile("" ::"v"(f)); }
+__device__ __forceinline__ void retire(float f) { asm volatile("" ::"v"(f)); }
 
 // XCD-aware (b,h,row-tile) decode: all row tiles of a head run on one XCD so that the
 // streamed operand (K/V or Q/dO of that head) stays in that XCD's L2.
@@ -538,11 +547,12 @@ struct DmaStage {
       valid[i] = ch * 8 < hd;
     }
   }
-  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, char* tile, unsigned row0_bytes, int wave) const {
+  __device__ __forceinline__ void issue(srd_t rs, char* tile, unsigned row0_bytes, int wave) const {
+    const unsigned base = lds_addr_of(tile) + wave * PER_WAVE * 1024;
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
       const unsigned off = valid[i] ? voff[i] + row0_bytes : 0xfffffff0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (wave * PER_WAVE + i) * 1024), 16, off, 0, 0, 0);
+      lds_dma16(rs, base + i * 1024, off);
     }
   }
 };
@@ -560,8 +570,8 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd4_kernel(AttnP p) {
   const int qrow = qt * 128 + wave * 32 + (lane & 31);
 
   const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
-  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
-  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+  const srd_t rk = slice_srd(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
+  const srd_t rv = slice_srd(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
 
   DmaStage<64, HDP> dk, dv;
   dk.init(p.k_sl, p.hd, wave, lane);
@@ -585,7 +595,10 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd4_kernel(AttnP p) {
   float m = -1e30f, l = 0.f;
   const float c = p.scale * LOG2E;
   const int nkt = (p.Lk + 63) / 64;
-  __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) retire(qf[ks]);
+  VDS_WAIT_VM(0);
+  __syncthreads();  // tile 0 landed (DMA waited above: the compiler does not see it)
 
   for (int j = 0; j < nkt; ++j) {
     if (j + 1 < nkt) {
@@ -648,7 +661,8 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd4_kernel(AttnP p) {
             o[db] = mfma32(frag_tr<HDP>(vt, kb * 32 + 16 * s2, db * 32, lane), pf[s2], o[db]);
       }
     }
-    __syncthreads();  // vmcnt(0) + barrier: next tile landed, everyone done reading this one
+    VDS_WAIT_VM(0);
+    __syncthreads();  // next tile landed, everyone done reading this one
   }
 
   const float lt = add_with_other_half(l);
@@ -698,8 +712,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 
   const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
   const __amdgpu_buffer_rsrc_t rdo = slice_rsrc(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
-  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
-  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+  const srd_t rk = slice_srd(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
+  const srd_t rv = slice_srd(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
 
   DmaStage<64, HDP> dk, dv;
   dk.init(p.k_sl, p.hd, wave, lane);
@@ -728,7 +742,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
   for (int i = 0; i < NDB; ++i) dq[i] = zero16();
   const int nkt = (p.Lk + 63) / 64;
-  __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) { retire(qf[ks]); retire(dof[ks]); }
+  retire(ndl);
+  retire(lse2);
+  VDS_WAIT_VM(0);
+  __syncthreads();  // tile 0 landed
 
   for (int j = 0; j < nkt; ++j) {
     if (j + 1 < nkt) {
@@ -760,7 +779,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
           dq[db] = mfma32(frag_tr<HDP>(kt, kb * 32 + 16 * s2, db * 32, lane), df, dq[db]);
       }
     }
-    __syncthreads();  // vmcnt(0) + barrier
+    VDS_WAIT_VM(0);
+    __syncthreads();
   }
   if (qrow < p.Lq)
     store_rows<NDB>(p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl, dq, p.scale, p.hd, h);
@@ -787,15 +807,15 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
   const int key0 = kt_idx * 128;
   const int krow = key0 + wave * 32 + (lane & 31);
 
-  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
-  const __amdgpu_buffer_rsrc_t rdo = slice_rsrc(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
+  const srd_t rq = slice_srd(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const srd_t rdo = slice_srd(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
   const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
   const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
   const long nrows = (long)p.B * p.H * p.Lq;
   const long srow0 = ((long)b * p.H + hh) * p.Lq;
   // statistics of this head: delta rows then lse2 rows, each bounded to the head's Lq entries
-  const __amdgpu_buffer_rsrc_t rdl = make_rsrc(p.delta + srow0, (unsigned)(p.Lq * 4));
-  const __amdgpu_buffer_rsrc_t rl2 = make_rsrc(p.delta + nrows + srow0, (unsigned)(p.Lq * 4));
+  const srd_t rdl = make_srd(p.delta + srow0, (unsigned)(p.Lq * 4));
+  const srd_t rl2 = make_srd(p.delta + nrows + srow0, (unsigned)(p.Lq * 4));
   const float c = p.scale * LOG2E;
 
   DmaStage<64, HDP> dq_, dd_;
@@ -808,8 +828,9 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
     dd_.issue(rdo, nb + Q_TILE, (unsigned)j * do_step, wave);
     if (wave == 0) {  // 64 rows x 4 B each: lse2 then delta
       char* st = stats + (j & 1) * 512;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rl2, LDS_PTR(st), 4, (unsigned)((j * 64 + lane) * 4), 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdl, LDS_PTR(st + 256), 4, (unsigned)((j * 64 + lane) * 4), 0, 0, 0);
+      const unsigned sa = lds_addr_of(st);
+      lds_dma4(rl2, sa, (unsigned)((j * 64 + lane) * 4));
+      lds_dma4(rdl, sa + 256, (unsigned)((j * 64 + lane) * 4));
     }
   };
   issue_tile(0);
@@ -830,7 +851,10 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
 #pragma unroll
   for (int i = 0; i < NDB; ++i) { dk[i] = zero16(); dv[i] = zero16(); }
   const int nqt = (p.Lq + 63) / 64;
-  __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) { retire(kf[ks]); retire(vf[ks]); }
+  VDS_WAIT_VM(0);
+  __syncthreads();  // tile 0 landed
 
   for (int j = 0; j < nqt; ++j) {
     if (j + 1 < nqt) issue_tile(j + 1);
@@ -876,7 +900,8 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
         }
       }
     }
-    __syncthreads();  // vmcnt(0) + barrier
+    VDS_WAIT_VM(0);
+    __syncthreads();
   }
   if (krow < p.Lk) {
     store_rows<NDB>(p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl, dk, p.scale, p.hd, h);

@@ -68,5 +68,47 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+// ---- LDS-DMA issued from inline asm ---------------------------------------------------------
+// hipcc's waitcnt pass treats every ds_read_b64_tr_b16 (and any LDS read it cannot disambiguate)
+// as possibly aliasing an outstanding `buffer_load ... lds` and drains vmcnt(0) in front of it,
+// which serialises the prefetch of the next tile with the current tile's MFMAs.  Issued from
+// inline asm the DMA is invisible to that pass; the kernels wait for it themselves with counted
+// `s_waitcnt vmcnt(N)` (VDS_WAIT_VM) before the barrier that publishes the tile.
+typedef __attribute__((ext_vector_type(4))) int srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* p, unsigned bytes) {
+  const unsigned long a = (unsigned long)p;
+  srd_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+// LDS byte address of a pointer into the dynamic LDS array (wave-uniform callers only)
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)LDS_PTR(p));
+}
+// 64 lanes x 16 B from buffer offset `voff` (per lane, range-checked: out of range = zeros) to the
+// 1 KiB at LDS byte address `lds` (wave-uniform).  M0 is saved and restored inside the statement.
+__device__ __forceinline__ void lds_dma16(srd_t srd, unsigned lds, unsigned voff) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds), "v"(voff), "s"(srd)
+      : "memory");
+}
+// 64 lanes x 4 B
+__device__ __forceinline__ void lds_dma4(srd_t srd, unsigned lds, unsigned voff) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds), "v"(voff), "s"(srd)
+      : "memory");
+}
+#define VDS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define VDS_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 static inline unsigned clamp_u32(size_t v) { return v > 0xffffffffull ? 0xffffffffu : (unsigned)v; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -57,11 +57,11 @@ __device__ __forceinline__ int swz_km(int krow) { return (krow & 3) | (((krow >>
 // `krem` (k-contiguous operands only): elements of K left in this tile; 16-byte chunks that start
 // at or past it are redirected out of range (-> zero) so that K need only be a multiple of 8.
 template <bool KMAJOR>
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const unsigned voff[4],
+__device__ __forceinline__ void stage_tile(srd_t rsrc, char* lds_tile, const unsigned voff[4],
                                            unsigned koff, int wave, int lane, int krem) {
+  const unsigned base = lds_addr_of(lds_tile) + wave * 4096;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    char* dst = lds_tile + (wave * 4 + j) * 1024;
     unsigned off = voff[j] + koff;
     if constexpr (!KMAJOR) {
       if (krem < BK) {
@@ -69,7 +69,7 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
         if (swz_kc(row, lane & 7) * 8 >= krem) off = 0xfffffff0u;
       }
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst), 16, off, 0, 0, 0);
+    lds_dma16(rsrc, base + j * 1024, off);
   }
 }
 
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
     if (kt_begin >= kt_end) return;
   }
 
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+  const srd_t ra = make_srd(p.A, p.a_bytes);
+  const srd_t rb = make_srd(p.B, p.b_bytes);
   unsigned va[4], vb[4];
   stage_offsets<A_KM>(va, wave, lane, p.lda, m0);
   stage_offsets<B_KM>(vb, wave, lane, p.ldb, n0);
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   // LDS: [buf0: A | B][buf1: A | B]
   stage_tile<A_KM>(ra, smem, va, kt_begin * a_step, wave, lane, p.K - kt_begin * BK);
   stage_tile<B_KM>(rb, smem + TILE_BYTES, vb, kt_begin * b_step, wave, lane, p.K - kt_begin * BK);
-  __syncthreads();  // vmcnt(0) + barrier: tile kt_begin landed
+  VDS_WAIT_VM(0);
+  __syncthreads();  // tile kt_begin landed (the DMA is invisible to the compiler: waited above)
 
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+    VDS_WAIT_VM(0);
+    __syncthreads();  // next tile landed and everyone is done reading `cur`
     cur ^= 1;
   }
 
@@ -347,8 +349,9 @@ __device__ __forceinline__ void half_offsets(unsigned (&voff)[2], int (&kchunk)[
 }
 
 template <bool KMAJOR>
-__device__ __forceinline__ void issue_half(__amdgpu_buffer_rsrc_t rsrc, char* slot, const unsigned (&voff)[2],
+__device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigned (&voff)[2],
                                            const int (&kchunk)[2], unsigned koff, int krem, int wave) {
+  const unsigned base = lds_addr_of(slot) + wave * 2048;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     unsigned off = voff[j] + koff;
@@ -357,12 +360,9 @@ __device__ __forceinline__ void issue_half(__amdgpu_buffer_rsrc_t rsrc, char* sl
     } else {
       if (krem <= 0) off = 0xfffffff0u;
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(slot + (wave * 2 + j) * 1024), 16, off, 0, 0, 0);
+    lds_dma16(rsrc, base + j * 1024, off);
   }
 }
-
-#define VDS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define VDS_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int LAYOUT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
@@ -396,8 +396,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     if (kt_begin >= kt_end) return;
   }
 
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+  const srd_t ra = make_srd(p.A, p.a_bytes);
+  const srd_t rb = make_srd(p.B, p.b_bytes);
   unsigned va[2][2], vb[2][2];
   int ca[2][2], cb[2][2];
 #pragma unroll
