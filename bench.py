@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0
 # name -> (DiT kwargs, latent [C,T,H,W], default per-GPU batch, description)
 WORKLOADS = {
     # the seq~8k DiT-XL step the metric's target is quoted on (fits one GPU)
-    "c3b": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 4,
+    "c3b": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 6,
             "C3b DiT-XL/2 bf16, latents [16,16,64,64] pt=2 -> 8192+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[1]
     "c2": (dict(hidden_size=768, depth=12, num_heads=12, time_patch_size=1), (16, 16, 32, 32), 8,

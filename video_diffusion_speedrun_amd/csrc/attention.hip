@@ -19,8 +19,9 @@
 //
 // LDS tiles use the 8-row x 32-column sub-tiled, XOR-swizzled image that is conflict-free
 // for both the 16-B row reads and the transposing reads (cdna guide T10 image (a)).
-// K/V (or Q/dO) tiles are staged HBM -> VGPR -> LDS with the loads issued one tile ahead
-// (issue-early / write-late), double-buffered, one barrier per tile.
+// K/V (or Q/dO) tiles go HBM -> LDS by LDS-DMA (buffer_load ... lds issued from inline asm, the
+// image swizzle applied to the per-lane source address), one tile ahead, double-buffered, one
+// barrier per tile; the forward pass uses a lazy-rescale online softmax per 32-key sub-block.
 #include "common.h"
 #include "prof.h"
 #include "../../include/vds.h"
@@ -87,35 +88,8 @@ __device__ __forceinline__ f32x16 zero16() {
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
 }
-// value of the partner lane (l ^ 32)
-__device__ __forceinline__ float other_half(float x) { return __shfl_xor(x, 32, 64); }
 // row index inside a 32x32 accumulator: reg -> (reg&3) + 8*(reg>>2) + 4*h
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-
-// ---- staged tile loads: ROWS x HDP bf16 through registers ------------------------------------
-template <int ROWS, int HDP>
-struct Stage {
-  static constexpr int NCH = HDP / 8;
-  static constexpr int N = ROWS * NCH / 256;
-  u32x4 r[N];
-  // rsrc covers rows [0, L) of one (b,h) slice; rows >= L and chunks >= hd/8 read zero
-  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, int row0, long sl, int hd, int tid) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
-      unsigned off = (unsigned)(((long)(row0 + row) * sl + ch * 8) * 2);
-      if (ch * 8 >= hd) off = 0xfffffff0u;
-      r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-    }
-  }
-  __device__ __forceinline__ void commit(char* tile, int tid) const {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
-      *reinterpret_cast<u32x4*>(tile + img_off<HDP>(row, ch)) = r[i];
-    }
-  }
-};
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const bf16_t* base, long sl, int L, int hd) {
   return make_rsrc(base, (unsigned)((((long)(L - 1)) * sl + hd) * 2));
@@ -157,115 +131,7 @@ __device__ __forceinline__ void store_rows(bf16_t* rowp, const f32x16 (&acc)[NDB
 }
 
 // ===================================== forward ==============================================
-template <int HDP, int HDQ>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
-  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
-  const int b = bh / p.H, hh = bh % p.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int qrow = qt * 128 + wave * 32 + (lane & 31);
-
-  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
-  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
-  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
-
-  bf16x8 qf[KSQ];
-#pragma unroll
-  for (int ks = 0; ks < KSQ; ++ks) {
-    const int e = ks * 16 + 8 * h;
-    unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
-    if (e >= p.hd) off = 0xfffffff0u;
-    qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
-  }
-
-  f32x16 o[NDB];
-#pragma unroll
-  for (int i = 0; i < NDB; ++i) o[i] = zero16();
-  float m = -1e30f, l = 0.f;
-  const float c = p.scale * LOG2E;
-  const int nkt = (p.Lk + 63) / 64;
-
-  Stage<64, HDP> sk, sv;
-  sk.issue(rk, 0, p.k_sl, p.hd, tid);
-  sv.issue(rv, 0, p.v_sl, p.hd, tid);
-  sk.commit(smem, tid);
-  sv.commit(smem + TILE, tid);
-  __syncthreads();
-
-  for (int j = 0; j < nkt; ++j) {
-    const bool more = (j + 1 < nkt);
-    if (more) {
-      sk.issue(rk, (j + 1) * 64, p.k_sl, p.hd, tid);
-      sv.issue(rv, (j + 1) * 64, p.v_sl, p.hd, tid);
-    }
-    const char* kt = smem + (j & 1) * 2 * TILE;
-    const char* vt = kt + TILE;
-
-    f32x16 s[2] = {zero16(), zero16()};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ks = 0; ks < KSQ; ++ks) s[kb] = mfma32(frag_row<HDP>(kt, kb * 32, ks, lane), qf[ks], s[kb]);
-
-    if (j == nkt - 1 && (p.Lk & 63)) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (j * 64 + kb * 32 + acc_row(r, h) >= p.Lk) s[kb][r] = -INFINITY;
-    }
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, other_half(mx));
-    const float m_new = fmaxf(m, mx * c);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-    m = m_new;
-    float ls = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[kb][r] * c - m_new);
-        s[kb][r] = e;
-        ls += e;
-      }
-    l = l * alpha + ls;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = acc_frag(s[kb], s2);
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-          o[db] = mfma32(frag_tr<HDP>(vt, kb * 32 + 16 * s2, db * 32, lane), pf, o[db]);
-      }
-
-    if (more) {
-      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
-      sk.commit(nk, tid);
-      sv.commit(nk + TILE, tid);
-    }
-    __syncthreads();
-  }
-
-  const float lt = l + other_half(l);
-  if (qrow < p.Lq) {
-    store_rows<NDB>(p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, o, 1.0f / lt, p.hd, h);
-    if (h == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m + __builtin_amdgcn_logf(lt)) * LN2;
-  }
-}
-
-// ---- forward, variant 2: lazy-rescale online softmax per 32-key sub-block --------------------
+// ---- lazy-rescale online softmax per 32-key sub-block ---------------------------------------
 // The running maximum is only raised (and O, l rescaled) when some row's sub-block maximum exceeds
 // it by more than 2^LAZY_THR (wave-uniform, rare after the first tile), so each 32-key sub-block is
 // an independent chain  S (MFMA) -> exp2 (VALU) -> P V (MFMA): the S products of sub-block kb+1
@@ -281,108 +147,7 @@ __device__ __forceinline__ float add_with_other_half(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int HDP, int HDQ, int WPS>
-__global__ __launch_bounds__(256, WPS) void attn_fwd2_kernel(AttnP p) {
-  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
-  const int b = bh / p.H, hh = bh % p.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int qrow = qt * 128 + wave * 32 + (lane & 31);
-
-  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
-  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
-  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
-
-  bf16x8 qf[KSQ];
-#pragma unroll
-  for (int ks = 0; ks < KSQ; ++ks) {
-    const int e = ks * 16 + 8 * h;
-    unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
-    if (e >= p.hd) off = 0xfffffff0u;
-    qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
-  }
-
-  f32x16 o[NDB];
-#pragma unroll
-  for (int i = 0; i < NDB; ++i) o[i] = zero16();
-  float m = -1e30f, l = 0.f;  // l: this lane-half's partial row sum
-  const float c = p.scale * LOG2E;
-  const int nkt = (p.Lk + 63) / 64;
-
-  Stage<64, HDP> sk, sv;
-  sk.issue(rk, 0, p.k_sl, p.hd, tid);
-  sv.issue(rv, 0, p.v_sl, p.hd, tid);
-  sk.commit(smem, tid);
-  sv.commit(smem + TILE, tid);
-  __syncthreads();
-
-  for (int j = 0; j < nkt; ++j) {
-    const bool more = (j + 1 < nkt);
-    if (more) {
-      sk.issue(rk, (j + 1) * 64, p.k_sl, p.hd, tid);
-      sv.issue(rv, (j + 1) * 64, p.v_sl, p.hd, tid);
-    }
-    const char* kt = smem + (j & 1) * 2 * TILE;
-    const char* vt = kt + TILE;
-    const bool ragged = (j == nkt - 1) && (p.Lk & 63);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s = zero16();
-#pragma unroll
-      for (int ks = 0; ks < KSQ; ++ks) s = mfma32(frag_row<HDP>(kt, kb * 32, ks, lane), qf[ks], s);
-      if (ragged) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (j * 64 + kb * 32 + acc_row(r, h) >= p.Lk) s[r] = -INFINITY;
-      }
-      float mx = fmaxf(s[0], s[1]);
-#pragma unroll
-      for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
-      mx = max_with_other_half(mx) * c;
-      if (__builtin_amdgcn_ballot_w64(mx > m + LAZY_THR) != 0) {  // wave-uniform, rare
-        const float m_new = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        m = m_new;
-        l *= alpha;
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-      }
-      float ls = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[r] * c - m);
-        s[r] = e;
-        ls += e;
-      }
-      l += ls;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = acc_frag(s, s2);
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-          o[db] = mfma32(frag_tr<HDP>(vt, kb * 32 + 16 * s2, db * 32, lane), pf, o[db]);
-      }
-    }
-    if (more) {
-      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
-      sk.commit(nk, tid);
-      sv.commit(nk + TILE, tid);
-    }
-    __syncthreads();
-  }
-
-  const float lt = add_with_other_half(l);
-  if (qrow < p.Lq) {
-    store_rows<NDB>(p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, o, 1.0f / lt, p.hd, h);
-    if (h == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m + __builtin_amdgcn_logf(lt)) * LN2;
-  }
-}
-
-// ---- forward, variant 3: variant 2 + explicit software pipeline of the LDS fragment reads -----
+// ---- explicit software pipeline of the LDS fragment reads ------------------------------------
 // All operand fragments of a 32-key sub-block are read from LDS one phase before the MFMAs that
 // consume them (K fragments of both sub-blocks at the top of the tile, the V^T fragments of a
 // sub-block while the S products / the other sub-block's softmax run), so no MFMA waits on an
@@ -430,100 +195,6 @@ __device__ __forceinline__ void lazy_softmax(f32x16& s, float c, float& m, float
   pf[1] = acc_frag(s, 1);
 }
 
-template <int HDP, int HDQ>
-__global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnP p) {
-  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
-  const int b = bh / p.H, hh = bh % p.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int qrow = qt * 128 + wave * 32 + (lane & 31);
-
-  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
-  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
-  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
-
-  bf16x8 qf[KSQ];
-#pragma unroll
-  for (int ks = 0; ks < KSQ; ++ks) {
-    const int e = ks * 16 + 8 * h;
-    unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
-    if (e >= p.hd) off = 0xfffffff0u;
-    qf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
-  }
-
-  f32x16 o[NDB];
-#pragma unroll
-  for (int i = 0; i < NDB; ++i) o[i] = zero16();
-  float m = -1e30f, l = 0.f;
-  const float c = p.scale * LOG2E;
-  const int nkt = (p.Lk + 63) / 64;
-
-  Stage<64, HDP> sk, sv;
-  sk.issue(rk, 0, p.k_sl, p.hd, tid);
-  sv.issue(rv, 0, p.v_sl, p.hd, tid);
-  sk.commit(smem, tid);
-  sv.commit(smem + TILE, tid);
-  __syncthreads();
-
-  for (int j = 0; j < nkt; ++j) {
-    const bool more = (j + 1 < nkt);
-    if (more) {
-      sk.issue(rk, (j + 1) * 64, p.k_sl, p.hd, tid);
-      sv.issue(rv, (j + 1) * 64, p.v_sl, p.hd, tid);
-    }
-    const char* kt = smem + (j & 1) * 2 * TILE;
-    const char* vt = kt + TILE;
-    const bool ragged = (j == nkt - 1) && (p.Lk & 63);
-
-    bf16x8 k0[KSQ], k1[KSQ];
-    load_kfrags<HDP, KSQ>(k0, kt, 0, lane);
-    load_kfrags<HDP, KSQ>(k1, kt, 32, lane);
-    f32x16 s0 = zero16(), s1 = zero16();
-#pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) s0 = mfma32(k0[ks], qf[ks], s0);
-    bf16x8 v0[2][NDB];
-    load_vfrags<HDP, NDB>(v0, vt, 0, lane);
-#pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) s1 = mfma32(k1[ks], qf[ks], s1);
-    if (ragged) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (j * 64 + acc_row(r, h) >= p.Lk) s0[r] = -INFINITY;
-        if (j * 64 + 32 + acc_row(r, h) >= p.Lk) s1[r] = -INFINITY;
-      }
-    }
-    bf16x8 pf[2];
-    lazy_softmax<NDB>(s0, c, m, l, o, pf);
-    bf16x8 v1[2][NDB];
-    load_vfrags<HDP, NDB>(v1, vt, 32, lane);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int db = 0; db < NDB; ++db) o[db] = mfma32(v0[s2][db], pf[s2], o[db]);
-    bf16x8 pg[2];
-    lazy_softmax<NDB>(s1, c, m, l, o, pg);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int db = 0; db < NDB; ++db) o[db] = mfma32(v1[s2][db], pg[s2], o[db]);
-
-    if (more) {
-      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
-      sk.commit(nk, tid);
-      sv.commit(nk + TILE, tid);
-    }
-    __syncthreads();
-  }
-
-  const float lt = add_with_other_half(l);
-  if (qrow < p.Lq) {
-    store_rows<NDB>(p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, o, 1.0f / lt, p.hd, h);
-    if (h == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m + __builtin_amdgcn_logf(lt)) * LN2;
-  }
-}
-
 // ---- LDS-DMA staging of a ROWS x HDP tile in image (a) ---------------------------------------
 // buffer_load ... lds writes 64 lanes x 16 B = 1 KiB contiguously, so the image's swizzle is applied
 // to the per-lane SOURCE address (guide rule 21): lane i of piece q fills LDS bytes q*1024 + 16 i,
@@ -557,9 +228,9 @@ struct DmaStage {
   }
 };
 
-// ---- forward, variant 4/5: lazy softmax + LDS-DMA staging (PIPE: explicit fragment prefetch) ---
+// ---- forward kernel: lazy softmax + LDS-DMA staging (PIPE: explicit fragment prefetch) ---------
 template <int HDP, int HDQ, int WPS, bool PIPE>
-__global__ __launch_bounds__(256, WPS) void attn_fwd4_kernel(AttnP p) {
+__global__ __launch_bounds__(256, WPS) void attn_fwd_kernel(AttnP p) {
   constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
@@ -693,6 +364,42 @@ __global__ void attn_delta_kernel(AttnP p) {
   }
   acc = wave_sum(acc);
   if (lane == 0) {
+    p.delta[row] = -acc;
+    p.delta[rows + row] = p.lse[row] * LOG2E;
+  }
+}
+
+// token-major fast path of the same preprocess: O and dO are [B*Lq, H*hd] row-major (what the model
+// passes), one wave per token reads both rows with 16-byte accesses; each 8-element chunk belongs
+// to one head (hd % 8 == 0), the per-chunk partial dots are folded per head through LDS.
+__global__ __launch_bounds__(256) void attn_delta_tokmajor_kernel(AttnP p) {
+  __shared__ float part[4][192];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long tok = (long)blockIdx.x * 4 + wave;  // over B*Lq
+  if (tok >= (long)p.B * p.Lq) return;
+  const int b = (int)(tok / p.Lq), q = (int)(tok % p.Lq);
+  const int nch = p.H * p.hd / 8, cph = p.hd / 8;
+  const bf16_t* o = p.o + b * p.o_sb + (long)q * p.o_sl;
+  const bf16_t* d = p.d_o + b * p.do_sb + (long)q * p.do_sl;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(o + c * 8);
+      const u32x4 g = *reinterpret_cast<const u32x4*>(d + c * 8);
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc += bflo(a[e]) * bflo(g[e]) + bfhi(a[e]) * bfhi(g[e]);
+      part[wave][c] = acc;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes
+  __builtin_amdgcn_wave_barrier();
+  if (lane < p.H) {
+    float acc = 0.f;
+    for (int i = 0; i < cph; ++i) acc += part[wave][lane * cph + i];
+    const long rows = (long)p.B * p.H * p.Lq;
+    const long row = ((long)b * p.H + lane) * p.Lq + q;
     p.delta[row] = -acc;
     p.delta[rows + row] = p.lse[row] * LOG2E;
   }
@@ -943,40 +650,16 @@ void set_lds(K kern, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int attn_variant() {  // experimentation switch: VDS_ATTN_VARIANT=0 legacy forward, 1 lazy 2 waves/SIMD, 2 lazy 3 waves/SIMD
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VDS_ATTN_VARIANT");
-    v = e ? atoi(e) : 5;
-  }
-  return v;
-}
-
 template <int HDP, int HDQ>
 int run_fwd(AttnP p, hipStream_t s) {
   constexpr int LDS = 4 * 64 * HDP * 2;
-  constexpr int WPS3 = HDP <= 96 ? 3 : 2;
   static bool once = false;
-  if (!once) {
-    set_lds(attn_fwd_kernel<HDP, HDQ>, LDS);
-    set_lds(attn_fwd2_kernel<HDP, HDQ, 2>, LDS);
-    set_lds(attn_fwd2_kernel<HDP, HDQ, WPS3>, LDS);
-    set_lds(attn_fwd3_kernel<HDP, HDQ>, LDS);
-    set_lds(attn_fwd4_kernel<HDP, HDQ, 2, true>, LDS);
-    set_lds(attn_fwd4_kernel<HDP, HDQ, WPS3, false>, LDS);
-    once = true;
-  }
+  if (!once) { set_lds(attn_fwd_kernel<HDP, HDQ, 2, true>, LDS); once = true; }
   p.n_rt = cdiv(p.Lq, 128);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
   vdsprof::Scope ps(VDS_PROF_ATTN_FWD, s, fl, 2.0 * p.B * p.H * p.hd * (2.0 * p.Lq + 2.0 * p.Lk));
-  const int var = attn_variant();
-  if (var == 0) hipLaunchKernelGGL((attn_fwd_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS, s, p);
-  else if (var == 1) hipLaunchKernelGGL((attn_fwd2_kernel<HDP, HDQ, 2>), dim3(grid), dim3(256), LDS, s, p);
-  else if (var == 2) hipLaunchKernelGGL((attn_fwd2_kernel<HDP, HDQ, WPS3>), dim3(grid), dim3(256), LDS, s, p);
-  else if (var == 3) hipLaunchKernelGGL((attn_fwd3_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS, s, p);
-  else if (var == 4) hipLaunchKernelGGL((attn_fwd4_kernel<HDP, HDQ, 2, true>), dim3(grid), dim3(256), LDS, s, p);
-  else hipLaunchKernelGGL((attn_fwd4_kernel<HDP, HDQ, WPS3, false>), dim3(grid), dim3(256), LDS, s, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<HDP, HDQ, 2, true>), dim3(grid), dim3(256), LDS, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 
@@ -996,7 +679,12 @@ int run_bwd(AttnP p, hipStream_t s) {
   const double qb = 2.0 * p.B * p.H * p.hd * (double)p.Lq, kb = 2.0 * p.B * p.H * p.hd * (double)p.Lk;
   {
     vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DELTA, s, 2.0 * rows * p.hd, 2.0 * qb);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
+    const bool tokmajor = p.o_sh == p.hd && p.do_sh == p.hd && p.o_sl == (long)p.H * p.hd && p.do_sl == p.o_sl &&
+                          (p.o_sl & 7) == 0 && (p.o_sb & 7) == 0 && (p.do_sb & 7) == 0 && p.H * p.hd <= 1536 && p.H <= 64;
+    if (tokmajor)
+      hipLaunchKernelGGL(attn_delta_tokmajor_kernel, dim3((unsigned)(((long)p.B * p.Lq + 3) / 4)), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
   }
   p.n_rt = cdiv(p.Lk, 128);
   int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
