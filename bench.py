@@ -228,8 +228,16 @@ def main():
             else:
                 ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
                 peak, unit = PEAK_HBM_GBS, "GB/s"
+            traffic = None  # HBM bytes per launch: from the committed PMC pass of this kernel / workload, if any
+            try:
+                tj = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
+                if tj["workload"] == args.workload and tj["per_gpu_batch"] == B and dominant in tj["kernels"]:
+                    k = tj["kernels"][dominant]
+                    traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": ach, "peak": peak, "unit": unit,
-                               "frac": ach / peak, "traffic": None, "kernel": dominant,
+                               "frac": ach / peak, "traffic": traffic, "kernel": dominant,
                                "launches": dom["launches"], "avg_ms": dom["ms"] / dom["launches"]}
         if breakdown:
             tot = sum(v["ms"] for v in breakdown.values())

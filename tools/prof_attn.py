@@ -5,7 +5,7 @@ import torch
 from video_diffusion_speedrun_amd import ops
 bf16, f32 = torch.bfloat16, torch.float32
 dev = "cuda"
-B, H, hd, hdp, Lq = 2, 16, 72, 96, 8208
+B, H, hd, hdp, Lq = int(os.environ.get("B", 6)), 16, 72, 96, 8208
 g = torch.Generator(device=dev).manual_seed(0)
 q, k, v = (torch.zeros(B, H, Lq, hdp, dtype=bf16, device=dev) for _ in range(3))
 for t_ in (q, k, v):
