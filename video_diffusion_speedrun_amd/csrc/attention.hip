@@ -686,6 +686,8 @@ int run_bwd(AttnP p, hipStream_t s) {
     else
       hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
   }
+  // (a 64-keys-per-wave, one-wave-per-SIMD variant of this kernel -- half the LDS reads per MFMA -- was
+  // measured at 0.55-0.8x: hipcc's single-wave schedule does not overlap the VALU softmax with the MFMAs)
   p.n_rt = cdiv(p.Lk, 128);
   int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {

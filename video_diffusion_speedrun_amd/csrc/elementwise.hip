@@ -75,8 +75,11 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
 
 // Backward.  grid = (row-groups, B); each wave walks rows of ONE sample so that the
 // d(shift), d(scale) sums over L stay in registers; one atomicAdd per column per block.
-template <int NC>
-__global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const bf16_t* dy, long lddy, const bf16_t* x, long ldx,
+// dy and x stay PACKED (bf16) between the two passes over a row and the norm-weight terms are
+// compiled out when there is no weight (the reference's default), which keeps the kernel at
+// >= 4 waves per SIMD -- it is HBM-bound and needs the loads in flight.
+template <int NC, bool HAS_W>
+__global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mod_bwd_kernel(const bf16_t* dy, long lddy, const bf16_t* x, long ldx,
                                                               const bf16_t* w, const float* mod, long ldmod,
                                                               int shift_col, int scale_col, const float* rstd,
                                                               const bf16_t* dres, long lddres, bf16_t* dx, long lddx,
@@ -88,43 +91,59 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const bf16_t* dy, 
   const int nch = D >> 3;
   const int l0 = blockIdx.x * rows_per_block;
   const int l1 = min(L, l0 + rows_per_block);
-  float sc1[NC][8], wv[NC][8], a_shift[NC][8], a_scale[NC][8], a_w[NC][8];
+  float sc1[NC][8], a_shift[NC][8], a_scale[NC][8];
+  float wv[HAS_W ? NC : 1][8], a_w[HAS_W ? NC : 1][8];
   const float* mrow = mod + (long)b * ldmod;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { a_shift[i][e] = 0.f; a_scale[i][e] = 0.f; a_w[i][e] = 0.f; sc1[i][e] = 0.f; wv[i][e] = 1.f; }
+    for (int e = 0; e < 8; ++e) { a_shift[i][e] = 0.f; a_scale[i][e] = 0.f; sc1[i][e] = 0.f; }
+    if constexpr (HAS_W) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a_w[i][e] = 0.f; wv[i][e] = 1.f; }
+    }
     if (c < nch) {
       load8f(mrow + scale_col + c * 8, sc1[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) sc1[i][e] += 1.0f;
-      if (w) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv[i]);
+      if constexpr (HAS_W) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv[i]);
     }
   }
   for (int l = l0 + wave; l < l1; l += 4) {
     const long row = (long)b * L + l;
     const float r = rstd[row];
-    float g[NC][8], xh[NC][8];
+    u32x4 pdy[NC], px[NC];
     float dot = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
-        float dyv[8], xv[8];
-        unpack8(*reinterpret_cast<const u32x4*>(dy + row * lddy + c * 8), dyv);
-        unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + c * 8), xv);
+        pdy[i] = *reinterpret_cast<const u32x4*>(dy + row * lddy + c * 8);
+        px[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
+      } else {
+        pdy[i] = u32x4{0u, 0u, 0u, 0u};
+        px[i] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xhat = xv[e] * r;
-          xh[i][e] = xhat;
-          a_shift[i][e] += dyv[e];
+    for (int i = 0; i < NC; ++i) {
+      float dyv[8], xv[8];
+      unpack8(pdy[i], dyv);
+      unpack8(px[i], xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xhat = xv[e] * r;
+        a_shift[i][e] += dyv[e];
+        float t = dyv[e] * sc1[i][e];  // d/d(xhat*w)
+        if constexpr (HAS_W) {
           a_scale[i][e] += dyv[e] * xhat * wv[i][e];
-          const float t = dyv[e] * sc1[i][e];  // d/d(xhat*w)
           a_w[i][e] += t * xhat;
-          g[i][e] = t * wv[i][e];               // d/d xhat
-          dot += g[i][e] * xhat;
+          t *= wv[i][e];                // d/d xhat
+        } else {
+          a_scale[i][e] += dyv[e] * xhat;
         }
+        dot += t * xhat;
       }
     }
     dot = wave_sum(dot) / (float)D;
@@ -132,37 +151,45 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const bf16_t* dy, 
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
-        float o[8];
+        float o[8], dyv[8], xv[8];
         if (dres) unpack8(*reinterpret_cast<const u32x4*>(dres + row * lddres + c * 8), o);
         else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = 0.f;
         }
+        unpack8(pdy[i], dyv);
+        unpack8(px[i], xv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += r * (g[i][e] - xh[i][e] * dot);
+        for (int e = 0; e < 8; ++e) {
+          float g = dyv[e] * sc1[i][e];
+          if constexpr (HAS_W) g *= wv[i][e];
+          o[e] += r * (g - xv[e] * r * dot);
+        }
         *reinterpret_cast<u32x4*>(dx + row * lddx + c * 8) = pack8(o);
       }
     }
   }
-  // block reduction of the three column sums, one pass each through LDS
+  // block reduction of the column sums, one pass each through LDS
   float* drow = dmod + (long)b * ldmod;
-  for (int pass = 0; pass < 3; ++pass) {
-    if (pass == 2 && !dw) break;
+  for (int pass = 0; pass < (HAS_W ? 3 : 2); ++pass) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NC; ++i)
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        red[wave][(i * 64 + lane) * 8 + e] = pass == 0 ? a_shift[i][e] : (pass == 1 ? a_scale[i][e] : a_w[i][e]);
+      for (int e = 0; e < 8; ++e) {
+        float v = pass == 0 ? a_shift[i][e] : a_scale[i][e];
+        if constexpr (HAS_W) { if (pass == 2) v = a_w[i][e]; }
+        red[wave][(i * 64 + lane) * 8 + e] = v;
+      }
     __syncthreads();
     for (int idx = threadIdx.x; idx < NC * 64 * 8; idx += 256) {
       const int i = idx / 512, rem = idx % 512, ln = rem / 8, e = rem % 8;
       const int col = (ln + 64 * i) * 8 + e;
       if (col < D) {
-        const float s = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
-        if (pass == 0) atomicAdd(drow + shift_col + col, s);
-        else if (pass == 1) atomicAdd(drow + scale_col + col, s);
-        else atomicAdd(dw + col, s);
+        const float sm = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+        if (pass == 0) atomicAdd(drow + shift_col + col, sm);
+        else if (pass == 1) atomicAdd(drow + scale_col + col, sm);
+        else atomicAdd(dw + col, sm);
       }
     }
   }
@@ -700,10 +727,18 @@ extern "C" int vds_rmsnorm_mod_bwd(const void* dy, int64_t lddy, const void* x, 
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((L + rpb - 1) / rpb, B);
   vdsprof::Scope ps(VDS_PROF_RMSNORM_BWD, s, 0.0, (dres ? 8.0 : 6.0) * B * L * D + 4.0 * B * L);
-#define CALL(NC)                                                                                                \
-  hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NC>), grid, dim3(256), 0, s, (const bf16_t*)dy, (long)lddy,         \
-                     (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, rstd, \
-                     (const bf16_t*)dres, (long)lddres, (bf16_t*)dx, (long)lddx, dmod, w ? dw : nullptr, B, L, D, rpb)
+#define CALL(NC)                                                                                                  \
+  do {                                                                                                            \
+    if (w)                                                                                                        \
+      hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NC, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, (long)lddy, \
+                         (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col,   \
+                         rstd, (const bf16_t*)dres, (long)lddres, (bf16_t*)dx, (long)lddx, dmod, dw, B, L, D, rpb); \
+    else                                                                                                          \
+      hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NC, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (long)lddy, \
+                         (const bf16_t*)x, (long)ldx, (const bf16_t*)nullptr, mod, (long)ldmod, shift_col,        \
+                         scale_col, rstd, (const bf16_t*)dres, (long)lddres, (bf16_t*)dx, (long)lddx, dmod,       \
+                         (float*)nullptr, B, L, D, rpb);                                                          \
+  } while (0)
   NC_DISPATCH(D, CALL);
 #undef CALL
   return ok();
