@@ -82,6 +82,13 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+#ifdef VDS_ATTN_PRIO
+#define PRIO_HI() __builtin_amdgcn_s_setprio(1)
+#define PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define PRIO_HI()
+#define PRIO_LO()
+#endif
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -579,11 +586,13 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
 #pragma unroll
         for (int e = 0; e < 4; ++e) dp[4 * rg + e] = d4[e];
       }
+      PRIO_HI();
 #pragma unroll
       for (int ks = 0; ks < KSQ; ++ks) {
         s = mfma32(frag_row<HDP>(qt, qb * 32, ks, lane), kf[ks], s);
         dp = mfma32(frag_row<HDP>(dot, qb * 32, ks, lane), vf[ks], dp);
       }
+      PRIO_LO();
       f32x16 pm;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
@@ -596,6 +605,7 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
           s[r] = pr * dp[r];  // dS (unscaled)
         }
       }
+      PRIO_HI();
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = acc_frag(pm, s2);
@@ -606,6 +616,7 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
           dk[db] = mfma32(frag_tr<HDP>(qt, qb * 32 + 16 * s2, db * 32, lane), df, dk[db]);
         }
       }
+      PRIO_LO();
     }
     VDS_WAIT_VM(0);
     __syncthreads();
