@@ -185,6 +185,12 @@ int vds_noise_latents(const void* x, const void* noise, const float* t, void* z_
 int vds_flow_loss(const void* v, const void* out, float* loss_out, float* per_sample, void* dout,
                   float gscale, int32_t B, int64_t per_sample_n, vds_stream_t stream);
 
+/* ------------------------------------------------------------ sampler --
+ * One Euler step of sampling/sample.py:139-146:  out = uncond + cfg_scale*(cond - uncond) in bf16
+ * (uncond may be NULL: out = cond), acc (f32) += dt * out, latents = bf16(acc).  n % 8 == 0. */
+int vds_cfg_euler_step(const void* cond, const void* uncond, float* acc, void* latents, float cfg_scale,
+                       float dt, int64_t n, vds_stream_t stream);
+
 /* -------------------------------------------------------------------- optimizer ------
  * Multi-tensor AdamW on fp32 master shards (torch.optim.AdamW(fused=True) semantics,
  * train.py:340-344,433) + bf16 shadow copy for the next all-gather.

@@ -330,6 +330,40 @@ def train_forward(P, cfg: DiTConfig, latent: Tensor, context: Tensor, z: Tensor,
 
 
 # --------------------------------------------------------------------------------------
+# Euler + classifier-free-guidance sampler (sampling/sample.py:77-159)
+# --------------------------------------------------------------------------------------
+def sample_euler_cfg(P, cfg: DiTConfig, latents: Tensor, prompt_embeds: Tensor, negative_embeds: Tensor,
+                     inference_steps: int, cfg_scale: float, rope_starts, dtype=torch.bfloat16,
+                     alpha: float = 8.0) -> Tensor:
+    """The sampling loop of generate_image: for i = steps..1 the shifted times t, t_next
+    (sample.py:126-136), model output for the prompt and -- when cfg_scale > 1 -- for the
+    negative embeddings, `uncond + cfg * (cond - uncond)` in the model dtype (sample.py:139-142),
+    Euler update of the fp32 accumulator by dt = t - t_next (sample.py:145-146).
+    `rope_starts`: the RoPE offsets of every model call, in call order (cond, uncond per step).
+    Returns the fp32 accumulator [1,C,T,H,W]."""
+    Pd = {k: v.to(dtype) for k, v in P.items()}
+    lat = latents.to(dtype)
+    acc = lat.to(torch.float32)
+    call = 0
+    for i in range(inference_steps, 0, -1):
+        t = i / inference_steps
+        t_next = (i - 1) / inference_steps
+        t = t * alpha / (1 + (alpha - 1) * t)
+        t_next = t_next * alpha / (1 + (alpha - 1) * t_next)
+        dt = t - t_next
+        tt = torch.tensor([t] * lat.shape[0]).to(dtype)
+        out = dit_forward(Pd, cfg, lat, prompt_embeds.to(dtype), tt, tuple(rope_starts[call]))
+        call += 1
+        if cfg_scale > 1:
+            un = dit_forward(Pd, cfg, lat, negative_embeds.to(dtype), tt, tuple(rope_starts[call]))
+            call += 1
+            out = un + cfg_scale * (out - un)
+        acc = acc + dt * out.to(torch.float32)
+        lat = acc.to(dtype)
+    return acc
+
+
+# --------------------------------------------------------------------------------------
 # parameters, muP table, AdamW, LR schedule
 # --------------------------------------------------------------------------------------
 def param_shapes(cfg: DiTConfig) -> Dict[str, Tuple[int, ...]]:

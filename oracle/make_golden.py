@@ -12,6 +12,7 @@ Fixtures:
   g2_dit_s_c1.pt                      DiT-S at BASELINE config-1 shape: output, loss, grad digests
   g3_harness.pt                       train.py::forward: t, noise, z_t, v, loss
   g4_optim.pt                         get_mup_setup tables (DiT-S, DiT-XL), 2 AdamW steps, LR schedule
+  g5_sampler.pt                       sampling/sample.py::generate_image (Euler + CFG), fp32 and bf16
 """
 import importlib.machinery
 import os
@@ -246,6 +247,74 @@ def g3():
     torch.save(fx, os.path.join(GOLD, "g3_harness.pt"))
 
 
+def g5():
+    """sampling/sample.py::generate_image run unmodified on CPU: streamlit and the Cosmos decoder
+    module are stubbed (the decoder stub captures the latents the sampler hands to it)."""
+    sys.path.insert(0, "/root/reference/sampling")
+    st = types.ModuleType("streamlit")
+    st.__spec__ = importlib.machinery.ModuleSpec("streamlit", None)
+    st.cache_resource = lambda f=None, **kw: (f if f is not None else (lambda g: g))
+
+    class _Bar:
+        def progress(self, v):
+            pass
+    st.progress = lambda v: _Bar()
+    sys.modules["streamlit"] = st
+    captured = {}
+    dec = types.ModuleType("decoder")
+    dec.__spec__ = importlib.machinery.ModuleSpec("decoder", None)
+    dec.get_decoder = lambda *a, **k: None
+    dec.save_tensor_to_mp4 = lambda latents, vae, out_dir, name: captured.__setitem__("latents", latents.clone())
+    sys.modules["decoder"] = dec
+    import sample as ref_sample  # reference sampler
+
+    cfg = O.DiTConfig(in_channels=16, patch_size=2, time_patch_size=2, hidden_size=144, depth=2,
+                      num_heads=2, mlp_ratio=4.0, cross_attn_input_size=64, residual_v=True,
+                      train_bias_and_rms=False)  # head_dim 72
+    P = O.init_params(cfg, seed=9, randomize_zero_init=True, init_std_factor=1.0)
+    Lc, steps, cfg_scale, hw, seed = 512, 3, 6.0, 64, 42
+    gi = torch.Generator().manual_seed(77)
+    ctx = torch.randn(1, Lc, 64, generator=gi)
+
+    class Tok:
+        def __call__(self, prompt, **kw):
+            return types.SimpleNamespace(input_ids=torch.zeros(len(prompt), Lc, dtype=torch.long))
+
+    fx = {"cfg": cfg.__dict__.copy(), "param_seed": 9, "context": ctx, "steps": steps, "cfg_scale": cfg_scale,
+          "height": hw, "width": hw, "seed": seed}
+    for dtype, key in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        class Enc:
+            def __call__(self, ids, **kw):
+                return types.SimpleNamespace(hidden_states=[ctx.to(dtype)])
+        Enc.dtype = dtype
+        m = build_ref(cfg, P).to(dtype)
+        starts, first = [], {}
+        real = m.forward
+
+        def spy(x, c, t, real=real, starts=starts, first=first, m=m):
+            first.setdefault("latents", x.detach().clone())
+            thw = (x.shape[2] // m.time_patch_size, x.shape[3] // m.patch_size, x.shape[4] // m.patch_size)
+            state = torch.get_rng_state()
+            starts.append(O.draw_rope_offsets(thw))  # the three draws the call below will make
+            torch.set_rng_state(state)
+            return real(x, c, t)
+        m.forward = spy
+        vae = torch.nn.Linear(1, 1)  # only its parameter dtype is read (sample.py:152)
+        torch.manual_seed(4321)
+        ref_sample.generate_image("a prompt", m, vae, Tok(), Enc(), device="cpu", dtype=dtype,
+                                  inference_steps=steps, cfg_scale=cfg_scale, height=hw, width=hw, seed=seed)
+        torch.set_grad_enabled(True)
+        out = captured["latents"]  # [C,T,H,W] fp32 (vae dtype)
+        acc = O.sample_euler_cfg(P, cfg, first["latents"], ctx, torch.zeros_like(ctx), steps, cfg_scale, starts,
+                                 dtype=dtype)
+        e = rel(acc.squeeze(0), out)
+        print(f"[g5] sampler {key}: {len(starts)} model calls, oracle vs reference rel {e:.2e}, "
+              f"latent std {out.std().item():.3f}")
+        assert e < (1e-4 if dtype == torch.float32 else 5e-2), e
+        fx[key] = {"latents0": first["latents"], "rope_starts": starts, "out": out}
+    torch.save(fx, os.path.join(GOLD, "g5_sampler.pt"))
+
+
 def g4():
     from transformers import get_cosine_schedule_with_warmup, get_linear_schedule_with_warmup
 
@@ -330,8 +399,9 @@ def g4():
 
 
 if __name__ == "__main__":
-    with torch.no_grad():
-        pass
+    if len(sys.argv) > 1 and sys.argv[1] == "g5":  # only the sampler fixture (the others are unchanged)
+        g5()
+        sys.exit(0)
     g1("g1_tiny_hd64", O.DiTConfig(in_channels=16, hidden_size=128, depth=2, num_heads=2,
                                    cross_attn_input_size=64, residual_v=True,
                                    train_bias_and_rms=False), seed=1)
@@ -341,5 +411,6 @@ if __name__ == "__main__":
     g2()
     g3()
     g4()
+    g5()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")

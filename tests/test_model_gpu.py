@@ -312,3 +312,32 @@ def test_shard_runtime_on_one_gpu_matches_unsharded(vds):
             assert rel(p1[k], p0[k]) <= 1e-5, (k, rel(p1[k], p0[k]))
     finally:
         dist.destroy_process_group()
+
+
+def test_g5_sampler_matches_reference(vds, golden_dir):
+    """Euler + CFG sampler (sampling/sample.py::generate_image) on the HIP forward path vs the
+    reference's latents; also the batched cond/uncond forward vs two separate forwards."""
+    from video_diffusion_speedrun_amd.sampling import generate_latents, shifted_times
+    fx = torch.load(os.path.join(golden_dir, "g5_sampler.pt"), weights_only=False)
+    cfg = O.DiTConfig(**fx["cfg"])
+    P = O.init_params(cfg, seed=fx["param_seed"], randomize_zero_init=True, init_std_factor=1.0)
+    m = build(vds, cfg, P)
+    ctx = fx["context"]
+    r16, r32 = fx["bf16"], fx["fp32"]
+    acc = generate_latents(m, ctx, None, fx["steps"], fx["cfg_scale"], latents=r16["latents0"],
+                           rope_starts=r16["rope_starts"])
+    assert acc.dtype == f32 and tuple(acc.shape) == (1, 16, 16, 8, 8)
+    e_ref = rel(r16["out"], r32["out"])          # the reference's own bf16-vs-fp32 gap
+    e = rel(acc.squeeze(0), r32["out"])
+    assert e <= max(2.5 * e_ref, 1.5e-2), (e, e_ref)
+    # batched guidance: same offsets for both calls of a step -> ONE B=2 forward per step
+    shared = [s for s in r16["rope_starts"][0::2] for _ in (0, 1)]
+    a2 = generate_latents(m, ctx, None, fx["steps"], fx["cfg_scale"], latents=r16["latents0"], rope_starts=shared)
+    ref2 = O.sample_euler_cfg(P, cfg, r16["latents0"], ctx, torch.zeros_like(ctx), fx["steps"], fx["cfg_scale"], shared,
+                              dtype=torch.float32)
+    assert rel(a2, ref2) <= 1.5e-2
+    # default call path: random offsets, seeded noise, reference latent shape for 64x64
+    a3 = generate_latents(m, ctx, inference_steps=2, cfg_scale=6.0, height=64, width=64, seed=1)
+    assert torch.isfinite(a3).all() and tuple(a3.shape) == (1, 16, 16, 8, 8)
+    t, tn = shifted_times(2, 2)
+    assert abs(t - 1.0) < 1e-12 and 0 < tn < 1

@@ -161,3 +161,20 @@ def test_patchify_roundtrip_and_token_order():
     # feature (p1=1,p2=0,p3=1,c=2) of token (h=1,w=2,t=1) lands at [c=2, t*2+1, h*2+1, w*2+0]
     f = ((1 * 2 + 0) * 2 + 1) * 3 + 2
     assert img[0, 2, 3, 3, 4] == y[0, (1 * 3 + 2) * 2 + 1, f]
+
+
+def test_g5_sampler_euler_cfg(golden_dir):
+    """sampling/sample.py::generate_image (run unmodified when the fixture was made) vs the oracle loop"""
+    fx = torch.load(os.path.join(golden_dir, "g5_sampler.pt"), weights_only=False)
+    cfg = O.DiTConfig(**fx["cfg"])
+    P = O.init_params(cfg, seed=fx["param_seed"], randomize_zero_init=True, init_std_factor=1.0)
+    ctx = fx["context"]
+    r = fx["fp32"]
+    acc = O.sample_euler_cfg(P, cfg, r["latents0"], ctx, torch.zeros_like(ctx), fx["steps"], fx["cfg_scale"],
+                             r["rope_starts"], dtype=torch.float32)
+    assert rel(acc.squeeze(0), r["out"]) < 1e-5
+    assert len(r["rope_starts"]) == 2 * fx["steps"]  # cond + uncond call per step
+    # cfg_scale <= 1: a single model call per step
+    acc1 = O.sample_euler_cfg(P, cfg, r["latents0"], ctx, torch.zeros_like(ctx), 2, 1.0, r["rope_starts"],
+                              dtype=torch.float32)
+    assert torch.isfinite(acc1).all()

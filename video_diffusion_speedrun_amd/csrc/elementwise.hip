@@ -639,6 +639,33 @@ __global__ __launch_bounds__(256) void flow_loss_kernel(const bf16_t* v, const b
   }
 }
 
+// Euler + classifier-free-guidance update of the sampler (sampling/sample.py:139-146), with the
+// reference's bf16 rounding points: out = bf16(u + bf16(cfg * bf16(c - u))) when guided, acc(f32) += dt * out,
+// latents = bf16(acc).  8 elements per thread, 16-byte accesses.
+__global__ void cfg_euler_kernel(const bf16_t* cond, const bf16_t* uncond, float* acc, bf16_t* lat, float cfg,
+                                 float dt, long n8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float c[8], a[8], o[8];
+  unpack8(*reinterpret_cast<const u32x4*>(cond + i * 8), c);
+  if (uncond) {
+    float u[8];
+    unpack8(*reinterpret_cast<const u32x4*>(uncond + i * 8), u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = bf2f(f2bf(c[e] - u[e]));
+      const float m = bf2f(f2bf(cfg * d));
+      c[e] = bf2f(f2bf(u[e] + m));
+    }
+  }
+  load8f(acc + i * 8, a);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] += dt * c[e]; o[e] = a[e]; }
+  *reinterpret_cast<f32x4*>(acc + i * 8) = f32x4{a[0], a[1], a[2], a[3]};
+  *reinterpret_cast<f32x4*>(acc + i * 8 + 4) = f32x4{a[4], a[5], a[6], a[7]};
+  *reinterpret_cast<u32x4*>(lat + i * 8) = pack8(o);
+}
+
 __global__ void cast_f32_bf16_kernel(const float* s, bf16_t* d, long n) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i + 8 <= n) {
@@ -889,6 +916,15 @@ extern "C" int vds_flow_loss(const void* v, const void* out, float* loss_out, fl
   if (bps > 256) bps = 256;
   hipLaunchKernelGGL(flow_loss_kernel, dim3(bps, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v,
                      (const bf16_t*)out, loss_out, per_sample, (bf16_t*)dout, gscale, B, (long)per_sample_n, bps);
+  return ok();
+}
+
+extern "C" int vds_cfg_euler_step(const void* cond, const void* uncond, float* acc, void* latents, float cfg_scale,
+                                  float dt, int64_t n, vds_stream_t stream) {
+  if (!cond || !acc || !latents || n <= 0 || (n & 7)) return VDS_ERR_ARG;
+  const long n8 = n / 8;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)cond, (const bf16_t*)uncond, acc, (bf16_t*)latents, cfg_scale, dt, n8);
   return ok();
 }
 

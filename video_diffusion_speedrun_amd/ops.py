@@ -307,6 +307,14 @@ def flow_loss(v, out, want_grad: bool, gscale: float = 1.0):
     return acc[0], acc[1:], dout
 
 
+def cfg_euler_step(cond, uncond, acc, latents, cfg_scale: float, dt: float):
+    """acc (f32) += dt * (uncond + cfg*(cond-uncond)) [bf16 math like the reference]; latents = bf16(acc)."""
+    n = cond.numel()
+    assert acc.dtype == f32 and acc.numel() == n and latents.numel() == n and cond.is_contiguous()
+    check(_lib.load().vds_cfg_euler_step(_p(cond), _p(uncond), _p(acc), _p(latents), float(cfg_scale), float(dt), n,
+                                         _stream()), "vds_cfg_euler_step")
+
+
 def cast_f32_bf16(src, dst):
     check(_lib.load().vds_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "vds_cast_f32_bf16")
 
