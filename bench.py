@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the live per-kernel HIP-event timing")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel-class table (stderr)")
+    ap.add_argument("--force-shard-runtime", action="store_true",
+                    help="1 GPU only: run the sharding runtime (streams, events, RCCL collectives on a 1-rank group)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +155,11 @@ def main():
     model = build_model(kw, device, seed=1234)  # same init on every rank
     if world > 1:
         model = apply_fsdp(model, torch.bfloat16, torch.float32)
+    elif args.force_shard_runtime:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        model = apply_fsdp(model, torch.bfloat16, torch.float32, force_runtime=True)
     groups, _ = model.get_mup_setup(1e-4, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
     opt = MuAdamW(groups, betas=(0.95, 0.99))
     sched = get_schedule(opt, "cosine", 20, 10000)
@@ -254,6 +261,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

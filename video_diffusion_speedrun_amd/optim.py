@@ -76,6 +76,17 @@ class MuAdamW(torch.optim.Optimizer):
             d.lr, d.wd = lrs[i], float(group["weight_decay"])
         self._dev["desc"] = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
 
+    def state_dict(self):
+        d = super().state_dict()
+        d["vds_step"] = self._step
+        return d
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        self._step = int(state_dict.pop("vds_step", 0))
+        super().load_state_dict(state_dict)
+        self._table_key = self._chunk_key = None  # moments were replaced: rebuild the descriptor table
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
