@@ -380,3 +380,27 @@ def test_checkpoint_resume_is_exact(vds, tmp_path):
     got = m2.full_state_dict()
     for k in ref:
         assert rel(got[k], ref[k]) <= 1e-5, k
+
+
+def test_device_prefetcher_feeds_the_train_step(vds):
+    """data path: serialized rows -> DataLoader -> pinned staging + side-stream H2D ->
+    the HIP train step; batches arrive in order, in bf16, on the GPU, bit-equal to the rows"""
+    from video_diffusion_speedrun_amd import data as D
+    g = torch.Generator().manual_seed(0)
+    lat = [torch.randn(16, 4, 8, 8, generator=g).to(bf16) for _ in range(6)]
+    rows = [{"serialized_latent": D.serialize_tensor(t), "caption": f"c{i}"} for i, t in enumerate(lat)]
+    dl = D.create_dataloader("train", 2, 0, False, dataset=D.LatentDataset(rows=rows))
+    cfg = O.DiTConfig(in_channels=16, hidden_size=128, depth=1, num_heads=2, cross_attn_input_size=64,
+                      residual_v=True, train_bias_and_rms=False)
+    m = build(vds, cfg, O.init_params(cfg, seed=51, randomize_zero_init=True, init_std_factor=1.0))
+    groups, _ = m.get_mup_setup(1e-3, 0.1, [])
+    opt = vds["optim"].MuAdamW(groups, betas=(0.95, 0.99))
+    seen = 0
+    for i, batch in enumerate(D.DevicePrefetcher(dl, "cuda")):
+        assert batch["latent"].is_cuda and batch["latent"].dtype == bf16 and batch["prompt"] == [f"c{2*i}", f"c{2*i+1}"]
+        assert torch.equal(batch["latent"].cpu(), torch.stack(lat[2 * i:2 * i + 2]))
+        batch["context"] = torch.randn(2, 8, 64, generator=g)
+        loss = vds["train"].train_step(m, opt, None, batch, "cuda")
+        assert torch.isfinite(loss)
+        seen += 1
+    assert seen == 3
