@@ -72,3 +72,41 @@ def test_model_refuses_cpu_tensors():
     m = DiT(in_channels=16, hidden_size=128, depth=1, num_heads=2, cross_attn_input_size=64)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 16, 2, 4, 4), torch.zeros(1, 4, 64), torch.zeros(1))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """no CPU / eager fallback: without libvds_hip.so the product raises instead of computing"""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libvds_hip.so"))
+    with pytest.raises(_lib.VdsError):
+        _lib.load()
+    import torch
+    from video_diffusion_speedrun_amd import ops
+    with pytest.raises((_lib.VdsError, AssertionError)):
+        ops.cast_f32_bf16(torch.zeros(8), torch.zeros(8, dtype=torch.bfloat16))
+
+
+def test_bench_flop_model_matches_the_oracle_formula():
+    """bench.py prices a step with BASELINE.md's formula; the oracle carries the same one"""
+    import bench
+    from oracle import dit_oracle as O
+    for name in ("c3b", "c2", "c4"):
+        kw, shape, _, _ = bench.WORKLOADS[name]
+        cfg = O.DiTConfig(in_channels=16, patch_size=2, time_patch_size=kw["time_patch_size"], hidden_size=kw["hidden_size"],
+                          depth=kw["depth"], num_heads=kw["num_heads"], cross_attn_input_size=4096)
+        C, T, H, W = shape
+        N = (T // kw["time_patch_size"]) * (H // 2) * (W // 2)
+        assert abs(bench.step_flops(kw, shape) - O.train_step_flops(cfg, N)) <= 1e-9 * bench.step_flops(kw, shape)
+    assert abs(bench.step_flops(*bench.WORKLOADS["c3b"][:2]) / 1e12 - 54.15) < 0.01  # BASELINE.md C3b
+
+
+def test_schedule_and_wgrad_split_helpers():
+    from oracle import dit_oracle as O
+    from video_diffusion_speedrun_amd.train import lr_lambda
+    from video_diffusion_speedrun_amd.ops import _wgrad_split
+    for kind in ("cosine", "linear", "constant"):
+        for s in (0, 1, 19, 20, 21, 500, 9999):
+            assert abs(lr_lambda(s, kind, 20, 10000) - O.lr_lambda(s, kind, 20, 10000)) < 1e-12
+    assert _wgrad_split(324, 16, 512) == 1          # short contraction: never split below 8 K tiles
+    s = _wgrad_split(81, 513, 512)
+    assert 2 <= s <= 16 and 81 * s <= 1024
