@@ -42,7 +42,7 @@ def test_struct_layouts_match_header():
     # vds_gemm_args / vds_attn_args / vds_adamw_tensor: field counts and sizes as declared
     assert C.sizeof(_lib.AdamWTensor) == 5 * 8 + 8 + 4 + 4
     assert C.sizeof(_lib.GemmArgs) == 5 * 4 + 4 + 8 * 13 + 4 + 4  # 5 int32 + pad, 13 pointer/int64, 2 int32
-    assert C.sizeof(_lib.AttnArgs) == 5 * 4 + 4 + 8 * (4 * 4 + 1 + 4 * 4 + 1)
+    assert C.sizeof(_lib.AttnArgs) == 5 * 4 + 4 + 8 * (4 * 4 + 1 + 4 * 4 + 1) + 8  # + kv_pad_ones (padded)
     assert C.sizeof(_lib.ProfStat) == 32
 
 

@@ -188,6 +188,38 @@ def test_attention_fwd_bwd(ops, hd, Lq, Lk):
         assert dq[..., hd:].abs().max().item() == 0  # pad columns are never written
 
 
+@pytest.mark.parametrize("Lq,Lk,spike", [(2100, 300, False), (2304, 4160, True)])
+def test_attention_fwd_ones_columns(ops, Lq, Lk, spike):
+    """head_dim 72 forward with the ones columns in the K / V padding (the path the model uses):
+    -max through the QK^T MFMA, row sums through the PV MFMA, lazy rescale; ragged key count and
+    a late score spike that forces a rescale long after the first tile."""
+    B, H, hd, hdp = 1, 2, 72, 96
+    q, k, v = gen(B, H, Lq, hd, seed=31), gen(B, H, Lk, hd, seed=32), gen(B, H, Lk, hd, seed=33)
+    if spike:
+        k[:, :, Lk - 70] = 6.0 * q[:, :, 5]      # one key row aligned with one query row, near the end
+        q[:, :, 1000] *= 8.0                      # and one query with very large logits throughout
+    def padk(t, cols):
+        out = torch.zeros(*t.shape[:-1], hdp, dtype=bf16)
+        out[..., :hd] = t
+        for c in cols:
+            out[..., c] = 1
+        return out.cuda()
+    qd, kd, vd = padk(q, []), padk(k, [hd]), padk(v, [hd, hd + 4])
+    o = torch.zeros(B * Lq, H * hd, dtype=bf16, device="cuda")
+    lse = torch.zeros(B, H, Lq, dtype=f32, device="cuda")
+    ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o, B, Lq, H, hd), lse, kv_pad_ones=True)
+    sc = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(hd)
+    ref = torch.softmax(sc, -1) @ v.float()
+    got = o.view(B, Lq, H, hd).permute(0, 2, 1, 3)
+    close("attn.ones.o", got, ref, 1e-2)
+    close("attn.ones.lse", lse, torch.logsumexp(sc, -1), 2e-3)
+    # same inputs through the path without the ones columns
+    o2 = torch.zeros_like(o)
+    lse2 = torch.zeros_like(lse)
+    ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o2, B, Lq, H, hd), lse2)
+    close("attn.ones.vs_plain", o, o2.float(), 1e-2)
+
+
 def test_attention_token_major_cross(ops):
     """cross-attention layout: q from [B,L,D], k/v from [B,Lc,2D] token-major buffers (hd=72)"""
     B, H, hd, L, Lc = 2, 2, 72, 150, 512
@@ -293,8 +325,13 @@ def test_qkv_rope_fwd_bwd(ops, hd, hdp):
     close("rope.q", qd[..., :hd], qr, 1e-3)
     close("rope.k", kd[..., :hd], kr, 1e-3)
     close("rope.v", vd[..., :hd], vm, 4e-3)
-    if hdp > hd:
-        assert qd[..., hd:].abs().max().item() == 0 and vd[..., hd:].abs().max().item() == 0
+    if hdp > hd:  # pad: zeros, except the ones columns of k and v (hdp >= hd + 8)
+        assert qd[..., hd:].abs().max().item() == 0
+        want_k = torch.zeros(hdp - hd); want_v = torch.zeros(hdp - hd)
+        if hdp - hd >= 8:
+            want_k[0] = 1; want_v[0] = 1; want_v[4] = 1
+        assert torch.equal(kd[..., hd:].float().cpu(), want_k.expand(B, H, L, -1))
+        assert torch.equal(vd[..., hd:].float().cpu(), want_v.expand(B, H, L, -1))
     # no-mix variant (block 0)
     _, _, v_raw = ops.qkv_rope_fwd(qkv.cuda(), cos.cuda(), sin.cuda(), None, None, B, L, H, hd, hdp)
     assert torch.equal(v_raw[..., :hd].cpu(), v.contiguous())

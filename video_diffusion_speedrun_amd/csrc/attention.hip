@@ -46,6 +46,7 @@ struct AttnP {
   float* delta;
   float scale;
   int n_rt;  // row tiles per (b,h) of the stationary operand
+  int kv_pad_ones;
 };
 
 // ---- LDS image (a): rows x HDP bf16, 8x32 sub-tiles of 512 B -------------------------------
@@ -181,6 +182,7 @@ __device__ __forceinline__ void lazy_softmax(f32x16& s, float c, float& m, float
   for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
   mx = max_with_other_half(mx) * c;
   if (__builtin_amdgcn_ballot_w64(mx > m + LAZY_THR) != 0) {  // wave-uniform, rare
+    asm volatile("; rescale" ::: "memory");  // keeps this a real branch (no if-conversion)
     const float m_new = fmaxf(m, mx);
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     m = m_new;
@@ -347,6 +349,174 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd_kernel(AttnP p) {
   if (qrow < p.Lq) {
     store_rows<NDB>(p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, o, 1.0f / lt, p.hd, h);
     if (h == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m + __builtin_amdgcn_logf(lt)) * LN2;
+  }
+}
+
+// ---- forward, wide kernel: 64 queries per wave (two 32-query blocks) --------------------------
+// Every K / V^T fragment read from LDS feeds two MFMAs (one per query block).  The kernel is bound by
+// VALU issue slots next to the MFMAs (an MFMA gap hides ~24 cycles of VALU issue; the plain online
+// softmax needs ~42), so with ONES (k / v rows carry ones columns in their padding, vds_attn_args
+// .kv_pad_ones) the softmax sheds its multiply-add and its row-sum adds:
+//   * Q is pre-multiplied by scale*log2(e) in registers and carries -m (the running maximum, kept
+//     bf16-representable) at column head_dim, where every K row holds 1.0: the QK^T MFMA delivers
+//     log2-domain scores MINUS the running maximum, ready for v_exp_f32;
+//   * every V row holds 1.0 at columns head_dim and head_dim+4: row head_dim (+4) of the O^T
+//     accumulator IS the softmax denominator (rescaled together with O, for free);
+//   * the running maximum is only raised when some score exceeds it by 2^LAZY_THR (wave-uniform
+//     branch, rare after the first tile); the common path has no cross-lane operation at all.
+__device__ __forceinline__ bf16x8 scale_frag(bf16x8 f, float c) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)((float)f[j] * c);
+  return r;
+}
+
+template <int NDB>
+__device__ __forceinline__ void ones_softmax(f32x16& s, float& m, bf16x8& q_ones, f32x16 (&o)[NDB], bf16x8 (&pf)[2],
+                                             bool first, int h) {
+  float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+  for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+  if (first || __builtin_amdgcn_ballot_w64(mx > LAZY_THR) != 0) {  // wave-uniform, rare
+    asm volatile("; rescale" ::: "memory");  // keeps this a real branch: hipcc otherwise if-converts it and
+                                             // runs the 48 O multiplies on every sub-block with alpha = 1
+    const float mxf = max_with_other_half(mx);                      // both lanes of a query agree
+    const float m_new = bf2f(f2bf(m + (first ? mxf : fmaxf(mxf, 0.f))));
+    const float delta = m_new - m;
+    const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+    m = m_new;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;  // includes the denominator row
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] -= delta;
+    if (h == 1) q_ones[0] = (__bf16)(-m);              // column head_dim of Q' (exact: m is a bf16 value)
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+  pf[0] = acc_frag(s, 0);
+  pf[1] = acc_frag(s, 1);
+}
+
+template <int HDP, int HDQ, bool ONES>
+__global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(AttnP p) {
+  constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
+  static_assert(!ONES || (HDP == 96 && HDQ == 80), "ones columns: head_dim 72 layout");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qrow0 = qt * 256 + wave * 64 + (lane & 31);  // query of block 0; block 1 = + 32
+  const int hd_kv = ONES ? p.hd + 8 : p.hd;               // columns of K / V rows that are fetched
+
+  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const srd_t rk = slice_srd(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, hd_kv);
+  const srd_t rv = slice_srd(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, hd_kv);
+
+  DmaStage<64, HDP> dk, dv;
+  dk.init(p.k_sl, hd_kv, wave, lane);
+  dv.init(p.v_sl, hd_kv, wave, lane);
+  const unsigned k_step = (unsigned)(64 * p.k_sl * 2), v_step = (unsigned)(64 * p.v_sl * 2);
+  dk.issue(rk, smem, 0, wave);
+  dv.issue(rv, smem + TILE, 0, wave);
+
+  const float c = p.scale * LOG2E;
+  bf16x8 qf[2][KSQ];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      const int e = ks * 16 + 8 * h;
+      unsigned off = (unsigned)(((long)(qrow0 + 32 * qb) * p.q_sl + e) * 2);
+      if (e >= p.hd) off = 0xfffffff0u;
+      qf[qb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+    }
+  if constexpr (ONES) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) qf[qb][ks] = scale_frag(qf[qb][ks], c);  // also retires the loads
+  } else {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) retire(qf[qb][ks]);
+  }
+
+  f32x16 o[2][NDB];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) o[qb][i] = zero16();
+  float m[2], l[2] = {0.f, 0.f};
+  m[0] = m[1] = ONES ? 0.f : -1e30f;
+  const int nkt = (p.Lk + 63) / 64;
+  VDS_WAIT_VM(0);
+  __syncthreads();
+
+  for (int j = 0; j < nkt; ++j) {
+    if (j + 1 < nkt) {
+      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
+      dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
+      dv.issue(rv, nk + TILE, (unsigned)(j + 1) * v_step, wave);
+    }
+    const char* kt = smem + (j & 1) * 2 * TILE;
+    const char* vt = kt + TILE;
+    const bool ragged = (j == nkt - 1) && (p.Lk & 63);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 kfr[KSQ];
+      load_kfrags<HDP, KSQ>(kfr, kt, kb * 32, lane);
+      f32x16 s0 = zero16(), s1 = zero16();
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) {
+        s0 = mfma32(kfr[ks], qf[0][ks], s0);
+        s1 = mfma32(kfr[ks], qf[1][ks], s1);
+      }
+      // keys past Lk: with ONES no mask is needed -- their zero-filled V rows (ones columns included)
+      // add nothing to the numerators or to the denominator, whatever exp2 makes of their scores
+      if constexpr (!ONES) {
+        if (ragged) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (j * 64 + kb * 32 + acc_row(r, h) >= p.Lk) { s0[r] = -INFINITY; s1[r] = -INFINITY; }
+        }
+      }
+      bf16x8 vfr[2][NDB];
+      load_vfrags<HDP, NDB>(vfr, vt, kb * 32, lane);
+      bf16x8 p0[2], p1[2];
+      if constexpr (ONES) {
+        const bool first = (j == 0) && (kb == 0);
+        ones_softmax<NDB>(s0, m[0], qf[0][KSQ - 1], o[0], p0, first, h);
+        ones_softmax<NDB>(s1, m[1], qf[1][KSQ - 1], o[1], p1, first, h);
+      } else {
+        lazy_softmax<NDB>(s0, c, m[0], l[0], o[0], p0);
+        lazy_softmax<NDB>(s1, c, m[1], l[1], o[1], p1);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          o[0][db] = mfma32(vfr[s2][db], p0[s2], o[0][db]);
+          o[1][db] = mfma32(vfr[s2][db], p1[s2], o[1][db]);
+        }
+    }
+    VDS_WAIT_VM(0);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = qrow0 + 32 * qb;
+    // ONES: the denominator is row head_dim (lanes 0-31) / head_dim+4 (lanes 32-63) of O^T = register 4 of block 2
+    const float lt = ONES ? o[qb][NDB - 1][4] : add_with_other_half(l[qb]);
+    if (qrow < p.Lq) {
+      store_rows<NDB>(p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, o[qb], 1.0f / lt, p.hd, h);
+      if (h == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m[qb] + __builtin_amdgcn_logf(lt)) * LN2;
+    }
   }
 }
 
@@ -642,6 +812,7 @@ AttnP to_p(const vds_attn_args* a) {
   p.delta = a->delta;
   p.scale = 1.0f / sqrtf((float)a->head_dim);
   p.n_rt = 0;
+  p.kv_pad_ones = a->kv_pad_ones;
   return p;
 }
 
@@ -665,11 +836,34 @@ template <int HDP, int HDQ>
 int run_fwd(AttnP p, hipStream_t s) {
   constexpr int LDS = 4 * 64 * HDP * 2;
   static bool once = false;
-  if (!once) { set_lds(attn_fwd_kernel<HDP, HDQ, 2, true>, LDS); once = true; }
-  p.n_rt = cdiv(p.Lq, 128);
+  if (!once) {
+    set_lds(attn_fwd_kernel<HDP, HDQ, 2, true>, LDS);
+    if constexpr (HDP == 96) {
+      set_lds(attn_fwd_wide_kernel<HDP, HDQ, false>, LDS);
+      set_lds(attn_fwd_wide_kernel<HDP, HDQ, true>, LDS);
+    }
+    once = true;
+  }
+  static int wide = -1;  // VDS_ATTN_FWD_WIDE=0/1 forces (experiments); default: head_dim 72, long query sequences
+  if (wide < 0) {
+    const char* e = getenv("VDS_ATTN_FWD_WIDE");
+    wide = e ? atoi(e) : 2;
+  }
+  bool use_wide = false;
+  if constexpr (HDP == 96) use_wide = wide == 1 || (wide == 2 && p.Lq >= 2048);
+  p.n_rt = cdiv(p.Lq, use_wide ? 256 : 128);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
   vdsprof::Scope ps(VDS_PROF_ATTN_FWD, s, fl, 2.0 * p.B * p.H * p.hd * (2.0 * p.Lq + 2.0 * p.Lk));
+  if constexpr (HDP == 96) {
+    if (use_wide) {
+      if (p.kv_pad_ones && p.hd == 72)
+        hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS, s, p);
+      else
+        hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS, s, p);
+      return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+    }
+  }
   hipLaunchKernelGGL((attn_fwd_kernel<HDP, HDQ, 2, true>), dim3(grid), dim3(256), LDS, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }

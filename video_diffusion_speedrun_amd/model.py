@@ -359,7 +359,8 @@ class DiT(nn.Module):
                                    hd, hdp)
         attn = torch.empty(B * L, D, dtype=bf16, device=dev)
         lse1 = torch.empty(B, H, L, dtype=f32, device=dev)
-        ops.attn_fwd(q[..., :hd], k[..., :hd], v[..., :hd], ops.heads_view(attn, B, L, H, hd), lse1)
+        ops.attn_fwd(q[..., :hd], k[..., :hd], v[..., :hd], ops.heads_view(attn, B, L, H, hd), lse1,
+                     kv_pad_ones=(hdp - hd) >= 8)
         y_sa, X1 = ops.linear_fwd_gate_res(attn, W("attn_proj.weight"), None, mod, 2 * D, X, L)
         # --- cross attention (model.py:142-160)
         has_cross = G.has(pre + "q_cross.weight")

@@ -125,8 +125,9 @@ def _st(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def attn_fwd(q, k, v, o, lse):
-    """q [B,H,Lq,hd], k/v [B,H,Lk,hd], o [B,H,Lq,hd] strided views (last dim contiguous); lse f32 [B,H,Lq]."""
+def attn_fwd(q, k, v, o, lse, kv_pad_ones: bool = False):
+    """q [B,H,Lq,hd], k/v [B,H,Lk,hd], o [B,H,Lq,hd] strided views (last dim contiguous); lse f32 [B,H,Lq].
+    kv_pad_ones: k / v are views into qkv_rope_fwd outputs whose pad carries the ones columns."""
     B, H, Lq, hd = q.shape
     Lk = k.shape[2]
     a = AttnArgs()
@@ -136,6 +137,7 @@ def attn_fwd(q, k, v, o, lse):
     a.v, (a.v_sb, a.v_sh, a.v_sl) = _p(v), _st(v)
     a.o, (a.o_sb, a.o_sh, a.o_sl) = _p(o), _st(o)
     a.lse = _p(lse)
+    a.kv_pad_ones = 1 if kv_pad_ones else 0
     check(_lib.load().vds_attn_fwd(C.byref(a), _stream()), f"vds_attn_fwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
 
 
