@@ -88,9 +88,10 @@ typedef struct vds_attn_args {
   void* dk; int64_t dk_sb, dk_sh, dk_sl;
   void* dv; int64_t dv_sb, dv_sh, dv_sl;
   float* delta;                /* workspace [2,B,H,Lq] f32: -rowsum(dO*O), then lse*log2(e) */
-  /* forward only: nonzero = every k row carries 1.0 at column head_dim and every v row 1.0 at columns
+  /* nonzero = every k row carries 1.0 at columns head_dim and head_dim+1 and every v row 1.0 at columns
    * head_dim and head_dim+4 (zeros in the rest of [head_dim, head_dim+8)), as vds_qkv_rope_fwd writes
-   * them for hdp >= hd+8; the kernel then gets score-minus-max and the softmax row sums from its MFMAs. */
+   * them for hdp >= hd+8; the kernels then fold the per-query constants of the softmax (max, lse, delta)
+   * into their MFMAs instead of spending VALU instructions on them. */
   int32_t kv_pad_ones;
 } vds_attn_args;
 
@@ -126,7 +127,7 @@ int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M, int32_t N
  *   q,k [B,H,L,hdp] rotated (fp32 math, half-split, cos/sin [L, hd/2] f32; model.py:266-275)
  *   v   [B,H,L,hdp] = lam*v_raw + (1-lam)*v0  (model.py:129-130) when v0 != NULL else v_raw.
  * hdp >= hd is the padded row length (pad columns are written as zero, except that with hdp >= hd+8
- * k gets 1.0 at column hd and v 1.0 at columns hd and hd+4: see vds_attn_args.kv_pad_ones). lam: bf16 device scalar
+ * k gets 1.0 at columns hd, hd+1 and v 1.0 at columns hd and hd+4: see vds_attn_args.kv_pad_ones). lam: bf16 device scalar
  * (the bf16-cast lambda_param, as under the reference's bf16 param policy). */
 int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float* sinb, const void* v0,
                      const void* lam, void* q, void* k, void* v, int32_t B, int32_t L, int32_t H,

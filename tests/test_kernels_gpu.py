@@ -204,7 +204,7 @@ def test_attention_fwd_ones_columns(ops, Lq, Lk, spike):
         for c in cols:
             out[..., c] = 1
         return out.cuda()
-    qd, kd, vd = padk(q, []), padk(k, [hd]), padk(v, [hd, hd + 4])
+    qd, kd, vd = padk(q, []), padk(k, [hd, hd + 1]), padk(v, [hd, hd + 4])
     o = torch.zeros(B * Lq, H * hd, dtype=bf16, device="cuda")
     lse = torch.zeros(B, H, Lq, dtype=f32, device="cuda")
     ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o, B, Lq, H, hd), lse, kv_pad_ones=True)
@@ -329,7 +329,7 @@ def test_qkv_rope_fwd_bwd(ops, hd, hdp):
         assert qd[..., hd:].abs().max().item() == 0
         want_k = torch.zeros(hdp - hd); want_v = torch.zeros(hdp - hd)
         if hdp - hd >= 8:
-            want_k[0] = 1; want_v[0] = 1; want_v[4] = 1
+            want_k[0] = 1; want_k[1] = 1; want_v[0] = 1; want_v[4] = 1
         assert torch.equal(kd[..., hd:].float().cpu(), want_k.expand(B, H, L, -1))
         assert torch.equal(vd[..., hd:].float().cpu(), want_v.expand(B, H, L, -1))
     # no-mix variant (block 0)

@@ -33,6 +33,7 @@ for hd, H, hdp in ((72, 16, 96), (64, 12, 64), (128, 16, 128)):
     ones = os.environ.get("ONES", "1") == "1" and hdp - hd >= 8
     if ones:  # the pad layout vds_qkv_rope_fwd produces
         k[..., hd] = 1
+        k[..., hd + 1] = 1
         v[..., hd] = 1
         v[..., hd + 4] = 1
     o = torch.empty(B * Lq, H * hd, dtype=bf16, device=dev)
@@ -47,7 +48,8 @@ for hd, H, hdp in ((72, 16, 96), (64, 12, 64), (128, 16, 128)):
     dov = ops.heads_view(do, B, Lq, H, hd)
     ops.prof_enable()
     for _ in range(4):
-        ops.attn_bwd(q[..., :hd], k[..., :hd], v[..., :hd], ov, lse, dov, dq[..., :hd], dk[..., :hd], dv[..., :hd], delta)
+        ops.attn_bwd(q[..., :hd], k[..., :hd], v[..., :hd], ov, lse, dov, dq[..., :hd], dk[..., :hd], dv[..., :hd], delta,
+                     kv_pad_ones=ones)
     st = ops.prof_collect()
     ops.prof_enable(0)
     for kname in ("attn_bwd_dkv", "attn_bwd_dq", "attn_bwd_delta"):

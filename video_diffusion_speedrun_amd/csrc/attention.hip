@@ -583,9 +583,21 @@ __global__ __launch_bounds__(256) void attn_delta_tokmajor_kernel(AttnP p) {
 }
 
 // ===================================== dQ ===================================================
-template <int HDP, int HDQ>
+// ONES (k / v rows carry ones columns in their padding, vds_attn_args.kv_pad_ones; head_dim 72): the
+// kernel is bound by the VALU work between its MFMAs, so the per-query constants move into the MFMAs:
+// Q is pre-multiplied by scale*log2(e) in registers and carries -lse*log2(e) as a bf16 (hi, lo) pair at
+// columns hd, hd+1 (K holds 1.0 there), dO carries -delta as a (hi, lo) pair at columns hd, hd+4 (V holds
+// 1.0 there): S' = log2 P and dP - delta come straight out of the two MFMA chains, leaving
+// exp2, one multiply and the bf16 pack per element.  Keys past Lk need no mask in either mode.
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)x;
+  lo = (__bf16)(x - (float)hi);
+}
+
+template <int HDP, int HDQ, bool ONES>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
+  static_assert(!ONES || (HDP == 96 && HDQ == 80), "ones columns: head_dim 72 layout");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
   if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
@@ -593,15 +605,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qrow = qt * 128 + wave * 32 + (lane & 31);
+  const int hd_kv = ONES ? p.hd + 8 : p.hd;
 
   const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
   const __amdgpu_buffer_rsrc_t rdo = slice_rsrc(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
-  const srd_t rk = slice_srd(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
-  const srd_t rv = slice_srd(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+  const srd_t rk = slice_srd(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, hd_kv);
+  const srd_t rv = slice_srd(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, hd_kv);
 
   DmaStage<64, HDP> dk, dv;
-  dk.init(p.k_sl, p.hd, wave, lane);
-  dv.init(p.v_sl, p.hd, wave, lane);
+  dk.init(p.k_sl, hd_kv, wave, lane);
+  dv.init(p.v_sl, hd_kv, wave, lane);
   const unsigned k_step = (unsigned)(64 * p.k_sl * 2), v_step = (unsigned)(64 * p.v_sl * 2);
   dk.issue(rk, smem, 0, wave);
   dv.issue(rv, smem + TILE, 0, wave);
@@ -621,15 +634,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   const float ndl = p.delta[srow];  // -delta of this lane's query
   const float lse2 = p.delta[nrows + srow];
   const float c = p.scale * LOG2E;
+  if constexpr (ONES) {
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) { qf[ks] = scale_frag(qf[ks], c); retire(dof[ks]); }
+    if (h == 1) {  // fragment KSQ-1 of lane half 1 holds columns hd .. hd+7
+      __bf16 hi, lo;
+      split_bf16(-lse2, hi, lo);
+      qf[KSQ - 1][0] = hi;
+      qf[KSQ - 1][1] = lo;
+      split_bf16(ndl, hi, lo);
+      dof[KSQ - 1][0] = hi;
+      dof[KSQ - 1][4] = lo;
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) { retire(qf[ks]); retire(dof[ks]); }
+    retire(ndl);
+    retire(lse2);
+  }
 
   f32x16 dq[NDB];
 #pragma unroll
   for (int i = 0; i < NDB; ++i) dq[i] = zero16();
   const int nkt = (p.Lk + 63) / 64;
-#pragma unroll
-  for (int ks = 0; ks < KSQ; ++ks) { retire(qf[ks]); retire(dof[ks]); }
-  retire(ndl);
-  retire(lse2);
   VDS_WAIT_VM(0);
   __syncthreads();  // tile 0 landed
 
@@ -646,15 +673,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s = zero16(), dp;
+      if constexpr (ONES) {
+        dp = zero16();
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dp[r] = ndl;  // accumulator starts at -delta: dP - delta for free
+        for (int r = 0; r < 16; ++r) dp[r] = ndl;  // accumulator starts at -delta: dP - delta for free
+      }
 #pragma unroll
       for (int ks = 0; ks < KSQ; ++ks) {
         s = mfma32(frag_row<HDP>(kt, kb * 32, ks, lane), qf[ks], s);
         dp = mfma32(frag_row<HDP>(vt, kb * 32, ks, lane), dof[ks], dp);
       }
+      if constexpr (ONES) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * c - lse2) * dp[r];  // dS^T (unscaled)
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];  // dS^T (unscaled)
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * c - lse2) * dp[r];
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 df = acc_frag(s, s2);
@@ -874,7 +910,8 @@ int run_bwd(AttnP p, hipStream_t s) {
   constexpr int LDS_DKV = 4 * 64 * HDP * 2 + 2 * 128 * 4;
   static bool once = false;
   if (!once) {
-    set_lds(attn_bwd_dq_kernel<HDP, HDQ>, LDS_DQ);
+    set_lds(attn_bwd_dq_kernel<HDP, HDQ, false>, LDS_DQ);
+    if constexpr (HDP == 96) set_lds(attn_bwd_dq_kernel<HDP, HDQ, true>, LDS_DQ);
     set_lds(attn_bwd_dkv_kernel<HDP, HDQ>, LDS_DKV);
     once = true;
   }
@@ -903,7 +940,12 @@ int run_bwd(AttnP p, hipStream_t s) {
   grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DQ, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS_DQ, s, p);
+    bool ones = false;
+    if constexpr (HDP == 96) ones = p.kv_pad_ones && p.hd == 72;
+    if constexpr (HDP == 96) {
+      if (ones) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DQ, s, p);
+    }
+    if (!ones) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS_DQ, s, p);
   }
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }

@@ -340,18 +340,19 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_kernel(const bf16_t* qkv, co
     *reinterpret_cast<u32x2*>(v + dst) = w1;
     *reinterpret_cast<u32x2*>(v + dst + half) = w2;
   }
-  // pad columns hd..hdp of this (token, head): zero, except K[hd] = V[hd] = V[hd+4] = 1.0 when there
-  // are >= 8 pad columns -- the forward attention kernel (kv_pad_ones) uses the K ones column to add
-  // -max to the scores inside the QK^T MFMA and the V ones columns to get the softmax row sums
-  // out of the PV MFMA.  Every other consumer ignores the pad.
+  // pad columns hd..hdp of this (token, head): zero, except K[hd] = K[hd+1] = V[hd] = V[hd+4] = 1.0 when
+  // there are >= 8 pad columns -- the attention kernels (kv_pad_ones) use the K ones columns to add a
+  // per-query constant (-max forward, -lse as a bf16 hi/lo pair backward) to the scores inside the QK^T
+  // MFMA, and the V ones columns to get the softmax row sums out of the PV MFMA (forward) and to
+  // subtract delta inside the dO V^T MFMA (backward).  Consumers without the flag ignore the pad.
   const int npad = (hdp - hd) >> 2;
   if (i < npad) {
     const long pd = (((long)b * H + hh) * L + l) * hdp + hd + 4 * i;
     const u32x2 z = {0u, 0u};
-    const u32x2 one = {0x3f80u, 0u};
+    const u32x2 one = {0x3f80u, 0u}, one2 = {0x3f803f80u, 0u};
     const bool ones = (hdp - hd) >= 8;
     *reinterpret_cast<u32x2*>(q + pd) = z;
-    *reinterpret_cast<u32x2*>(k + pd) = (ones && i == 0) ? one : z;
+    *reinterpret_cast<u32x2*>(k + pd) = (ones && i == 0) ? one2 : z;
     *reinterpret_cast<u32x2*>(v + pd) = (ones && i < 2) ? one : z;
   }
 }

@@ -503,7 +503,8 @@ class DiT(nn.Module):
         dv = torch.empty_like(dq)
         delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
         ops.attn_bwd(bs.q[..., :hd], bs.k[..., :hd], bs.v[..., :hd], ops.heads_view(bs.attn, B, L, H, hd), bs.lse1,
-                     ops.heads_view(dattn, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta)
+                     ops.heads_view(dattn, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta,
+                     kv_pad_ones=(hdp - hd) >= 8)
         first = (i == 0)
         dqkv = ops.qkv_rope_bwd(dq, dk, dv, sv.cos, sv.sin, bs.qkv if bs.mix else None, sv.v0 if bs.mix else None,
                                 W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),

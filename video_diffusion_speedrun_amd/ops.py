@@ -141,7 +141,7 @@ def attn_fwd(q, k, v, o, lse, kv_pad_ones: bool = False):
     check(_lib.load().vds_attn_fwd(C.byref(a), _stream()), f"vds_attn_fwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta):
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta, kv_pad_ones: bool = False):
     """delta: f32 workspace of 2*B*H*Lq elements (rowsum(dO*O), then lse*log2 e)."""
     B, H, Lq, hd = q.shape
     assert delta.numel() >= 2 * B * H * Lq and delta.is_contiguous(), "attn_bwd: delta workspace is [2,B,H,Lq] f32"
@@ -159,6 +159,7 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta):
     a.dk, (a.dk_sb, a.dk_sh, a.dk_sl) = _p(dk), _st(dk)
     a.dv, (a.dv_sb, a.dv_sh, a.dv_sl) = _p(dv), _st(dv)
     a.delta = _p(delta)
+    a.kv_pad_ones = 1 if kv_pad_ones else 0
     check(_lib.load().vds_attn_bwd(C.byref(a), _stream()), f"vds_attn_bwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
 
 
