@@ -91,7 +91,9 @@ typedef struct vds_attn_args {
   /* nonzero = every k row carries 1.0 at columns head_dim and head_dim+1 and every v row 1.0 at columns
    * head_dim and head_dim+4 (zeros in the rest of [head_dim, head_dim+8)), as vds_qkv_rope_fwd writes
    * them for hdp >= hd+8; the kernels then fold the per-query constants of the softmax (max, lse, delta)
-   * into their MFMAs instead of spending VALU instructions on them. */
+   * into their MFMAs instead of spending VALU instructions on them.  With the flag the q rows must be
+   * padded to head_dim+8 columns as well: vds_attn_bwd OVERWRITES their columns head_dim, head_dim+1
+   * (scratch: -lse*log2(e) as a bf16 hi/lo pair for the dK/dV kernel). */
   int32_t kv_pad_ones;
 } vds_attn_args;
 

@@ -520,6 +520,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(AttnP p) {
   }
 }
 
+// kv_pad_ones: the (otherwise unused) pad columns hd, hd+1 of the q row receive -lse*log2(e) as a bf16
+// (hi, lo) pair; the dK/dV kernel stages Q rows with their pad and holds 1.0 in the matching columns of
+// its K fragments, so its QK^T MFMA delivers log2 P directly.
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)x;
+  lo = (__bf16)(x - (float)hi);
+}
+__device__ __forceinline__ void annotate_q(const AttnP& p, int b, int hh, int q, float lse2) {
+  __bf16 hi, lo;
+  split_bf16(-lse2, hi, lo);
+  bf16x2 v;
+  v[0] = hi;
+  v[1] = lo;
+  bf16_t* dst = const_cast<bf16_t*>(p.q) + b * p.q_sb + hh * p.q_sh + (long)q * p.q_sl + p.hd;
+  *reinterpret_cast<bf16x2*>(dst) = v;
+}
+
 // ndelta[b,h,q] = -sum_d dO[q,d] * O[q,d] and lse2 = lse * log2(e) (one wave per row; HBM-bound
 // preprocess).  Workspace layout: ndelta[0 .. rows) | lse2[rows .. 2 rows).  The NEGATED delta is
 // what the backward kernels load straight into the dP accumulators (dP - delta for free).
@@ -541,8 +558,10 @@ __global__ void attn_delta_kernel(AttnP p) {
   }
   acc = wave_sum(acc);
   if (lane == 0) {
+    const float l2 = p.lse[row] * LOG2E;
     p.delta[row] = -acc;
-    p.delta[rows + row] = p.lse[row] * LOG2E;
+    p.delta[rows + row] = l2;
+    if (p.kv_pad_ones) annotate_q(p, b, hh, q, l2);
   }
 }
 
@@ -577,8 +596,10 @@ __global__ __launch_bounds__(256) void attn_delta_tokmajor_kernel(AttnP p) {
     for (int i = 0; i < cph; ++i) acc += part[wave][lane * cph + i];
     const long rows = (long)p.B * p.H * p.Lq;
     const long row = ((long)b * p.H + lane) * p.Lq + q;
+    const float l2 = p.lse[row] * LOG2E;
     p.delta[row] = -acc;
-    p.delta[rows + row] = p.lse[row] * LOG2E;
+    p.delta[rows + row] = l2;
+    if (p.kv_pad_ones) annotate_q(p, b, lane, q, l2);
   }
 }
 
@@ -589,11 +610,6 @@ __global__ __launch_bounds__(256) void attn_delta_tokmajor_kernel(AttnP p) {
 // columns hd, hd+1 (K holds 1.0 there), dO carries -delta as a (hi, lo) pair at columns hd, hd+4 (V holds
 // 1.0 there): S' = log2 P and dP - delta come straight out of the two MFMA chains, leaving
 // exp2, one multiply and the bf16 pack per element.  Keys past Lk need no mask in either mode.
-__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
-  hi = (__bf16)x;
-  lo = (__bf16)(x - (float)hi);
-}
-
 template <int HDP, int HDQ, bool ONES>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
@@ -712,8 +728,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 // double-buffered Q/dO tiles and their row statistics (lse2, delta), all filled by LDS-DMA.
 // Rows past Lq arrive as zeros (SRD bounds): Q = dO = 0 makes their contribution to dV and dK
 // vanish whatever P evaluates to.  S and dP have the key on the lane.
-template <int HDP, int HDQ>
-__global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(AttnP p) {
+// ONES (kv_pad_ones, head_dim 72): Q rows are staged WITH their pad, which the delta preprocess filled
+// with -lse*log2(e) (hi, lo); the K fragments are pre-multiplied by scale*log2(e) and hold 1.0 in those
+// two columns, so S comes out of the MFMA as log2 P: no multiply-add and no lse reads per element.
+template <int HDP, int HDQ, bool ONES>
+__global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void attn_bwd_dkv_kernel(AttnP p) {
   constexpr int KSQ = HDQ / 16, NDB = HDP / 32, Q_TILE = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS: [buf0: Q | dO][buf1: Q | dO][stats: 2 bufs x (lse2[64], delta[64])]
@@ -727,7 +746,8 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
   const int key0 = kt_idx * 128;
   const int krow = key0 + wave * 32 + (lane & 31);
 
-  const srd_t rq = slice_srd(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const int hd_q = ONES ? p.hd + 8 : p.hd;  // Q row columns that are staged
+  const srd_t rq = slice_srd(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, hd_q);
   const srd_t rdo = slice_srd(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
   const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
   const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
@@ -739,7 +759,7 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
   const float c = p.scale * LOG2E;
 
   DmaStage<64, HDP> dq_, dd_;
-  dq_.init(p.q_sl, p.hd, wave, lane);
+  dq_.init(p.q_sl, hd_q, wave, lane);
   dd_.init(p.do_sl, p.hd, wave, lane);
   const unsigned q_step = (unsigned)(64 * p.q_sl * 2), do_step = (unsigned)(64 * p.do_sl * 2);
   auto issue_tile = [&](int j) {
@@ -765,6 +785,14 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
     if (e >= p.hd) { offk = 0xfffffff0u; offv = 0xfffffff0u; }
     kf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, offk, 0, 0));
     vf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, offv, 0, 0));
+  }
+  if constexpr (ONES) {
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) kf[ks] = scale_frag(kf[ks], c);
+    if (h == 1) {  // columns hd, hd+1 of every key row: 1.0 (they meet -lse2 hi, lo in the Q pad)
+      kf[KSQ - 1][0] = (__bf16)1.0f;
+      kf[KSQ - 1][1] = (__bf16)1.0f;
+    }
   }
 
   f32x16 dk[NDB], dv[NDB];
@@ -800,15 +828,24 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : 2)) void attn_bwd_dkv_kernel(A
       }
       PRIO_LO();
       f32x16 pm;
+      if constexpr (ONES) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + qb * 32 + 8 * rg + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * rg + e;
-          const float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[e]);
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(s[r]);
           pm[r] = pr;
           s[r] = pr * dp[r];  // dS (unscaled)
+        }
+      } else {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + qb * 32 + 8 * rg + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rg + e;
+            const float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[e]);
+            pm[r] = pr;
+            s[r] = pr * dp[r];  // dS (unscaled)
+          }
         }
       }
       PRIO_HI();
@@ -912,7 +949,8 @@ int run_bwd(AttnP p, hipStream_t s) {
   if (!once) {
     set_lds(attn_bwd_dq_kernel<HDP, HDQ, false>, LDS_DQ);
     if constexpr (HDP == 96) set_lds(attn_bwd_dq_kernel<HDP, HDQ, true>, LDS_DQ);
-    set_lds(attn_bwd_dkv_kernel<HDP, HDQ>, LDS_DKV);
+    set_lds(attn_bwd_dkv_kernel<HDP, HDQ, false>, LDS_DKV);
+    if constexpr (HDP == 96) set_lds(attn_bwd_dkv_kernel<HDP, HDQ, true>, LDS_DKV);
     once = true;
   }
   const long rows = (long)p.B * p.H * p.Lq;
@@ -934,7 +972,12 @@ int run_bwd(AttnP p, hipStream_t s) {
   int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DKV, s, 3.0 * prod, 2.0 * qb + 4.0 * kb);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ>), dim3(grid), dim3(256), LDS_DKV, s, p);
+    bool ones_kv = false;
+    if constexpr (HDP == 96) ones_kv = p.kv_pad_ones && p.hd == 72;
+    if constexpr (HDP == 96) {
+      if (ones_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DKV, s, p);
+    }
+    if (!ones_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS_DKV, s, p);
   }
   p.n_rt = cdiv(p.Lq, 128);
   grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
