@@ -192,7 +192,8 @@ def main():
     if breakdown:
         dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])
     names = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_delta", "attn_bwd_dkv", "attn_bwd_dq",
-             "rmsnorm_mod_fwd", "rmsnorm_mod_bwd", "adamw", "qkv_rope_fwd", "qkv_rope_bwd", "gate_bwd"]
+             "rmsnorm_mod_fwd", "rmsnorm_mod_bwd", "adamw", "qkv_rope_fwd", "qkv_rope_bwd", "gate_bwd",
+             "attn_fwd_plain", "attn_bwd_dkv_plain", "attn_bwd_dq_plain"]
 
     # ---- timed region: exactly K steps between barrier + synchronize --------------------------
     sync()

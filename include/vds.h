@@ -226,7 +226,9 @@ int vds_cast_bf16_f32(const void* src, float* dst, int64_t n, vds_stream_t strea
  * flops / bytes are the ALGORITHMIC work of the recorded launches (per kernel). */
 enum { VDS_PROF_GEMM_NT = 0, VDS_PROF_GEMM_NN, VDS_PROF_GEMM_TN, VDS_PROF_ATTN_FWD, VDS_PROF_ATTN_BWD_DELTA,
        VDS_PROF_ATTN_BWD_DKV, VDS_PROF_ATTN_BWD_DQ, VDS_PROF_RMSNORM_FWD, VDS_PROF_RMSNORM_BWD, VDS_PROF_ADAMW,
-       VDS_PROF_QKV_ROPE_FWD, VDS_PROF_QKV_ROPE_BWD, VDS_PROF_GATE_BWD, VDS_PROF_NCLASS };
+       VDS_PROF_QKV_ROPE_FWD, VDS_PROF_QKV_ROPE_BWD, VDS_PROF_GATE_BWD,
+       /* the attention kernel instances without the ones-column contract (cross-attention, hd 64/128) */
+       VDS_PROF_ATTN_FWD_PLAIN, VDS_PROF_ATTN_BWD_DKV_PLAIN, VDS_PROF_ATTN_BWD_DQ_PLAIN, VDS_PROF_NCLASS };
 typedef struct vds_prof_stat { int64_t launches; double ms; double flops; double bytes; } vds_prof_stat;
 int vds_prof_enable(uint32_t class_mask);
 int vds_prof_collect(vds_prof_stat* out /* [VDS_PROF_NCLASS] */);

@@ -53,5 +53,5 @@ for hd, H, hdp in ((72, 16, 96), (64, 12, 64), (128, 16, 128)):
     st = ops.prof_collect()
     ops.prof_enable(0)
     for kname in ("attn_bwd_dkv", "attn_bwd_dq", "attn_bwd_delta"):
-        r = st[kname]
+        r = st.get(kname) or st[kname + "_plain"]
         print(f"{tag} {kname} hd{hd}: {r['ms']/r['launches']:8.3f} ms {r['flops']/r['ms']/1e9:7.1f} TF/s")

@@ -42,7 +42,7 @@ class ProfStat(C.Structure):
     _fields_ = [("launches", c_i64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-PROF_NCLASS = 13
+PROF_NCLASS = 16
 
 
 class AdamWTensor(C.Structure):

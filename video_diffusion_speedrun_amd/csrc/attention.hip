@@ -927,7 +927,9 @@ int run_fwd(AttnP p, hipStream_t s) {
   p.n_rt = cdiv(p.Lq, use_wide ? 256 : 128);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
-  vdsprof::Scope ps(VDS_PROF_ATTN_FWD, s, fl, 2.0 * p.B * p.H * p.hd * (2.0 * p.Lq + 2.0 * p.Lk));
+  const bool ones_fwd = HDP == 96 && use_wide && p.kv_pad_ones && p.hd == 72;
+  vdsprof::Scope ps(ones_fwd ? VDS_PROF_ATTN_FWD : VDS_PROF_ATTN_FWD_PLAIN, s, fl,
+                    2.0 * p.B * p.H * p.hd * (2.0 * p.Lq + 2.0 * p.Lk));
   if constexpr (HDP == 96) {
     if (use_wide) {
       if (p.kv_pad_ones && p.hd == 72)
@@ -971,9 +973,9 @@ int run_bwd(AttnP p, hipStream_t s) {
   p.n_rt = cdiv(p.Lk, 128);
   int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
-    vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DKV, s, 3.0 * prod, 2.0 * qb + 4.0 * kb);
     bool ones_kv = false;
     if constexpr (HDP == 96) ones_kv = p.kv_pad_ones && p.hd == 72;
+    vdsprof::Scope ps(ones_kv ? VDS_PROF_ATTN_BWD_DKV : VDS_PROF_ATTN_BWD_DKV_PLAIN, s, 3.0 * prod, 2.0 * qb + 4.0 * kb);
     if constexpr (HDP == 96) {
       if (ones_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DKV, s, p);
     }
@@ -982,9 +984,9 @@ int run_bwd(AttnP p, hipStream_t s) {
   p.n_rt = cdiv(p.Lq, 128);
   grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
-    vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DQ, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
     bool ones = false;
     if constexpr (HDP == 96) ones = p.kv_pad_ones && p.hd == 72;
+    vdsprof::Scope ps(ones ? VDS_PROF_ATTN_BWD_DQ : VDS_PROF_ATTN_BWD_DQ_PLAIN, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
     if constexpr (HDP == 96) {
       if (ones) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DQ, s, p);
     }
