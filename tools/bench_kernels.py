@@ -26,7 +26,7 @@ def rnd(*shape, scale=1.0, dtype=bf16):
 
 
 res = []
-B, L, D = 2, 8208, 1152
+B, L, D = int(os.environ.get("B", 2)), 8208, 1152
 M = B * L
 for name, N, K in (("qkv", 3 * D, D), ("proj", D, D), ("fc1", 4 * D, D), ("fc2", D, 4 * D)):
     x, w = rnd(M, K), rnd(N, K, scale=0.03)

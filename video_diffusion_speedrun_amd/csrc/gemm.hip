@@ -44,6 +44,7 @@ struct GemmP {
   int atomic;
   unsigned a_bytes, b_bytes;
   int tiles_m, tiles_n;
+  int group_m;
 };
 
 // ---- swizzles -------------------------------------------------------------------------
@@ -380,9 +381,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int group = GROUP_M * p.tiles_n;
-  const int first_m = (pid / group) * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int group = p.group_m * p.tiles_n;
+  const int first_m = (pid / group) * p.group_m;
+  const int gsz = min(p.tiles_m - first_m, p.group_m);
   const int tile_m = first_m + (pid % group) % gsz;
   const int tile_n = (pid % group) / gsz;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -611,6 +612,12 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   bool use_big = a->layout != VDS_TN && a->K >= 256 && (double)rounds_big * (2.0 / 1.24) < (double)rounds_small;
   if (force_tile == 128) use_big = false;
   if (force_tile == 256) use_big = true;
+  static int group_m = -1;
+  if (group_m < 0) {
+    const char* e = getenv("VDS_GEMM_GROUP_M");
+    group_m = e ? atoi(e) : GROUP_M;
+  }
+  p.group_m = group_m;
   if (use_big) {
     p.tiles_m = tm;
     p.tiles_n = tn;
