@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvds_hip.so")
+LIB_PATH = os.environ.get("VDS_LIB_PATH") or os.path.join(_HERE, "libvds_hip.so")  # override: A/B of kernel builds
 
 VDS_NT, VDS_NN, VDS_TN = 0, 1, 2
 EPI_STORE, EPI_BIAS_GELU, EPI_GATE_RES, EPI_DGELU, EPI_F32 = 0, 1, 2, 3, 4

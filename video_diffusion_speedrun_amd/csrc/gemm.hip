@@ -21,6 +21,7 @@
 #include "prof.h"
 #include "../../include/vds.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -409,10 +410,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   const unsigned a_step = A_KM ? (unsigned)(BK * p.lda * 2) : BK * 2;
   const unsigned b_step = B_KM ? (unsigned)(BK * p.ldb * 2) : BK * 2;
 
-  // issue half-tile `which` (0 A0, 1 B0, 2 B1, 3 A1) of K tile T into its slot of buffer T & 1
-  auto issue = [&](int T, int which) {
+  // issue half-tile `which` (0 A0, 1 B0, 2 B1, 3 A1) of K tile T into its slot of buffer `par`
+  // (= (T - kt_begin) & 1, passed as a compile-time constant so that every LDS address is base + immediate)
+  auto issue = [&](int T, int which, int par) {
     const int krem = (T < kt_end) ? p.K - T * BK : 0;
-    char* buf = smem + (T & 1) * BUF;
+    char* buf = smem + par * BUF;
     if (which == 0) issue_half<A_KM>(ra, buf + SLOT_A0, va[0], ca[0], (unsigned)T * a_step, krem, wave);
     else if (which == 3) issue_half<A_KM>(ra, buf + SLOT_A1, va[1], ca[1], (unsigned)T * a_step, krem, wave);
     else if (which == 1) issue_half<B_KM>(rb, buf + SLOT_B0, vb[0], cb[0], (unsigned)T * b_step, krem, wave);
@@ -426,8 +428,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: 7 half-tiles in flight, A0 / B0 of the first tile landed -------------------
-  issue(kt_begin, 0); issue(kt_begin, 1); issue(kt_begin, 2); issue(kt_begin, 3);
-  issue(kt_begin + 1, 0); issue(kt_begin + 1, 1); issue(kt_begin + 1, 2);
+  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0);
+  issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1); issue(kt_begin + 1, 2, 1);
   VDS_WAIT_VM(10);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
@@ -462,12 +464,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     __builtin_amdgcn_s_setprio(0);                                                                    \
   } while (0)
 
-  for (int T = kt_begin; T < kt_end; ++T) {
-    const char* buf = smem + (T & 1) * BUF;
+  // one K tile = 4 phases; unrolled by two so that the buffer parity is a compile-time constant
+  auto k_tile = [&](int T, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    const char* buf = smem + par * BUF;
     // ---- phase 0: quadrant (0,0) <- A0, B0 ----
     read_a(buf + SLOT_A0);
     read_b(buf + SLOT_B0, fb0);
-    issue(T + 1, 3);
+    issue(T + 1, 3, par ^ 1);
     VDS_WAIT_LGKM0();
     VDS_WAIT_VM(10);  // B1(T) landed
     __builtin_amdgcn_s_barrier();
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     // ---- phase 1: quadrant (0,1) <- B1 ----
     read_b(buf + SLOT_B1, fb1);
-    issue(T + 2, 0);
+    issue(T + 2, 0, par);
     VDS_WAIT_LGKM0();
     VDS_WAIT_VM(10);  // A1(T) landed
     __builtin_amdgcn_s_barrier();
@@ -483,17 +487,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: quadrant (1,1) <- A1 ----
     read_a(buf + SLOT_A1);
-    issue(T + 2, 1);
+    issue(T + 2, 1, par);
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
     VDS_QUADRANT(1, 1, fb1);
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: quadrant (1,0) <- B0 (registers) ----
-    issue(T + 2, 2);
+    issue(T + 2, 2, par);
     VDS_WAIT_VM(10);  // A0(T+1), B0(T+1) landed
     __builtin_amdgcn_s_barrier();
     VDS_QUADRANT(1, 0, fb0);
     __builtin_amdgcn_s_barrier();
+  };
+  for (int T = kt_begin; T < kt_end; T += 2) {
+    k_tile(T, std::integral_constant<int, 0>{});
+    if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
   }
 #undef VDS_QUADRANT
   if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
