@@ -450,3 +450,38 @@ def test_oracle_parity_long_sequence_hd72(vds):
         torch.manual_seed(0)
         losses.append(vds["train"].train_step(m, opt, None, batch, "cuda", generator=gen, rope_start=start).item())
     assert all(map(lambda z: z == z, losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.timeout(900)
+def test_headline_shape_block_vs_oracle(vds):
+    """ONE DiT-XL block (+ embed / final layers) at the headline shape -- latent [1,16,16,64,64],
+    8192+16 tokens, 16 heads of 72, context [512,4096] -- against the fp32 CPU oracle: output,
+    loss and every gradient.  (The oracle needs ~14 GB of host memory and some tens of seconds.)"""
+    cfg = O.DiTConfig(in_channels=16, patch_size=2, time_patch_size=2, hidden_size=1152, depth=1, num_heads=16,
+                      cross_attn_input_size=4096, residual_v=True, train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=71, randomize_zero_init=True, init_std_factor=0.1)
+    g = torch.Generator().manual_seed(72)
+    x = torch.randn(1, 16, 16, 64, 64, generator=g).to(bf16)
+    ctx = torch.randn(1, 512, 4096, generator=g).to(bf16)
+    t = torch.tensor([0.55]).to(bf16)
+    v = torch.randn(1, 16, 16, 64, 64, generator=g).to(bf16)
+    start = (9, 21, 33)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    Pg = {k: w.clone().requires_grad_(True) for k, w in P.items()}
+    o_ref = O.dit_forward(Pg, cfg, x.float(), ctx.float(), t.float(), start)
+    l_ref, _ = O.flow_loss(v, o_ref)
+    l_ref.backward()
+    m = build(vds, cfg, P)
+    out = m(x.cuda(), ctx.cuda(), t.cuda(), rope_start=start)
+    assert rel(out, o_ref) <= 2.5e-2, rel(out, o_ref)
+    loss, _ = vds["train"].flow_loss(out, v.cuda())
+    assert abs(loss.item() - l_ref.item()) / l_ref.item() <= 1e-2
+    loss.backward()
+    bad = []
+    for k, p in m.named_parameters():
+        if Pg[k].grad is None or k.endswith("lambda_param") or float(Pg[k].grad.abs().max()) == 0:
+            continue
+        c, e = cosine(p.grad, Pg[k].grad), rel(p.grad, Pg[k].grad)
+        if not (c >= 0.99 and e <= 6e-2):
+            bad.append((k, c, e))
+    assert not bad, bad
