@@ -191,6 +191,8 @@ def main():
             ops.prof_enable(0)
     if breakdown:
         dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])
+    elif not args.no_prof:  # --warmup 0: no ranking step; time the kernel that dominates every attention-heavy config
+        dominant = "attn_bwd_dkv" if (kw["hidden_size"] // kw["num_heads"]) == 72 else "attn_bwd_dkv_plain"
     names = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_delta", "attn_bwd_dkv", "attn_bwd_dq",
              "rmsnorm_mod_fwd", "rmsnorm_mod_bwd", "adamw", "qkv_rope_fwd", "qkv_rope_bwd", "gate_bwd",
              "attn_fwd_plain", "attn_bwd_dkv_plain", "attn_bwd_dq_plain"]
