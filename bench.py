@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the live per-kernel HIP-event timing")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel-class table (stderr)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one captured HIP graph (1 GPU; launch-bound workloads)")
     ap.add_argument("--force-shard-runtime", action="store_true",
                     help="1 GPU only: run the sharding runtime (streams, events, RCCL collectives on a 1-rank group)")
     args = ap.parse_args()
@@ -173,6 +175,13 @@ def main():
     def one_step():
         return train_step(model, opt, sched, batch, device, generator=gen)
 
+    graphed = None
+    if args.graph:  # whole-step HIP-graph replay (graph.py); world_size 1 only
+        from video_diffusion_speedrun_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, sched, device, eager_steps=1)
+        for _ in range(2):  # one eager step, then capture + first replay (untimed)
+            graphed.step(batch)
+
     def sync():
         if world > 1:
             dist.barrier()
@@ -199,14 +208,17 @@ def main():
 
     # ---- timed region: exactly K steps between barrier + synchronize --------------------------
     sync()
-    if dominant is not None:
+    if dominant is not None and graphed is None:
         ops.prof_enable(1 << names.index(dominant))  # events around the dominant kernel's launches only
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = one_step()
+        loss = graphed.step(batch) if graphed is not None else one_step()
     sync()
     dt = time.perf_counter() - t0
-    dom = ops.prof_collect().get(dominant) if dominant is not None else None
+    if graphed is not None:  # a replay has no per-launch events: the kernel's duration comes from the eager warmup step
+        dom = breakdown.get(dominant)
+    else:
+        dom = ops.prof_collect().get(dominant) if dominant is not None else None
     ops.prof_enable(0)
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -226,6 +238,7 @@ def main():
             "data": "synthetic (N(0,1) latents/context, random-init weights, zero-init tensors re-drawn N(0,0.02))",
             "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"fsdp{world}" if world > 1 else "single",
+                       "launch": "hip-graph replay" if graphed is not None else "eager",
                        "step_tflop_per_sample": flops / 1e12},
             "mfma_util_step": value * flops / (world * PEAK_BF16_TFLOPS * 1e12),
             "loss": loss_val,

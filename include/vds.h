@@ -150,6 +150,12 @@ int vds_rope_rows(const float* tab_t_cos, const float* tab_t_sin, const float* t
                   int32_t st, int32_t sh, int32_t sw, int32_t n_reg, float* cosb, float* sinb,
                   vds_stream_t stream);
 
+/* the same with the offsets (st, sh, sw) read from device memory (int32[3], clamped to the table): nothing
+ * per-step remains in the arguments, so a captured whole-step graph can be replayed */
+int vds_rope_rows_dev(const float* tab_t_cos, const float* tab_t_sin, const float* tab_s_cos,
+                      const float* tab_s_sin, int32_t nt, int32_t ns, int32_t t, int32_t h, int32_t w,
+                      const int32_t* start_dev, int32_t n_reg, float* cosb, float* sinb, vds_stream_t stream);
+
 /* ------------------------------------------------------------- small-M linears (B rows) --
  * y[b, n] = act_out( sum_k act_in(x[b,k]) * W[n,k] + bias[n] ), M = B <= 16 rows:
  * time_embed / adaLN_modulation / final_modulation (model.py:90,318-322,339-341).
@@ -213,6 +219,12 @@ int vds_adamw_multi(const vds_adamw_tensor* desc_dev, const int32_t* chunk_tenso
                     const int64_t* chunk_start_dev, int32_t n_chunks, int32_t chunk_elems,
                     float beta1, float beta2, float eps, int32_t step, float lr_mult,
                     float grad_scale, vds_stream_t stream);
+
+/* the same with the per-step scalars in device memory: scalars_dev = { 1 - beta1^step, 1/sqrt(1 - beta2^step),
+ * lr_mult } (graph replay: the host refreshes them with a copy before each replay) */
+int vds_adamw_multi_dev(const vds_adamw_tensor* desc_dev, const int32_t* chunk_tensor_dev,
+                        const int64_t* chunk_start_dev, int32_t n_chunks, int32_t chunk_elems, float beta1,
+                        float beta2, float eps, const float* scalars_dev, float grad_scale, vds_stream_t stream);
 
 /* f32 -> bf16 cast (FSDP param_dtype cast before all-gather, model.py:516-518) */
 int vds_cast_f32_bf16(const float* src, void* dst, int64_t n, vds_stream_t stream);

@@ -485,3 +485,54 @@ def test_headline_shape_block_vs_oracle(vds):
         if not (c >= 0.99 and e <= 6e-2):
             bad.append((k, c, e))
     assert not bad, bad
+
+
+def test_graph_replay_matches_eager_steps(vds):
+    """graph.GraphedTrainStep (whole-step HIP-graph replay): two eager steps, capture, four
+    replays give the same losses and parameters as six eager steps from the same seeds -- same kernels
+    in the same order; the RoPE offsets, AdamW scalars and LR multiplier reach the replays through
+    device memory, the z / noise / caption-dropout draws through torch's graph-safe device generator.
+    Allowed difference: summation order of fp32 atomics and the last-ulp of the host-side powf."""
+    from video_diffusion_speedrun_amd.graph import GraphedTrainStep
+    cfg = O.DiTConfig(in_channels=16, hidden_size=128, depth=3, num_heads=2, cross_attn_input_size=64,
+                      residual_v=True, train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=41, randomize_zero_init=True, init_std_factor=1.0)
+    g = torch.Generator().manual_seed(5)
+    batches = [{"latent": torch.randn(2, 16, 4, 8, 8, generator=g).cuda(), "context": torch.randn(2, 16, 64, generator=g).cuda(),
+                "prompt": ["", ""]} for _ in range(6)]
+    results = []
+    for graphed in (False, True):
+        m = build(vds, cfg, P)
+        groups, _ = m.get_mup_setup(3e-3, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
+        opt = vds["optim"].MuAdamW(groups, betas=(0.95, 0.99))
+        sched = vds["train"].get_schedule(opt, "cosine", 3, 50)
+        torch.manual_seed(77)  # CPU RNG (RoPE offsets) and the default device generator (z, noise, dropout)
+        torch.cuda.manual_seed(77)
+        losses = []
+        if graphed:
+            gs = GraphedTrainStep(m, opt, sched, "cuda", eager_steps=2)
+            for b in batches:
+                losses.append(gs.step(b).item())
+            assert gs.n_replays == 4 and opt._step == 6
+        else:
+            for b in batches:
+                losses.append(vds["train"].train_step(m, opt, sched, b, "cuda").item())
+        torch.cuda.synchronize()
+        results.append((losses, {k: v.clone() for k, v in m.full_state_dict().items()}))
+    (l0, p0), (l1, p1) = results
+    assert len(set(l0)) == 6  # different batches / draws every step
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    for k in p0:
+        assert rel(p1[k], p0[k]) <= 1e-5, (k, rel(p1[k], p0[k]))
+
+
+def test_graph_replay_rejects_other_shapes(vds):
+    from video_diffusion_speedrun_amd.graph import GraphedTrainStep
+    cfg = O.DiTConfig(in_channels=16, hidden_size=128, depth=1, num_heads=2, cross_attn_input_size=64,
+                      residual_v=True, train_bias_and_rms=False)
+    m = build(vds, cfg, O.init_params(cfg, seed=42, randomize_zero_init=True, init_std_factor=1.0))
+    groups, _ = m.get_mup_setup(3e-3, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
+    gs = GraphedTrainStep(m, vds["optim"].MuAdamW(groups, betas=(0.95, 0.99)), None, "cuda", eager_steps=1)
+    gs.step({"latent": torch.randn(2, 16, 4, 8, 8).cuda(), "context": torch.randn(2, 16, 64).cuda()})
+    with pytest.raises(ValueError):
+        gs.step({"latent": torch.randn(2, 16, 4, 8, 16).cuda(), "context": torch.randn(2, 16, 64).cuda()})

@@ -69,6 +69,7 @@ SIGNATURES = {
                          c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_rope_rows": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
                       c_vp, c_vp],
+    "vds_rope_rows_dev": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp],
     "vds_small_linear_fwd": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_small_linear_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_timestep_embedding": [c_vp, c_vp, c_i32, c_i32, c_vp],
@@ -81,6 +82,7 @@ SIGNATURES = {
     "vds_flow_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i64, c_vp],
     "vds_cfg_euler_step": [c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i64, c_vp],
     "vds_adamw_multi": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32, c_vp],
+    "vds_adamw_multi_dev": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_f32, c_vp],
     "vds_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
     "vds_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
     "vds_selftest_lanemaps": [c_vp, c_vp],

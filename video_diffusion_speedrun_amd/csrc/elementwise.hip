@@ -692,7 +692,12 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* s, float* d, long n) {
 // cos=1, sin=0.  tab_* are the per-axis tables [128, n] the reference's buffer factorises into.
 __global__ void rope_rows_kernel(const float* tab_t_cos, const float* tab_t_sin, const float* tab_s_cos,
                                  const float* tab_s_sin, int nt, int ns, int t, int h, int w, int st, int sh, int sw,
-                                 int n_reg, float* cosb, float* sinb) {
+                                 int n_reg, float* cosb, float* sinb, const int* start_dev) {
+  if (start_dev) {  // offsets kept in device memory (whole-step graph replay: nothing per-step in the arguments)
+    st = min(max(start_dev[0], 0), 128 - t);
+    sh = min(max(start_dev[1], 0), 128 - h);
+    sw = min(max(start_dev[2], 0), 128 - w);
+  }
   const int half = nt + 2 * ns;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long rows = n_reg + (long)t * h * w;
@@ -957,6 +962,18 @@ extern "C" int vds_rope_rows(const float* tab_t_cos, const float* tab_t_sin, con
   if (st < 0 || sh < 0 || sw < 0 || st + t > 128 || sh + h > 128 || sw + w > 128) return VDS_ERR_ARG;
   const long n = ((long)n_reg + (long)t * h * w) * (nt + 2 * ns);
   hipLaunchKernelGGL(rope_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tab_t_cos,
-                     tab_t_sin, tab_s_cos, tab_s_sin, nt, ns, t, h, w, st, sh, sw, n_reg, cosb, sinb);
+                     tab_t_sin, tab_s_cos, tab_s_sin, nt, ns, t, h, w, st, sh, sw, n_reg, cosb, sinb, (const int*)nullptr);
+  return ok();
+}
+
+extern "C" int vds_rope_rows_dev(const float* tab_t_cos, const float* tab_t_sin, const float* tab_s_cos,
+                                 const float* tab_s_sin, int32_t nt, int32_t ns, int32_t t, int32_t h, int32_t w,
+                                 const int32_t* start_dev, int32_t n_reg, float* cosb, float* sinb,
+                                 vds_stream_t stream) {
+  if (!tab_t_cos || !tab_t_sin || !tab_s_cos || !tab_s_sin || !cosb || !sinb || !start_dev) return VDS_ERR_ARG;
+  if (t > 128 || h > 128 || w > 128) return VDS_ERR_ARG;
+  const long n = ((long)n_reg + (long)t * h * w) * (nt + 2 * ns);
+  hipLaunchKernelGGL(rope_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tab_t_cos,
+                     tab_t_sin, tab_s_cos, tab_s_sin, nt, ns, t, h, w, 0, 0, 0, n_reg, cosb, sinb, (const int*)start_dev);
   return ok();
 }

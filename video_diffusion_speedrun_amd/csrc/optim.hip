@@ -18,7 +18,12 @@ struct AdamT {
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamT* desc, const int* chunk_tensor,
                                                     const long* chunk_start, int chunk_elems, float beta1,
                                                     float beta2, float eps, float bc1, float rsqrt_bc2_inv,
-                                                    float lr_mult, float grad_scale) {
+                                                    float lr_mult, float grad_scale, const float* sc_dev) {
+  if (sc_dev) {  // per-step scalars kept in device memory (whole-step graph replay)
+    bc1 = sc_dev[0];
+    rsqrt_bc2_inv = sc_dev[1];
+    lr_mult = sc_dev[2];
+  }
   const AdamT t = desc[chunk_tensor[blockIdx.x]];
   const long s0 = chunk_start[blockIdx.x];
   const long s1 = min(t.numel, s0 + (long)chunk_elems);
@@ -202,7 +207,20 @@ extern "C" int vds_adamw_multi(const vds_adamw_tensor* desc_dev, const int32_t* 
   vdsprof::Scope ps(VDS_PROF_ADAMW, (hipStream_t)stream, 0.0, 30.0 * (double)n_chunks * chunk_elems);
   hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamT*)desc_dev,
                      chunk_tensor_dev, (const long*)chunk_start_dev, chunk_elems, beta1, beta2, eps, bc1,
-                     1.0f / sqrtf(bc2), lr_mult, grad_scale);
+                     1.0f / sqrtf(bc2), lr_mult, grad_scale, (const float*)nullptr);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+extern "C" int vds_adamw_multi_dev(const vds_adamw_tensor* desc_dev, const int32_t* chunk_tensor_dev,
+                                   const int64_t* chunk_start_dev, int32_t n_chunks, int32_t chunk_elems, float beta1,
+                                   float beta2, float eps, const float* scalars_dev, float grad_scale,
+                                   vds_stream_t stream) {
+  if (!desc_dev || !chunk_tensor_dev || !chunk_start_dev || !scalars_dev || n_chunks < 0 || chunk_elems < 4) return VDS_ERR_ARG;
+  if (n_chunks == 0) return VDS_OK;
+  vdsprof::Scope ps(VDS_PROF_ADAMW, (hipStream_t)stream, 0.0, 30.0 * (double)n_chunks * chunk_elems);
+  hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamT*)desc_dev,
+                     chunk_tensor_dev, (const long*)chunk_start_dev, chunk_elems, beta1, beta2, eps, 1.0f, 1.0f, 1.0f,
+                     grad_scale, scalars_dev);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 

@@ -1,0 +1,109 @@
+"""Whole-step HIP-graph replay of the train step (the reference's analogue is
+`torch.compile(dit_model)` behind `--compile_models`, train.py:326-328, which removes Python and
+launch overhead with a tracing compiler).
+
+MI355X-first: nothing is traced or re-generated.  The explicit kernel sequence of
+`train.forward -> loss.backward -> MuAdamW.step` (about 60 launches per DiT block) is captured once
+into a HIP graph and replayed with one launch per step.  That needs every per-step value to live
+in device memory rather than in kernel arguments:
+
+  * the batch            -> static input buffers, refreshed with stream-ordered copies;
+  * the RoPE offsets     -> device int32[3] read by `vds_rope_rows_dev` (drawn on the host from the
+                            global CPU RNG exactly like the eager path, model.py:224-226);
+  * the AdamW bias corrections and LR multiplier -> device float[3] read by `vds_adamw_multi_dev`;
+  * z / noise / caption-dropout draws -> torch's default device generator (graph-safe Philox: the
+                            captured kernels take seed/offset from device memory).
+
+The first `eager_steps` calls run the ordinary path (they are real train steps: they build the
+optimizer's descriptor tables and the allocator pool the capture then reuses); the next call
+captures and from then on every call is a replay.  Large configurations are device-bound and gain
+little; launch-bound ones (C1-size models, small batches) gain the most -- DESIGN.md 7e.
+
+Single-GPU (world_size 1) only: the sharded runtime's RCCL collectives are not captured.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import train as _train
+
+bf16 = torch.bfloat16
+
+
+class GraphedTrainStep:
+    """`step(batch) -> loss` with the semantics of `train.train_step` (train.py:412-434)."""
+
+    def __init__(self, dit_model, optimizer, lr_scheduler, device, eager_steps: int = 2):
+        if getattr(dit_model, "_fsdp", None) is not None:
+            raise RuntimeError("GraphedTrainStep: the sharded (multi-GPU) runtime is not capturable; use the eager step")
+        if eager_steps < 1:
+            raise ValueError("at least one eager step is needed before the capture (descriptor tables, shadows)")
+        self.model, self.opt, self.sched = dit_model, optimizer, lr_scheduler
+        self.device = torch.device(device)
+        self.eager_left = eager_steps
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static: Dict[str, torch.Tensor] = {}
+        self.rope_dev = torch.zeros(3, dtype=torch.int32, device=self.device)
+        self.loss: Optional[torch.Tensor] = None
+        self.n_replays = 0
+        optimizer.use_device_scalars(self.device)
+
+    # ------------------------------------------------------------------------------------------
+    def _thw(self, latent):
+        m = self.model
+        return (latent.shape[2] // m.time_patch_size, latent.shape[3] // m.patch_size, latent.shape[4] // m.patch_size)
+
+    def _stage(self, batch):
+        """copy the batch into the static buffers (allocating them on first use)"""
+        lat, ctx = batch["latent"], batch["context"]
+        if not self.static:
+            self.static["latent"] = torch.empty(lat.shape, dtype=bf16, device=self.device)
+            self.static["context"] = torch.empty(ctx.shape, dtype=bf16, device=self.device)
+        for k, src in (("latent", lat), ("context", ctx)):
+            dst = self.static[k]
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"GraphedTrainStep was captured for {k} {tuple(dst.shape)}, got {tuple(src.shape)}")
+            dst.copy_(src, non_blocking=True)
+
+    def _draw_rope(self):
+        st = self.model.rope.draw_start(self._thw(self.static["latent"]))
+        self.rope_dev.copy_(torch.tensor(st, dtype=torch.int32))
+        return st
+
+    def _body(self, rope_start):
+        loss, _ = _train.forward(self.model, self.static, None, None, self.device, 0, False, rope_start=rope_start)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def _capture(self):
+        step0 = self.opt._step
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            loss = self._body(self.rope_dev)
+        self.opt._step = step0  # the capture launched nothing: `advance()` counts the step at replay time
+        self.graph, self.loss = g, loss
+
+    # ------------------------------------------------------------------------------------------
+    def step(self, batch) -> torch.Tensor:
+        if "context" not in batch:
+            raise ValueError("GraphedTrainStep takes pre-encoded batches: {'latent', 'context'}")
+        self._stage(batch)
+        if self.eager_left > 0:
+            self.eager_left -= 1
+            loss = self._body(self._draw_rope()).detach().clone()
+        else:
+            if self.graph is None:
+                self._capture()
+            self._draw_rope()
+            self.opt.advance()
+            self.graph.replay()
+            self.n_replays += 1
+            loss = self.loss.detach()
+        if self.sched is not None:
+            self.sched.step()
+        return loss

@@ -257,12 +257,14 @@ class DiT(nn.Module):
         thw = (t // self.time_patch_size, h // self.patch_size, w // self.patch_size)
         if rope_start is None:
             rope_start = self.rope.draw_start(thw)
+        if not isinstance(rope_start, torch.Tensor):  # a device int32[3] tensor is read by the kernel (graph.py)
+            rope_start = tuple(rope_start)
         self._ensure_groups(x.device)
         params = [p for p in self.parameters() if p.requires_grad]
         need_grad = torch.is_grad_enabled() and len(params) > 0
         if need_grad:
-            return _DiTFunction.apply(self, x, context, timesteps, tuple(rope_start), *params)
-        out, _ = self._forward_impl(x, context, timesteps, tuple(rope_start), save=False)
+            return _DiTFunction.apply(self, x, context, timesteps, rope_start, *params)
+        out, _ = self._forward_impl(x, context, timesteps, rope_start, save=False)
         return out
 
     def _gather_all(self):

@@ -227,6 +227,11 @@ def rope_rows(tabs, thw, start, n_reg, device):
     rows = n_reg + t * h * w
     cos = torch.empty(rows, nt + 2 * ns, dtype=f32, device=device)
     sin = torch.empty_like(cos)
+    if isinstance(start, torch.Tensor):  # offsets in device memory (int32[3]): whole-step graph replay
+        assert start.is_cuda and start.dtype == torch.int32 and start.numel() == 3
+        check(_lib.load().vds_rope_rows_dev(_p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]), nt, ns, t, h, w,
+                                            _p(start), n_reg, _p(cos), _p(sin), _stream()), "vds_rope_rows_dev")
+        return cos, sin
     check(_lib.load().vds_rope_rows(_p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _p(tabs[3]), nt, ns, t, h, w, start[0],
                                     start[1], start[2], n_reg, _p(cos), _p(sin), _stream()), "vds_rope_rows")
     return cos, sin

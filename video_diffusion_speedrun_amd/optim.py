@@ -27,6 +27,32 @@ class MuAdamW(torch.optim.Optimizer):
         self._table_key = None
         self._chunk_key = None
         self._dev = {}
+        self._dev_scalars = None  # device float[3]: see use_device_scalars
+
+    def use_device_scalars(self, device):
+        """Keep the per-step scalars (bias corrections, LR multiplier) in device memory instead of kernel
+        arguments, so that a captured step can be replayed (graph.py).  `step()` refreshes them with a
+        stream-ordered copy unless the stream is capturing; a replay driver calls `advance()` itself."""
+        if self._dev_scalars is None:
+            self._dev_scalars = torch.zeros(3, dtype=torch.float32, device=device)
+        return self._dev_scalars
+
+    def _scalars(self, mult):
+        import numpy as np
+        b1, b2 = (np.float32(b) for b in self.param_groups[0]["betas"])
+        one, st = np.float32(1), np.float32(self._step)
+        bc1 = one - np.power(b1, st)
+        bc2 = one - np.power(b2, st)
+        return torch.tensor([bc1, one / np.sqrt(bc2), np.float32(mult)], dtype=torch.float32)
+
+    def advance(self):
+        """host half of one captured step: count it and push its scalars (call before the replay)"""
+        plist = [(p, g) for g in self.param_groups for p in g["params"] if p.grad is not None and p.numel() > 0]
+        lrs, mult = self._lr_plan(plist)
+        if self._table_key is not None and tuple(k[2] for k in self._table_key) != tuple(lrs):
+            raise RuntimeError("MuAdamW: the base learning rates changed under a captured step; capture again")
+        self._step += 1
+        self._dev_scalars.copy_(self._scalars(mult))
 
     def _build_chunks(self, plist, device):
         chunk_t: List[int] = []
@@ -115,9 +141,17 @@ class MuAdamW(torch.optim.Optimizer):
             self._table_key = key
         b1, b2 = self.param_groups[0]["betas"]
         eps = self.param_groups[0]["eps"]
-        _lib.check(_lib.load().vds_adamw_multi(self._dev["desc"].data_ptr(), self._dev["ct"].data_ptr(),
-                                               self._dev["cs"].data_ptr(), self._dev["n"], CHUNK, b1, b2, eps,
-                                               self._step, mult, 1.0, ops._stream()), "vds_adamw_multi")
+        if self._dev_scalars is not None:
+            if not torch.cuda.is_current_stream_capturing():
+                self._dev_scalars.copy_(self._scalars(mult))
+            _lib.check(_lib.load().vds_adamw_multi_dev(self._dev["desc"].data_ptr(), self._dev["ct"].data_ptr(),
+                                                       self._dev["cs"].data_ptr(), self._dev["n"], CHUNK, b1, b2, eps,
+                                                       self._dev_scalars.data_ptr(), 1.0, ops._stream()),
+                       "vds_adamw_multi_dev")
+        else:
+            _lib.check(_lib.load().vds_adamw_multi(self._dev["desc"].data_ptr(), self._dev["ct"].data_ptr(),
+                                                   self._dev["cs"].data_ptr(), self._dev["n"], CHUNK, b1, b2, eps,
+                                                   self._step, mult, 1.0, ops._stream()), "vds_adamw_multi")
         # the bf16 shadows of these flat groups are now current: the next forward skips its cast pass
         for g in {id(getattr(p, "_vds_group", None)): getattr(p, "_vds_group", None) for p, _ in plist}.values():
             if g is not None:

@@ -78,7 +78,10 @@ def forward(dit_model, batch, text_encoder, tokenizer, device, global_step, mast
                                                     return_index=return_index)
         caption_encoded = caption_encoded.to(bf16)
         do_zero_out = torch.rand(caption_encoded.shape[0], device=device) < 0.01  # train.py:86
-        caption_encoded[do_zero_out] = 0
+        # same result as `caption_encoded[do_zero_out] = 0` without the host sync of a boolean index
+        # (capturable) and without writing into the caller's batch["context"]
+        caption_encoded = torch.where(do_zero_out[:, None, None], torch.zeros((), dtype=bf16, device=device),
+                                      caption_encoded)
     B = vae_latent.size(0)
     z = torch.randn(B, device=device, dtype=bf16, generator=generator)
     t = time_shift_from_normal(z)
