@@ -70,6 +70,23 @@ typedef struct vds_gemm_args {
 
 int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);
 
+/* The same GEMM with OCP fp8 operands (BASELINE config 5; no reference counterpart -- the reference trains in
+ * bf16): layout VDS_NT only, A[M,K] and B[N,K] one byte per element (a_fmt / b_fmt: 0 = e4m3fn, 1 = e5m2; B must
+ * be e4m3fn), K, lda, ldb multiples of 16.  C = epilogue((sum_k A B) * *scale_a * *scale_b) with per-tensor
+ * dequantisation factors read from device memory (NULL = 1).  Runs v_mfma_f32_16x16x128_f8f6f4 (2x the bf16
+ * MFMA rate).  Input / weight gradients are NT products of the transposed copies written by vds_quant_fp8. */
+int vds_gemm_fp8(const vds_gemm_args* args, const float* scale_a, const float* scale_b, int32_t a_fmt,
+                 int32_t b_fmt, vds_stream_t stream);
+
+/* amax[0] = max(amax[0], max |x|) over a bf16 matrix x[M,K] (row stride ldx elements); the caller zeroes amax. */
+int vds_absmax(const void* x, int64_t ldx, int32_t M, int32_t K, float* amax, vds_stream_t stream);
+
+/* Per-tensor fp8 quantisation of a bf16 matrix: q[m,k] = sat(x[m,k] * fmax / *amax) (fmt 0: e4m3fn, fmax 448;
+ * fmt 1: e5m2, fmax 57344), written row-major to q[M,K] (ldq, may be NULL) and / or transposed to qt[K,M] (ldt,
+ * may be NULL); *dq_out = *amax / fmax is the factor vds_gemm_fp8 multiplies back in.  *amax == 0 -> scale 1. */
+int vds_quant_fp8(const void* x, int64_t ldx, int32_t M, int32_t K, int32_t fmt, const float* amax, void* q,
+                  int64_t ldq, void* qt, int64_t ldt, float* dq_out, vds_stream_t stream);
+
 /* --------------------------------------------------------------- attention (MFMA) ----
  * F.scaled_dot_product_attention(q,k,v) full/non-causal (model.py:136,157), flash style.
  * q/k/v are addressed as base + b*stride_b + h*stride_h + l*stride_l (elements), rows of
@@ -240,7 +257,8 @@ enum { VDS_PROF_GEMM_NT = 0, VDS_PROF_GEMM_NN, VDS_PROF_GEMM_TN, VDS_PROF_ATTN_F
        VDS_PROF_ATTN_BWD_DKV, VDS_PROF_ATTN_BWD_DQ, VDS_PROF_RMSNORM_FWD, VDS_PROF_RMSNORM_BWD, VDS_PROF_ADAMW,
        VDS_PROF_QKV_ROPE_FWD, VDS_PROF_QKV_ROPE_BWD, VDS_PROF_GATE_BWD,
        /* the attention kernel instances without the ones-column contract (cross-attention, hd 64/128) */
-       VDS_PROF_ATTN_FWD_PLAIN, VDS_PROF_ATTN_BWD_DKV_PLAIN, VDS_PROF_ATTN_BWD_DQ_PLAIN, VDS_PROF_NCLASS };
+       VDS_PROF_ATTN_FWD_PLAIN, VDS_PROF_ATTN_BWD_DKV_PLAIN, VDS_PROF_ATTN_BWD_DQ_PLAIN, VDS_PROF_GEMM_FP8,
+       VDS_PROF_NCLASS };
 typedef struct vds_prof_stat { int64_t launches; double ms; double flops; double bytes; } vds_prof_stat;
 int vds_prof_enable(uint32_t class_mask);
 int vds_prof_collect(vds_prof_stat* out /* [VDS_PROF_NCLASS] */);

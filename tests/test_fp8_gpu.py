@@ -1,0 +1,95 @@
+"""fp8 path (BASELINE config 5) kernel tests: quantiser and fp8 GEMM through the C ABI.
+The reference has no fp8 path; the checker here is torch's own float8 dtypes on the CPU (OCP e4m3fn / e5m2,
+round-to-nearest-even) and exact small-integer products."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from video_diffusion_speedrun_amd import ops
+    return ops
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(bf16)
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("M,K", [(300, 136), (128, 128), (516, 1152), (4, 8)])
+def test_quant_matches_torch_float8(ops, fmt, M, K):
+    x = gen(M, K, seed=M + K, scale=3.0)
+    x[0, 0] = 0.0
+    amax = ops.absmax(x.cuda())
+    assert amax.item() == x.float().abs().max().item()
+    q, qt, dq = ops.quant_fp8(x.cuda(), fmt, amax, rowmajor=True, transposed=True)
+    fmax = 448.0 if fmt == 0 else 57344.0
+    scale = torch.tensor(fmax, dtype=f32) / amax.cpu()
+    want = (x.float() * scale).clamp(-fmax, fmax).to(ops.fp8_dtypes[fmt])
+    assert torch.equal(q.cpu().view(torch.uint8), want.view(torch.uint8))
+    assert torch.equal(qt.cpu().view(torch.uint8), want.view(torch.uint8).t().contiguous())
+    assert abs(dq.item() - amax.item() / fmax) <= 1e-7 * dq.item()
+    # strided source (a column block of a wider matrix), transposed copy only
+    wide = gen(M, K + 64, seed=7, scale=2.0).cuda()
+    am2 = ops.absmax(wide[:, 8:8 + K])
+    _, qt2, _ = ops.quant_fp8(wide[:, 8:8 + K], fmt, am2, rowmajor=False, transposed=True)
+    sc2 = torch.tensor(fmax, dtype=f32) / am2.cpu()
+    want2 = (wide[:, 8:8 + K].cpu().float() * sc2).clamp(-fmax, fmax).to(ops.fp8_dtypes[fmt])
+    assert torch.equal(qt2.cpu().view(torch.uint8), want2.view(torch.uint8).t().contiguous())
+
+
+def _small_ints(M, K, seed, vals):
+    g = torch.Generator().manual_seed(seed)
+    v = torch.tensor(vals, dtype=f32)
+    return v[torch.randint(0, len(vals), (M, K), generator=g)]
+
+
+@pytest.mark.parametrize("a_fmt", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 272), (256, 256, 128), (1000, 520, 1152), (16, 8, 16)])
+def test_gemm_fp8_exact_on_small_integers(ops, a_fmt, M, N, K):
+    """operands exactly representable in both fp8 formats, products and fp32 sums exact: the lane maps of
+    v_mfma_f32_16x16x128_f8f6f4, the K tail and ragged tiles must give the exact matrix product"""
+    from video_diffusion_speedrun_amd._lib import EPI_F32, EPI_STORE
+    A = _small_ints(M, K, 1, [-2.0, -1.0, -0.5, 0.0, 0.5, 1.0, 2.0, 3.0])
+    B = _small_ints(N, K, 2, [-1.5, -1.0, 0.0, 0.25, 1.0, 2.0])
+    want = A @ B.t()
+    Aq = A.to(ops.fp8_dtypes[a_fmt]).cuda()
+    Bq = B.to(torch.float8_e4m3fn).cuda()
+    assert torch.equal(Aq.float().cpu(), A) and torch.equal(Bq.float().cpu(), B)
+    sa = torch.tensor([0.5], device="cuda")
+    sb = torch.tensor([4.0], device="cuda")
+    C32 = torch.zeros(M, N, dtype=f32, device="cuda")
+    ops.gemm_fp8(EPI_F32, M, N, K, Aq, Bq, sa, sb, a_fmt, C32, N)
+    assert torch.equal(C32.cpu(), want * 2.0)
+    if K >= 1024:  # split-K with atomic accumulation (the weight-gradient form)
+        C32.zero_()
+        ops.gemm_fp8(EPI_F32, M, N, K, Aq, Bq, sa, sb, a_fmt, C32, N, split_k=3)
+        assert torch.equal(C32.cpu(), want * 2.0)
+    Cb = torch.empty(M, N, dtype=bf16, device="cuda")
+    ops.gemm_fp8(EPI_STORE, M, N, K, Aq, Bq, sa, None, a_fmt, Cb, N)
+    assert torch.equal(Cb.cpu(), (want * 0.5).to(bf16))
+
+
+def test_linear_fp8_close_to_bf16_linear(ops):
+    """quantise -> fp8 GEMM -> dequantise against the fp32 product of the same bf16 inputs: error at the
+    e4m3 quantisation level (2^-4 relative per element, averaged down by the contraction)"""
+    from video_diffusion_speedrun_amd._lib import EPI_STORE
+    M, N, K = 1024, 768, 1152
+    x, W = gen(M, K, seed=3), gen(N, K, seed=4, scale=0.03)
+    xq, _, sx = ops.quant_fp8(x.cuda(), 0, ops.absmax(x.cuda()))
+    Wq, _, sw = ops.quant_fp8(W.cuda(), 0, ops.absmax(W.cuda()))
+    y = torch.empty(M, N, dtype=bf16, device="cuda")
+    ops.gemm_fp8(EPI_STORE, M, N, K, xq, Wq, sx, sw, 0, y, N)
+    ref = x.float() @ W.float().t()
+    err = ((y.cpu().float() - ref).norm() / ref.norm()).item()
+    assert err <= 4e-2, err
+    # and exactly the product of the dequantised operands (up to the bf16 store)
+    ref_q = (xq.cpu().float() * sx.cpu()) @ (Wq.cpu().float() * sw.cpu()).t()
+    err_q = ((y.cpu().float() - ref_q).norm() / ref_q.norm()).item()
+    assert err_q <= 3e-3, err_q

@@ -42,7 +42,7 @@ class ProfStat(C.Structure):
     _fields_ = [("launches", c_i64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-PROF_NCLASS = 16
+PROF_NCLASS = 17
 
 
 class AdamWTensor(C.Structure):
@@ -85,6 +85,9 @@ SIGNATURES = {
     "vds_adamw_multi_dev": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_f32, c_vp],
     "vds_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
     "vds_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
+    "vds_gemm_fp8": [C.POINTER(GemmArgs), c_vp, c_vp, c_i32, c_i32, c_vp],
+    "vds_absmax": [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
+    "vds_quant_fp8": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "vds_selftest_lanemaps": [c_vp, c_vp],
     "vds_prof_enable": [C.c_uint32],
     "vds_prof_collect": [c_vp],

@@ -440,95 +440,144 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* dq, con
 }
 
 // ------------------------------------------------------------------ small-M linears ------
-// y[b,n] = sum_k act(x[b,k]) W[n,k] + bias[n]; one wave per output column, M <= 16 rows.
+// y[b,n] = sum_k act(x[b,k]) W[n,k] + bias[n]; one wave per 4 output columns (the x chunk a lane loads is
+// reused for 4 rows of W), M <= 16 rows.
 // (time_embed model.py:318-322, adaLN_modulation model.py:89-91, final_modulation 339-341)
+template <int MB>
 __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* x, const bf16_t* W, const bf16_t* bias,
                                                                float* y, int M, int N, int K, int act_in) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = blockIdx.x * 4 + wave;
-  if (n >= N) return;
-  float acc[16];
+  const int n0 = (blockIdx.x * 4 + wave) * 4;
+  if (n0 >= N) return;
+  float acc[4][MB];
 #pragma unroll
-  for (int b = 0; b < 16; ++b) acc[b] = 0.f;
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[i][b] = 0.f;
   for (int c = lane; c < (K >> 3); c += 64) {
-    float wv[8];
-    unpack8(*reinterpret_cast<const u32x4*>(W + (long)n * K + c * 8), wv);
+    float wv[4][8];
 #pragma unroll
-    for (int b = 0; b < 16; ++b)
+    for (int i = 0; i < 4; ++i)
+      unpack8(*reinterpret_cast<const u32x4*>(W + (long)min(n0 + i, N - 1) * K + c * 8), wv[i]);
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
       if (b < M) {
         float xv[8];
         load8f(x + (long)b * K + c * 8, xv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[b] += (act_in ? silu_f(xv[e]) : xv[e]) * wv[e];
+        for (int e = 0; e < 8; ++e) {
+          const float xe = act_in ? silu_f(xv[e]) : xv[e];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][b] += xe * wv[i][e];
+        }
       }
   }
-  const float bs = bias ? bf2f(bias[n]) : 0.f;
 #pragma unroll
-  for (int b = 0; b < 16; ++b)
-    if (b < M) {
-      const float s = wave_sum(acc[b]);
-      if (lane == 0) y[(long)b * N + n] = s + bs;
-    }
+  for (int i = 0; i < 4; ++i) {
+    if (n0 + i >= N) break;
+    const float bs = bias ? bf2f(bias[n0 + i]) : 0.f;
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+      if (b < M) {
+        const float s = wave_sum(acc[i][b]);
+        if (lane == 0) y[(long)b * N + n0 + i] = s + bs;
+      }
+  }
 }
 
-// dW[n,k] = sum_b dy[b,n] act(x[b,k]);  dbias[n] = sum_b dy[b,n]   (thread per (n, k-chunk))
+// dW[n,k] = sum_b dy[b,n] act(x[b,k]);  dbias[n] = sum_b dy[b,n]   (thread per (4 rows n, k-chunk): the
+// activated x chunk is built once and reused for the 4 rows)
 __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* dy, const float* x, float* dW,
                                                               float* dbias, int M, int N, int K, int act_in) {
   const int kc = K >> 3;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long)N * kc) return;
-  const int n = (int)(gid / kc), c = (int)(gid % kc);
-  float acc[8];
+  if (gid >= (long)((N + 3) / 4) * kc) return;
+  const int n0 = (int)(gid / kc) * 4, c = (int)(gid % kc);
+  float acc[4][8], sb[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  float sb = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    sb[i] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+  }
   for (int b = 0; b < M; ++b) {
-    const float g = dy[(long)b * N + n];
-    sb += g;
     float xv[8];
     load8f(x + (long)b * K + c * 8, xv);
+    if (act_in)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += g * (act_in ? silu_f(xv[e]) : xv[e]);
+      for (int e = 0; e < 8; ++e) xv[e] = silu_f(xv[e]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float g = dy[(long)b * N + min(n0 + i, N - 1)];
+      sb[i] += g;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[i][e] += g * xv[e];
+    }
   }
-  float* o = dW + (long)n * K + c * 8;
-  *reinterpret_cast<f32x4*>(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-  *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-  if (c == 0 && dbias) dbias[n] = sb;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (n0 + i >= N) break;
+    float* o = dW + (long)(n0 + i) * K + c * 8;
+    *reinterpret_cast<f32x4*>(o) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+    if (c == 0 && dbias) dbias[n0 + i] = sb[i];
+  }
 }
 
-// dx[b,k] += act'(x[b,k]) * sum_n dy[b,n] W[n,k]; block = one 64-row slab of W, thread = k-chunk
+// dx[b,k] += act'(x[b,k]) * sum_n dy[b,n] W[n,k].
+// block = (64-column range of W: 128-byte row segments) x (range of rows n); thread = (row lane tid/8, 8-column
+// chunk tid%8).  Every thread streams one 16-byte piece of W per row step (32 rows per step, unrolled), the 32 row
+// lanes are summed with lane exchanges + 4 KB of LDS, and only the n-ranges meet in atomics (dx accumulates the
+// modulation gradients of every block anyway).  W is read exactly once at full HBM request parallelism.
+template <int MB>
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* dy, const float* x, const bf16_t* W,
-                                                              float* dx, int M, int N, int K, int act_in) {
-  const int kc = K >> 3;
-  const int n0 = blockIdx.x * 64, n1 = min(N, n0 + 64);
-  for (int c = threadIdx.x; c < kc; c += 256) {
-    for (int b0 = 0; b0 < M; b0 += 4) {
-      float acc[4][8];
+                                                              float* dx, int M, int N, int K, int act_in,
+                                                              int rows_per_block) {
+  __shared__ float red[4][8][MB][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = tid & 7, r = tid >> 3;
+  const int kc = K >> 3, cg = blockIdx.x * 8 + c;
+  const bool live = cg < kc;
+  const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+  float acc[MB][8];
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb)
+  for (int b = 0; b < MB; ++b)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[bb][e] = 0.f;
-      for (int n = n0; n < n1; ++n) {
-        float wv[8];
-        unpack8(*reinterpret_cast<const u32x4*>(W + (long)n * K + c * 8), wv);
+    for (int e = 0; e < 8; ++e) acc[b][e] = 0.f;
+  const bf16_t* wp = W + (long)cg * 8;
+#pragma unroll 4
+  for (int n = n0 + r; n < n1; n += 32) {
+    float wv[8];
+    u32x4 raw = u32x4{0, 0, 0, 0};
+    if (live) raw = *reinterpret_cast<const u32x4*>(wp + (long)n * K);
+    unpack8(raw, wv);
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-          if (b0 + bb < M) {
-            const float g = dy[(long)(b0 + bb) * N + n];
+    for (int b = 0; b < MB; ++b)
+      if (b < M) {
+        const float g = dy[(long)b * N + n];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[bb][e] += g * wv[e];
-          }
+        for (int e = 0; e < 8; ++e) acc[b][e] += g * wv[e];
       }
+  }
+  // sum the 8 row lanes of this wave (lanes differing in bits 3..5), then the 4 waves through LDS
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb)
-        if (b0 + bb < M) {
-          float xv[8];
-          if (act_in) load8f(x + (long)(b0 + bb) * K + c * 8, xv);
+  for (int b = 0; b < MB; ++b)
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            atomicAdd(dx + (long)(b0 + bb) * K + c * 8 + e, act_in ? acc[bb][e] * dsilu_f(xv[e]) : acc[bb][e]);
-        }
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[b][e];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 8) red[wave][lane][b][e] = v;
     }
+  __syncthreads();
+  for (int i = tid; i < 8 * MB * 8; i += 256) {
+    const int e = i & 7, b = (i >> 3) % MB, cc = i / (8 * MB);
+    const int k = (blockIdx.x * 8 + cc) * 8 + e;
+    if (b >= M || k >= K) continue;
+    float v = red[0][cc][b][e] + red[1][cc][b][e] + red[2][cc][b][e] + red[3][cc][b][e];
+    if (act_in) v *= dsilu_f(x[(long)b * K + k]);
+    atomicAdd(dx + (long)b * K + k, v);
   }
 }
 
@@ -839,8 +888,16 @@ extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, 
 extern "C" int vds_small_linear_fwd(const float* x, const void* W, const void* bias, float* y, int32_t M,
                                     int32_t N, int32_t K, int32_t act_in, vds_stream_t stream) {
   if (!x || !W || !y || M < 1 || M > 16 || (K & 7)) return VDS_ERR_ARG;
-  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
-                     (const bf16_t*)W, (const bf16_t*)bias, y, M, N, K, act_in);
+  const dim3 grid((N + 15) / 16);
+  if (M <= 4)
+    hipLaunchKernelGGL(small_linear_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)W,
+                       (const bf16_t*)bias, y, M, N, K, act_in);
+  else if (M <= 8)
+    hipLaunchKernelGGL(small_linear_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)W,
+                       (const bf16_t*)bias, y, M, N, K, act_in);
+  else
+    hipLaunchKernelGGL(small_linear_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)W,
+                       (const bf16_t*)bias, y, M, N, K, act_in);
   return ok();
 }
 
@@ -849,12 +906,22 @@ extern "C" int vds_small_linear_bwd(const float* dy, const float* x, const void*
   if (!dy || !x || M < 1 || M > 16 || (K & 7)) return VDS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (dW) {
-    const long n = (long)N * (K >> 3);
+    const long n = (long)((N + 3) / 4) * (K >> 3);
     hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, x, dW, dbias, M, N, K, act_in);
   }
   if (dx) {
     if (!W) return VDS_ERR_ARG;
-    hipLaunchKernelGGL(small_linear_dx_kernel, dim3((N + 63) / 64), dim3(256), 0, s, dy, x, (const bf16_t*)W, dx, M, N, K, act_in);
+    const int gx = ((K >> 3) + 7) / 8;
+    int ny = max(1, min((N + 31) / 32, (512 + gx - 1) / gx));
+    const int rows = ((N + ny - 1) / ny + 31) / 32 * 32;
+    ny = (N + rows - 1) / rows;
+    const dim3 grid(gx, ny);
+    if (M <= 4)
+      hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)W, dx, M, N, K, act_in, rows);
+    else if (M <= 8)
+      hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)W, dx, M, N, K, act_in, rows);
+    else
+      hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)W, dx, M, N, K, act_in, rows);
   }
   return ok();
 }

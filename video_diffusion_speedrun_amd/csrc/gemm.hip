@@ -46,6 +46,8 @@ struct GemmP {
   unsigned a_bytes, b_bytes;
   int tiles_m, tiles_n;
   int group_m;
+  const float* sa; const float* sb;  // fp8 path: per-tensor dequantisation factors (device), else unused
+  double prof_k;                      // contraction length in elements (profiler flop count)
 };
 
 // ---- swizzles -------------------------------------------------------------------------
@@ -110,6 +112,17 @@ __device__ __forceinline__ bf16x8 frag_km(const char* tile, int col0, int ks, in
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 4 * 256));
   s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, r);
+}
+
+// fp8 k-contiguous tile (128-B rows = 128 k): fragment of v_mfma_f32_16x16x128_f8f6f4, lane -> row (l&15),
+// k 32*(l>>4)..+31 = the two 16-byte chunks 2g, 2g+1 (adjacent after the swizzle: (2g+1)^x = (2g^x)^1)
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ i32x8 frag_kc8(const char* tile, int row0, int lane) {
+  const int row = row0 + (lane & 15);
+  const int c0 = swz_kc(row, 2 * (lane >> 4));
+  const i32x4 lo = *reinterpret_cast<const i32x4*>(tile + row * 128 + c0 * 16);
+  const i32x4 hi = *reinterpret_cast<const i32x4*>(tile + row * 128 + (c0 ^ 1) * 16);
+  return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
 // Shared epilogue: a wave's staged 64x64 fp32 sub-tile (stg, EPI_LD floats per row) -> global memory
@@ -366,9 +379,14 @@ __device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigne
   }
 }
 
-template <int LAYOUT, int EPI>
+// FMT 0: bf16 operands.  FMT 1 / 2: OCP fp8 operands (A e4m3 / e5m2, B e4m3), NT only: a 128-byte tile row is
+// 128 k instead of 64, one v_mfma_f32_16x16x128_f8f6f4 replaces two 16x16x32 bf16 MFMAs in the same 32 cycles --
+// bytes staged, LDS reads and the phase schedule are identical, the contraction per K tile doubles.  The
+// addressing below counts in 2-byte units (p.K, lda, ldb = bytes / 2).
+template <int LAYOUT, int EPI, int FMT = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(FMT == 0 || LAYOUT == VDS_NT, "fp8 operands are k-contiguous (transposed copies are made by the quantiser)");
   constexpr bool A_KM = (LAYOUT == VDS_TN);
   constexpr bool B_KM = (LAYOUT != VDS_NT);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -434,33 +452,41 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
 
-  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  constexpr int KS = FMT == 0 ? 2 : 1;  // MFMA k-steps per K tile
+  using frag_t = std::conditional_t<FMT == 0, bf16x8, i32x8>;
+  frag_t fa[4][KS], fb0[2][KS], fb1[2][KS];
   auto read_a = [&](const char* slot) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if constexpr (A_KM) fa[i][ks] = frag_km(slot, wr * 64 + i * 16, ks, lane);
+      for (int ks = 0; ks < KS; ++ks) {
+        if constexpr (FMT != 0) fa[i][ks] = frag_kc8(slot, wr * 64 + i * 16, lane);
+        else if constexpr (A_KM) fa[i][ks] = frag_km(slot, wr * 64 + i * 16, ks, lane);
         else fa[i][ks] = frag_kc(slot, wr * 64 + i * 16, ks, lane);
       }
   };
-  auto read_b = [&](const char* slot, bf16x8 (&fb)[2][2]) {
+  auto read_b = [&](const char* slot, frag_t (&fb)[2][KS]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if constexpr (B_KM) fb[j][ks] = frag_km(slot, wc * 32 + j * 16, ks, lane);
+      for (int ks = 0; ks < KS; ++ks) {
+        if constexpr (FMT != 0) fb[j][ks] = frag_kc8(slot, wc * 32 + j * 16, lane);
+        else if constexpr (B_KM) fb[j][ks] = frag_km(slot, wc * 32 + j * 16, ks, lane);
         else fb[j][ks] = frag_kc(slot, wc * 32 + j * 16, ks, lane);
       }
+  };
+  auto mma = [&](const frag_t& a, const frag_t& b, f32x4 c) {
+    if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    // cbsz: format of A (0 e4m3, 1 e5m2), blgp: format of B; block scales unused (0 selects the unscaled form)
+    else return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, FMT == 2 ? 1 : 0, 0, 0, 0, 0, 0);
   };
 #define VDS_QUADRANT(QA, QB, FB)                                                                      \
   do {                                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                    \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                 \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
-          acc[(QA) * 4 + i][(QB) * 2 + j] =                                                           \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[j][ks], acc[(QA) * 4 + i][(QB) * 2 + j], 0, 0, 0); \
+          acc[(QA) * 4 + i][(QB) * 2 + j] = mma(fa[i][ks], FB[j][ks], acc[(QA) * 4 + i][(QB) * 2 + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                    \
   } while (0)
 
@@ -510,6 +536,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
 
   // ---- epilogue: two 64-row quadrant rows per wave through the wave's private staging area ----
   float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
+  float dq = 1.0f;
+  if constexpr (FMT != 0) dq = (p.sa ? *p.sa : 1.0f) * (p.sb ? *p.sb : 1.0f);
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa) {
 #pragma unroll
@@ -518,7 +546,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          stg[(i * 16 + 4 * (lane >> 4) + r) * EPI_LD + j * 16 + (lane & 15)] = acc[qa * 4 + i][j][r];
+          stg[(i * 16 + 4 * (lane >> 4) + r) * EPI_LD + j * 16 + (lane & 15)] =
+              FMT != 0 ? acc[qa * 4 + i][j][r] * dq : acc[qa * 4 + i][j][r];
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_wave_barrier();
     epilogue_64x64<EPI>(p, stg, m0 + wr * 128 + qa * 64, n0 + wc * 64, lane);
@@ -526,18 +555,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   }
 }
 
-template <int LAYOUT, int EPI>
+template <int LAYOUT, int EPI, int FMT = 0>
 int launch(const GemmP& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI, FMT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.split_k > 1 ? p.split_k : 1, 1);
-  vdsprof::Scope ps(LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : LAYOUT == VDS_NN ? VDS_PROF_GEMM_NN : VDS_PROF_GEMM_TN, s,
-                    2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
-  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI>), grid, dim3(512), LDS_BYTES, s, p);
+  const double k = FMT != 0 ? p.prof_k : (double)p.K;
+  vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : LAYOUT == VDS_NN ? VDS_PROF_GEMM_NN
+                                                                                                       : VDS_PROF_GEMM_TN,
+                    s, 2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT>), grid, dim3(512), LDS_BYTES, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 }  // namespace big
@@ -576,6 +607,8 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   // split_k < 0: |split_k| splits and atomic accumulation into C even for a single split
   p.split_k = a->split_k > 1 ? a->split_k : (a->split_k < -1 ? -a->split_k : 1);
   p.atomic = (a->split_k > 1 || a->split_k < 0) ? 1 : 0;
+  p.sa = p.sb = nullptr;
+  p.prof_k = a->K;
   p.tiles_m = cdiv(a->M, BM);
   p.tiles_n = cdiv(a->N, BN);
   size_t abytes, bbytes;
@@ -646,5 +679,47 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   GO(VDS_NN, VDS_EPI_DGELU)
   GO(VDS_TN, VDS_EPI_F32)
 #undef GO
+  return VDS_ERR_UNSUPPORTED;
+}
+
+// OCP fp8 GEMM, NT only: C[M,N] = (sum_k A[m,k] B[n,k]) * scale_a * scale_b with A, B one byte per element
+// (a_fmt / b_fmt: 0 = e4m3fn, 1 = e5m2; B must be e4m3), always on the 256^2 kernel.
+extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const float* scale_b, int32_t a_fmt,
+                            int32_t b_fmt, vds_stream_t stream) {
+  if (!a || !a->A || !a->B || a->M <= 0 || a->N <= 0 || a->K <= 0) return VDS_ERR_ARG;
+  if (a->layout != VDS_NT || b_fmt != 0 || (a_fmt != 0 && a_fmt != 1)) return VDS_ERR_UNSUPPORTED;
+  if ((a->N & 7) || (a->K & 15) || (a->lda & 15) || (a->ldb & 15)) return VDS_ERR_ARG;
+  GemmP p;
+  p.M = a->M; p.N = a->N; p.K = a->K / 2;  // the kernel addresses in 2-byte units
+  p.A = (const bf16_t*)a->A; p.lda = a->lda / 2;
+  p.B = (const bf16_t*)a->B; p.ldb = a->ldb / 2;
+  p.C = a->C; p.ldc = a->ldc; p.C2 = a->C2; p.ldc2 = a->ldc2;
+  p.bias = (const bf16_t*)a->bias;
+  p.aux = (const bf16_t*)a->aux; p.ldaux = a->ldaux;
+  p.gate = a->gate; p.ldgate = a->ldgate;
+  p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
+  p.split_k = a->split_k > 1 ? a->split_k : (a->split_k < -1 ? -a->split_k : 1);
+  p.atomic = (a->split_k > 1 || a->split_k < 0) ? 1 : 0;
+  p.sa = scale_a; p.sb = scale_b;
+  p.prof_k = a->K;
+  p.tiles_m = cdiv(a->M, 256);
+  p.tiles_n = cdiv(a->N, 256);
+  const size_t abytes = (size_t)(a->M - 1) * a->lda + a->K, bbytes = (size_t)(a->N - 1) * a->ldb + a->K;
+  if (abytes >= (1ull << 32) || bbytes >= (1ull << 32)) return VDS_ERR_UNSUPPORTED;
+  p.a_bytes = (unsigned)abytes;
+  p.b_bytes = (unsigned)bbytes;
+  p.group_m = GROUP_M;
+  if (p.atomic && a->epilogue != VDS_EPI_F32) return VDS_ERR_ARG;
+  if (!a->C && a->epilogue != VDS_EPI_GATE_RES) return VDS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+#define GOF(E, F) if (a->epilogue == E && a_fmt == F - 1) return big::launch<VDS_NT, E, F>(p, s);
+  GOF(VDS_EPI_STORE, 1)
+  GOF(VDS_EPI_BIAS_GELU, 1)
+  GOF(VDS_EPI_GATE_RES, 1)
+  GOF(VDS_EPI_STORE, 2)
+  GOF(VDS_EPI_DGELU, 2)
+  GOF(VDS_EPI_F32, 2)
+  GOF(VDS_EPI_F32, 1)
+#undef GOF
   return VDS_ERR_UNSUPPORTED;
 }

@@ -30,43 +30,60 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamT* desc, const int
   const float lr = t.lr * lr_mult;
   const float decay = 1.0f - lr * t.wd;
   const float step_size = lr / bc1;
-  for (long i = s0 + threadIdx.x * 4; i < s1; i += 256 * 4) {
-    if (i + 4 <= s1 && ((reinterpret_cast<uintptr_t>(t.p + i) & 15) == 0)) {
-      f32x4 p = *reinterpret_cast<const f32x4*>(t.p + i);
-      const f32x4 g = *reinterpret_cast<const f32x4*>(t.g + i);
-      f32x4 m = *reinterpret_cast<const f32x4*>(t.m + i);
-      f32x4 v = *reinterpret_cast<const f32x4*>(t.v + i);
+#ifndef VDS_ADAMW_U
+#define VDS_ADAMW_U 2
+#endif
+#ifdef VDS_ADAMW_NT
+#define VDS_LD(ptr) __builtin_nontemporal_load(ptr)
+#define VDS_ST(ptr, val) __builtin_nontemporal_store(val, ptr)
+#else
+#define VDS_LD(ptr) (*(ptr))
+#define VDS_ST(ptr, val) (*(ptr) = (val))
+#endif
+  constexpr int U = VDS_ADAMW_U;
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(t.p + s0) & 15) == 0 && (!t.pb || (reinterpret_cast<uintptr_t>(t.pb + s0) & 7) == 0);
+  long i = s0 + threadIdx.x * 4;
+  if (vec_ok) {
+    // U independent 16-byte vectors per thread and iteration: every load is issued before the first use
+    for (; i + (U - 1) * 1024 + 4 <= s1; i += U * 1024) {
+      f32x4 p[U], g[U], m[U], v[U];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float gg = g[e] * grad_scale;
-        p[e] *= decay;
-        m[e] = beta1 * m[e] + (1.0f - beta1) * gg;
-        v[e] = beta2 * v[e] + (1.0f - beta2) * gg * gg;
-        const float denom = sqrtf(v[e]) * rsqrt_bc2_inv + eps;
-        p[e] -= step_size * (m[e] / denom);
+      for (int u = 0; u < U; ++u) {
+        p[u] = VDS_LD(reinterpret_cast<const f32x4*>(t.p + i + u * 1024));
+        g[u] = VDS_LD(reinterpret_cast<const f32x4*>(t.g + i + u * 1024));
+        m[u] = VDS_LD(reinterpret_cast<const f32x4*>(t.m + i + u * 1024));
+        v[u] = VDS_LD(reinterpret_cast<const f32x4*>(t.v + i + u * 1024));
       }
-      *reinterpret_cast<f32x4*>(t.p + i) = p;
-      *reinterpret_cast<f32x4*>(t.m + i) = m;
-      *reinterpret_cast<f32x4*>(t.v + i) = v;
-      if (t.pb) {
-        if ((reinterpret_cast<uintptr_t>(t.pb + i) & 7) == 0) {
-          u32x2 w = {pack_bf2(p[0], p[1]), pack_bf2(p[2], p[3])};
-          *reinterpret_cast<u32x2*>(t.pb + i) = w;
-        } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) t.pb[i + e] = f2bf(p[e]);
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gg = g[u][e] * grad_scale;
+          p[u][e] *= decay;
+          m[u][e] = beta1 * m[u][e] + (1.0f - beta1) * gg;
+          v[u][e] = beta2 * v[u][e] + (1.0f - beta2) * gg * gg;
+          const float denom = sqrtf(v[u][e]) * rsqrt_bc2_inv + eps;
+          p[u][e] -= step_size * (m[u][e] / denom);
+        }
+        VDS_ST(reinterpret_cast<f32x4*>(t.p + i + u * 1024), p[u]);
+        VDS_ST(reinterpret_cast<f32x4*>(t.m + i + u * 1024), m[u]);
+        VDS_ST(reinterpret_cast<f32x4*>(t.v + i + u * 1024), v[u]);
+        if (t.pb) {
+          const u32x2 w = {pack_bf2(p[u][0], p[u][1]), pack_bf2(p[u][2], p[u][3])};
+          VDS_ST(reinterpret_cast<u32x2*>(t.pb + i + u * 1024), w);
         }
       }
-    } else {
-      for (long j = i; j < min(s1, i + 4); ++j) {
-        const float gg = t.g[j] * grad_scale;
-        float p = t.p[j] * decay;
-        const float m = beta1 * t.m[j] + (1.0f - beta1) * gg;
-        const float v = beta2 * t.v[j] + (1.0f - beta2) * gg * gg;
-        p -= step_size * (m / (sqrtf(v) * rsqrt_bc2_inv + eps));
-        t.p[j] = p; t.m[j] = m; t.v[j] = v;
-        if (t.pb) t.pb[j] = f2bf(p);
-      }
+    }
+  }
+  for (; i < s1; i += 1024) {  // tail of the chunk / unaligned tensors
+    for (long j = i; j < min(s1, i + 4); ++j) {
+      const float gg = t.g[j] * grad_scale;
+      float p = t.p[j] * decay;
+      const float m = beta1 * t.m[j] + (1.0f - beta1) * gg;
+      const float v = beta2 * t.v[j] + (1.0f - beta2) * gg * gg;
+      p -= step_size * (m / (sqrtf(v) * rsqrt_bc2_inv + eps));
+      t.p[j] = p; t.m[j] = m; t.v[j] = v;
+      if (t.pb) t.pb[j] = f2bf(p);
     }
   }
 }

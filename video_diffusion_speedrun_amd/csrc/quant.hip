@@ -1,0 +1,136 @@
+// OCP fp8 quantisation for the fp8 GEMM path (BASELINE config 5; the reference has no fp8 path, so the recipe is
+// this build's: per-tensor scaling, e4m3fn for activations / weights, e5m2 for gradients, saturating casts).
+//
+//   vds_absmax       amax = max |x| over a bf16 matrix (atomic max on the float bits; caller zeroes amax)
+//   vds_quant_fp8    q = sat(x * fmax / amax) as fp8, written row-major [M,K] and, optionally, transposed [K,M]
+//                    (the k-contiguous operand of the input- / weight-gradient products, which the fp8 GEMM runs
+//                    as NT); dequantisation factor amax / fmax written to *dq_out.
+//
+// HBM-bound: 2 B/element read, 1 (+1) B/element written.  Tile 128 x 128 per 256-thread workgroup: 16-byte
+// loads, 8-byte row-major stores, and the transposed copy through LDS with 4x4 byte transposes (v_perm_b32) so
+// that every global store instruction still writes 128 contiguous bytes per row.
+#include "common.h"
+#include "../../include/vds.h"
+
+namespace {
+
+constexpr int QT = 128;       // tile edge
+constexpr int QLD = QT + 4;   // LDS row stride in bytes (33 dwords: 2-way conflicts at most on the column reads)
+
+__device__ __forceinline__ void unpack8(const u32x4& u, float (&f)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = bflo(u[e]); f[2 * e + 1] = bfhi(u[e]); }
+}
+
+__device__ __forceinline__ float fp8_max(int fmt) { return fmt == 0 ? 448.0f : 57344.0f; }
+
+__global__ __launch_bounds__(256) void absmax_kernel(const bf16_t* x, long ldx, int M, int K, float* amax) {
+  const int kc = K >> 3;
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)M * kc; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / kc), c = (int)(i % kc);
+    float v[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + (long)r * ldx + c * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));
+}
+
+template <int FMT>
+__device__ __forceinline__ unsigned cvt4(float a, float b, float c, float d) {
+  int w = 0;
+  if constexpr (FMT == 0) {
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  } else {
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+  }
+  return (unsigned)w;
+}
+
+template <int FMT, bool TRANS>
+__global__ __launch_bounds__(256) void quant_kernel(const bf16_t* x, long ldx, int M, int K, const float* amax,
+                                                    unsigned char* q, long ldq, unsigned char* qt, long ldt,
+                                                    float* dq_out) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[TRANS ? QT * QLD : 16];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * QT, k0 = blockIdx.x * QT;
+  const float fmax = fp8_max(FMT);
+  const float am = *amax;
+  const float scale = am > 0.f ? fmax / am : 1.0f;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && dq_out) *dq_out = am > 0.f ? am / fmax : 1.0f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + 256 * it;
+    const int r = idx >> 4, c = idx & 15;
+    const int m = m0 + r, k = k0 + 8 * c;
+    u32x2 w = {0u, 0u};
+    if (m < M && k < K) {  // K is a multiple of 8: chunks are all-in or all-out
+      float v[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + (long)m * ldx + k), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * scale, -fmax), fmax);
+      w[0] = cvt4<FMT>(v[0], v[1], v[2], v[3]);
+      w[1] = cvt4<FMT>(v[4], v[5], v[6], v[7]);
+      if (q) *reinterpret_cast<u32x2*>(q + (long)m * ldq + k) = w;
+    }
+    if constexpr (TRANS) *reinterpret_cast<u32x2*>(tile + r * QLD + 8 * c) = w;
+  }
+  if constexpr (TRANS) {
+    __syncthreads();
+    const int mq = tid & 31;  // 4 consecutive m per lane: a wave's 32 lanes cover the tile's 128 m of one k row
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int kq = (tid >> 5) + 8 * it;
+      unsigned r[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const unsigned*>(tile + (4 * mq + i) * QLD + 4 * kq);
+      // 4x4 byte transpose: r[i] byte j = element (m 4mq+i, k 4kq+j)  ->  c[j] byte i
+      const unsigned t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
+      const unsigned t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+      const unsigned c[4] = {__builtin_amdgcn_perm(t2, t0, 0x05040100u), __builtin_amdgcn_perm(t2, t0, 0x07060302u),
+                             __builtin_amdgcn_perm(t3, t1, 0x05040100u), __builtin_amdgcn_perm(t3, t1, 0x07060302u)};
+      const int m = m0 + 4 * mq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 4 * kq + j;
+        if (k >= K || m >= M) continue;
+        unsigned char* dst = qt + (long)k * ldt + m;
+        if (m + 4 <= M) *reinterpret_cast<unsigned*>(dst) = c[j];
+        else
+          for (int i = 0; i < M - m; ++i) dst[i] = (unsigned char)(c[j] >> (8 * i));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vds_absmax(const void* x, int64_t ldx, int32_t M, int32_t K, float* amax, vds_stream_t stream) {
+  if (!x || !amax || M < 1 || K < 8 || (K & 7) || (ldx & 7)) return VDS_ERR_ARG;
+  const long n = (long)M * (K >> 3);
+  const int blocks = (int)min((n + 255) / 256, 4096L);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, M, K, amax);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+extern "C" int vds_quant_fp8(const void* x, int64_t ldx, int32_t M, int32_t K, int32_t fmt, const float* amax,
+                             void* q, int64_t ldq, void* qt, int64_t ldt, float* dq_out, vds_stream_t stream) {
+  if (!x || !amax || (!q && !qt) || M < 1 || K < 8 || (K & 7) || (ldx & 7) || (fmt != 0 && fmt != 1)) return VDS_ERR_ARG;
+  if ((q && (ldq & 7)) || (qt && (ldt & 3))) return VDS_ERR_ARG;
+  const dim3 grid((K + QT - 1) / QT, (M + QT - 1) / QT);
+  hipStream_t s = (hipStream_t)stream;
+#define GOQ(F, T)                                                                                                  \
+  if (fmt == F && (qt != nullptr) == T) {                                                                          \
+    hipLaunchKernelGGL((quant_kernel<F, T>), grid, dim3(256), 0, s, (const bf16_t*)x, (long)ldx, M, K, amax,      \
+                       (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, dq_out);                       \
+    return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;                                              \
+  }
+  GOQ(0, false) GOQ(0, true) GOQ(1, false) GOQ(1, true)
+#undef GOQ
+  return VDS_ERR_UNSUPPORTED;
+}

@@ -89,6 +89,43 @@ def linear_dgrad(dy, W, pre: Optional[torch.Tensor] = None):
     return dx
 
 
+# --------------------------------------------------------------------------- fp8 GEMM ----
+FP8_E4M3, FP8_E5M2 = 0, 1
+fp8_dtypes = (torch.float8_e4m3fn, torch.float8_e5m2)
+
+
+def absmax(x: torch.Tensor, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """amax[0] = max |x| of a bf16 matrix (f32 device scalar; accumulates into `amax` when given)."""
+    ld, K = _rows(x)
+    if amax is None:
+        amax = torch.zeros(1, dtype=f32, device=x.device)
+    check(_lib.load().vds_absmax(_p(x), ld, x.shape[0], K, _p(amax), _stream()), "vds_absmax")
+    return amax
+
+
+def quant_fp8(x: torch.Tensor, fmt: int, amax: torch.Tensor, rowmajor: bool = True, transposed: bool = False):
+    """bf16 [M,K] -> (q [M,K] fp8 | None, qt [K,M] fp8 | None, dq f32[1]) with per-tensor scale fmax / amax."""
+    ld, K = _rows(x)
+    M = x.shape[0]
+    assert (M % 4 == 0 or not transposed) and K % 8 == 0
+    q = torch.empty(M, K, dtype=fp8_dtypes[fmt], device=x.device) if rowmajor else None
+    qt = torch.empty(K, M, dtype=fp8_dtypes[fmt], device=x.device) if transposed else None
+    dq = torch.empty(1, dtype=f32, device=x.device)
+    check(_lib.load().vds_quant_fp8(_p(x), ld, M, K, fmt, _p(amax), _p(q), K, _p(qt), M, _p(dq), _stream()),
+          "vds_quant_fp8")
+    return q, qt, dq
+
+
+def gemm_fp8(epi: int, M: int, N: int, K: int, A, B, sa, sb, a_fmt: int, Cp=None, ldc=0, C2=None, ldc2=0, bias=None,
+             aux=None, ldaux=0, gate=None, ldgate=0, rows_per_batch=0, split_k=1):
+    """C = epilogue((A[M,K] . B[N,K]^T) * sa * sb), A / B contiguous fp8 (A e4m3 or e5m2, B e4m3)."""
+    assert A.is_contiguous() and B.is_contiguous() and A.shape == (M, K) and B.shape == (N, K)
+    a = GemmArgs(VDS_NT, epi, M, N, K, _p(A), K, _p(B), K, _p(Cp), ldc, _p(C2), ldc2, _p(bias), _p(aux), ldaux,
+                 _p(gate), ldgate, rows_per_batch, split_k)
+    check(_lib.load().vds_gemm_fp8(C.byref(a), _p(sa), _p(sb), a_fmt, 0, _stream()),
+          f"vds_gemm_fp8(epi={epi},M={M},N={N},K={K})")
+
+
 def _wgrad_split(tiles: int, kt: int, slots: int) -> int:
     """split-K factor of a weight-gradient GEMM: minimise (rounds of `slots` co-resident workgroups) x
     (K tiles per workgroup) plus the fp32-atomic traffic of the partial tiles (64 KB each at the
