@@ -46,6 +46,10 @@ WORKLOADS = {
     # BASELINE.json configs[3]
     "c4": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=1), (16, 33, 64, 64), 1,
            "C4 DiT-XL/2 bf16, latents [16,33,64,64] pt=1 -> 33792+16 tokens, ctx [512,4096]"),
+    # BASELINE.json configs[4]: the C3b shapes with the qkv / MLP GEMMs on the fp8 MFMA path (fp8.py)
+    "c5": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 6,
+           "C5 DiT-XL/2 fp8 (e4m3 activations/weights, e5m2 gradients in the qkv + MLP GEMMs; rest bf16), "
+           "latents [16,16,64,64] pt=2 -> 8192+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[0] shape, on the GPU
     "c1": (dict(hidden_size=384, depth=12, num_heads=6, time_patch_size=2), (16, 8, 16, 16), 4,
            "C1 DiT-S/2 bf16, latents [16,8,16,16] pt=2 -> 256+16 tokens, ctx [512,4096]"),
@@ -155,6 +159,8 @@ def main():
     flops = step_flops(kw, latent_shape)
 
     model = build_model(kw, device, seed=1234)  # same init on every rank
+    if args.workload == "c5":
+        model.enable_fp8()
     if world > 1:
         model = apply_fsdp(model, torch.bfloat16, torch.float32)
     elif args.force_shard_runtime:
@@ -204,7 +210,7 @@ def main():
         dominant = "attn_bwd_dkv" if (kw["hidden_size"] // kw["num_heads"]) == 72 else "attn_bwd_dkv_plain"
     names = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_delta", "attn_bwd_dkv", "attn_bwd_dq",
              "rmsnorm_mod_fwd", "rmsnorm_mod_bwd", "adamw", "qkv_rope_fwd", "qkv_rope_bwd", "gate_bwd",
-             "attn_fwd_plain", "attn_bwd_dkv_plain", "attn_bwd_dq_plain"]
+             "attn_fwd_plain", "attn_bwd_dkv_plain", "attn_bwd_dq_plain", "gemm_fp8"]
 
     # ---- timed region: exactly K steps between barrier + synchronize --------------------------
     sync()
@@ -234,7 +240,8 @@ def main():
         out = {
             "metric": "train-step samples/sec (video latents)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp8+bf16" if args.workload == "c5" else "bf16",
             "data": "synthetic (N(0,1) latents/context, random-init weights, zero-init tensors re-drawn N(0,0.02))",
             "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"fsdp{world}" if world > 1 else "single",

@@ -24,19 +24,37 @@ __device__ __forceinline__ void unpack8(const u32x4& u, float (&f)[8]) {
 
 __device__ __forceinline__ float fp8_max(int fmt) { return fmt == 0 ? 448.0f : 57344.0f; }
 
+// one 128 x 128 tile per workgroup, 8 independent 16-byte loads per thread (same indexing as quant_kernel)
 __global__ __launch_bounds__(256) void absmax_kernel(const bf16_t* x, long ldx, int M, int K, float* amax) {
-  const int kc = K >> 3;
-  float m = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)M * kc; i += (long)gridDim.x * 256) {
-    const int r = (int)(i / kc), c = (int)(i % kc);
-    float v[8];
-    unpack8(*reinterpret_cast<const u32x4*>(x + (long)r * ldx + c * 8), v);
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * QT, k0 = blockIdx.x * QT;
+  u32x4 raw[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + 256 * it;
+    const int m = m0 + (idx >> 4), k = k0 + 8 * (idx & 15);
+    raw[it] = u32x4{0u, 0u, 0u, 0u};
+    if (m < M && k < K) raw[it] = *reinterpret_cast<const u32x4*>(x + (long)m * ldx + k);
   }
+  unsigned mx = 0u;  // max over |bf16| bit patterns (monotone for non-negative floats)
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));
+  for (int it = 0; it < 8; ++it)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mx = max(mx, (raw[it][e] << 16) & 0x7fffffffu);
+      mx = max(mx, raw[it][e] & 0x7fff0000u);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+  // same-address atomics serialise (~10 ns each): one per workgroup, and only when it can raise the running max
+  __shared__ unsigned red[4];
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    mx = max(max(red[0], red[1]), max(red[2], red[3]));
+    unsigned* a = reinterpret_cast<unsigned*>(amax);
+    if (mx > __atomic_load_n(a, __ATOMIC_RELAXED)) atomicMax(a, mx);
+  }
 }
 
 template <int FMT>
@@ -112,9 +130,8 @@ __global__ __launch_bounds__(256) void quant_kernel(const bf16_t* x, long ldx, i
 
 extern "C" int vds_absmax(const void* x, int64_t ldx, int32_t M, int32_t K, float* amax, vds_stream_t stream) {
   if (!x || !amax || M < 1 || K < 8 || (K & 7) || (ldx & 7)) return VDS_ERR_ARG;
-  const long n = (long)M * (K >> 3);
-  const int blocks = (int)min((n + 255) / 256, 4096L);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, M, K, amax);
+  const dim3 grid((K + QT - 1) / QT, (M + QT - 1) / QT);
+  hipLaunchKernelGGL(absmax_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, M, K, amax);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 

@@ -1,0 +1,83 @@
+"""fp8 linears of the DiT block (BASELINE config 5: "fp8 weights + activations on CDNA4 fp8 MFMA").
+
+The reference trains in bf16 only (model.py:516-518), so the recipe is this build's own and is stated here:
+
+  * the three large token GEMMs of a block -- qkv, mlp.0 (fc1), mlp.2 (fc2), 11 of its 14 linear-layer FLOP
+    units -- run on `vds_gemm_fp8` (v_mfma_f32_16x16x128_f8f6f4, 2x the bf16 MFMA rate) in forward, input
+    gradient and weight gradient; attention, the K=N=1152 projections (whose quantisation passes would cost more
+    than the faster GEMM returns), norms, modulation, residuals, loss and the optimizer stay as in the bf16 path;
+  * OCP e4m3fn for activations and weights, e5m2 for gradients, fp32 accumulation, bf16 / fp32 outputs;
+  * per-tensor scaling, computed from the current tensor (amax pass) -- nothing is carried between steps, so a
+    step is a pure function of its inputs, like the bf16 path; saturating casts;
+  * every operand is quantised once per use site into a row-major copy and, where the backward pass contracts
+    over its other index, a transposed copy, so that all three products of a linear layer are NT GEMMs:
+        y  = x_q  W_q^T          dx = dy_q (W_q^T)^T         dW = dy_q^T^T ... = (dy^T)_q (x^T)_q^T
+  * master weights, gradients and optimizer state remain fp32; the bf16 compute copy is the quantiser's input.
+
+Parity: tests/test_fp8_gpu.py (kernels: exact against torch's float8 dtypes) and
+tests/test_model_gpu.py::test_fp8_step_close_to_oracle (whole step against the fp32 oracle, tolerance stated there).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_F32, EPI_GATE_RES, EPI_STORE
+
+bf16, f32 = torch.bfloat16, torch.float32
+E4M3, E5M2 = ops.FP8_E4M3, ops.FP8_E5M2
+
+
+class Q:
+    """a quantised matrix: row-major copy `q` [M,K], transposed copy `t` [K,M] (either may be None), factor `s`"""
+    __slots__ = ("q", "t", "s", "rows", "cols")
+
+    def __init__(self, x: torch.Tensor, fmt: int, rowmajor: bool, transposed: bool):
+        self.rows, self.cols = x.shape
+        self.q, self.t, self.s = ops.quant_fp8(x, fmt, ops.absmax(x), rowmajor, transposed)
+
+
+def supported(M: int, N: int, K: int) -> bool:
+    """alignment the fp8 GEMM needs for all three products of a [M,K] x [N,K] linear layer"""
+    return M % 16 == 0 and N % 16 == 0 and K % 16 == 0
+
+
+def fwd(xq: Q, wq: Q, out, bias=None):
+    M, K, N = xq.rows, xq.cols, wq.rows
+    ops.gemm_fp8(EPI_STORE, M, N, K, xq.q, wq.q, xq.s, wq.s, E4M3, out, out.stride(0), bias=bias)
+
+
+def fwd_gelu(xq: Q, wq: Q, bias):
+    M, K, N = xq.rows, xq.cols, wq.rows
+    pre = torch.empty(M, N, dtype=bf16, device=xq.q.device)
+    act = torch.empty(M, N, dtype=bf16, device=xq.q.device)
+    ops.gemm_fp8(EPI_BIAS_GELU, M, N, K, xq.q, wq.q, xq.s, wq.s, E4M3, pre, N, act, N, bias=bias)
+    return pre, act
+
+
+def fwd_gate_res(xq: Q, wq: Q, bias, mod, gate_col: int, res, rows_per_batch: int):
+    M, K, N = xq.rows, xq.cols, wq.rows
+    y = torch.empty(M, N, dtype=bf16, device=xq.q.device)
+    xn = torch.empty(M, N, dtype=bf16, device=xq.q.device)
+    ops.gemm_fp8(EPI_GATE_RES, M, N, K, xq.q, wq.q, xq.s, wq.s, E4M3, y, N, xn, N, bias=bias, aux=res,
+                 ldaux=res.stride(0), gate=mod[:, gate_col:], ldgate=mod.stride(0), rows_per_batch=rows_per_batch)
+    return y, xn
+
+
+def dgrad(dyq: Q, wq: Q, pre=None):
+    """dx [M,K] = dy [M,N] W [N,K] as dy_q . (W^T)_q^T; with `pre`: times gelu'(pre)"""
+    M, N, K = dyq.rows, dyq.cols, wq.cols
+    dx = torch.empty(M, K, dtype=bf16, device=dyq.q.device)
+    if pre is None:
+        ops.gemm_fp8(EPI_STORE, M, K, N, dyq.q, wq.t, dyq.s, wq.s, E5M2, dx, K)
+    else:
+        ops.gemm_fp8(EPI_DGELU, M, K, N, dyq.q, wq.t, dyq.s, wq.s, E5M2, dx, K, aux=pre, ldaux=pre.stride(0))
+    return dx
+
+
+def wgrad(dyq: Q, xq: Q, dW: torch.Tensor, n_cu: int = 256):
+    """dW [N,K] (f32, accumulated atomically: pre-zeroed by the model) = dy^T x as (dy^T)_q . (x^T)_q^T"""
+    M, N, K = dyq.rows, dyq.cols, xq.cols
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    split = ops._wgrad_split(tiles, (M + 127) // 128, n_cu)
+    ops.gemm_fp8(EPI_F32, N, K, M, dyq.t, xq.t, dyq.s, xq.s, E5M2, dW, K, split_k=-split)

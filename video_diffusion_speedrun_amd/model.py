@@ -30,6 +30,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import nn
 
+from . import fp8 as F8
 from . import ops
 from .params import FlatGroup
 
@@ -204,6 +205,13 @@ class DiT(nn.Module):
         self._groups: Optional[List[FlatGroup]] = None
         self._world, self._rank, self._pg = 1, 0, None
         self._fsdp = None  # set by fsdp.apply_fsdp
+        self.fp8 = False   # enable_fp8(): qkv / mlp GEMMs on the fp8 MFMA path (fp8.py; BASELINE config 5)
+
+    def enable_fp8(self, on: bool = True):
+        """Run the qkv and MLP linears of every block in OCP fp8 (e4m3 activations / weights, e5m2 gradients,
+        per-tensor current scaling; fp8.py states the recipe).  The reference has no such mode."""
+        self.fp8 = bool(on)
+        return self
 
     # --------------------------------------------------------------------- parameters ----
     def _group_members(self):
@@ -358,7 +366,16 @@ class DiT(nn.Module):
         mod = ops.small_linear_fwd(cvec, W("adaLN_modulation.1.weight"), W("adaLN_modulation.1.bias"), 1)
         # --- self attention (model.py:122-139)
         xn1, rstd1 = ops.rmsnorm_mod_fwd(X, Wo("norm1.weight"), mod, 0, D, B, L)
-        qkv = ops.linear_fwd(xn1, W("qkv.weight"), Wo("qkv.bias"))
+        f8 = self.fp8 and F8.supported(B * L, 3 * D, D)
+        if self.fp8 and not f8:
+            raise ValueError(f"fp8 linears need B*L ({B * L}) and hidden size ({D}) to be multiples of 16")
+        if f8:
+            q_xn1 = F8.Q(xn1, F8.E4M3, True, save)
+            q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save)
+            qkv = torch.empty(B * L, 3 * D, dtype=bf16, device=dev)
+            F8.fwd(q_xn1, q_wqkv, qkv, Wo("qkv.bias"))
+        else:
+            qkv = ops.linear_fwd(xn1, W("qkv.weight"), Wo("qkv.bias"))
         mix = self.residual_v and v0 is not None
         q, k, v = ops.qkv_rope_fwd(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None, B, L, H,
                                    hd, hdp)
@@ -382,8 +399,16 @@ class DiT(nn.Module):
             X2 = X1
         # --- MLP (model.py:163-165)
         xn3, rstd3 = ops.rmsnorm_mod_fwd(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L)
-        hpre, hact = ops.linear_fwd_gelu(xn3, W("mlp.0.weight"), W("mlp.0.bias"))
-        y_mlp, X3 = ops.linear_fwd_gate_res(hact, W("mlp.2.weight"), W("mlp.2.bias"), mod, 8 * D, X2, L)
+        if f8:
+            q_xn3 = F8.Q(xn3, F8.E4M3, True, save)
+            q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save)
+            hpre, hact = F8.fwd_gelu(q_xn3, q_w1, W("mlp.0.bias"))
+            q_hact = F8.Q(hact, F8.E4M3, True, save)
+            q_w2 = F8.Q(W("mlp.2.weight"), F8.E4M3, True, save)
+            y_mlp, X3 = F8.fwd_gate_res(q_hact, q_w2, W("mlp.2.bias"), mod, 8 * D, X2, L)
+        else:
+            hpre, hact = ops.linear_fwd_gelu(xn3, W("mlp.0.weight"), W("mlp.0.bias"))
+            y_mlp, X3 = ops.linear_fwd_gate_res(hact, W("mlp.2.weight"), W("mlp.2.bias"), mod, 8 * D, X2, L)
         bs = None
         if save:
             bs = _Saved()
@@ -393,6 +418,10 @@ class DiT(nn.Module):
             if has_cross:
                 bs.xn2, bs.rstd2, bs.qc, bs.ckv, bs.catt, bs.lse2, bs.y_ca = xn2, rstd2, qc, ckv, catt, lse2, y_ca
             bs.xn3, bs.rstd3, bs.hpre, bs.hact, bs.y_mlp = xn3, rstd3, hpre, hact, y_mlp
+            bs.f8 = f8
+            if f8:  # the backward contracts the fp8 copies: the bf16 GEMM inputs need not be kept
+                bs.q_xn1, bs.q_wqkv, bs.q_xn3, bs.q_w1, bs.q_hact, bs.q_w2 = q_xn1, q_wqkv, q_xn3, q_w1, q_hact, q_w2
+                bs.xn1 = bs.xn3 = bs.hact = None
         return X3, v, bs
 
     # ----------------------------------------------------------------------- backward ----
@@ -468,11 +497,21 @@ class DiT(nn.Module):
         dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
         # --- MLP
         dy = ops.gate_bwd(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L)
-        ops.linear_wgrad(dy, bs.hact, Gr("mlp.2.weight"))
-        dh = ops.linear_dgrad(dy, W("mlp.2.weight"), pre=bs.hpre)
-        ops.linear_wgrad(dh, bs.xn3, Gr("mlp.0.weight"))
-        ops.colsum(dh, Gr("mlp.0.bias"))
-        dxn = ops.linear_dgrad(dh, W("mlp.0.weight"))
+        if bs.f8:
+            q_dy = F8.Q(dy, F8.E5M2, True, True)
+            F8.wgrad(q_dy, bs.q_hact, Gr("mlp.2.weight"))
+            dh = F8.dgrad(q_dy, bs.q_w2, pre=bs.hpre)
+            q_dh = F8.Q(dh, F8.E5M2, True, True)
+            F8.wgrad(q_dh, bs.q_xn3, Gr("mlp.0.weight"))
+            ops.colsum(dh, Gr("mlp.0.bias"))
+            dxn = F8.dgrad(q_dh, bs.q_w1)
+            del q_dy, q_dh
+        else:
+            ops.linear_wgrad(dy, bs.hact, Gr("mlp.2.weight"))
+            dh = ops.linear_dgrad(dy, W("mlp.2.weight"), pre=bs.hpre)
+            ops.linear_wgrad(dh, bs.xn3, Gr("mlp.0.weight"))
+            ops.colsum(dh, Gr("mlp.0.bias"))
+            dxn = ops.linear_dgrad(dh, W("mlp.0.weight"))
         del dh
         dX2 = ops.rmsnorm_mod_bwd(dxn, bs.X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, bs.rstd3, dX, dmod,
                                   Go("norm3.weight"), B, L)
@@ -515,10 +554,16 @@ class DiT(nn.Module):
                                 W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),
                                 Gr("lambda_param") if bs.mix else None, bs.mix,
                                 first and dv0 is not None, B, L, H, hd, hdp)
-        ops.linear_wgrad(dqkv, bs.xn1, Gr("qkv.weight"))
         if G.has(pre + "qkv.bias"):
             ops.colsum(dqkv, Gr("qkv.bias"))
-        dxn = ops.linear_dgrad(dqkv, W("qkv.weight"))
+        if bs.f8:
+            q_dqkv = F8.Q(dqkv, F8.E5M2, True, True)
+            F8.wgrad(q_dqkv, bs.q_xn1, Gr("qkv.weight"))
+            dxn = F8.dgrad(q_dqkv, bs.q_wqkv)
+            del q_dqkv
+        else:
+            ops.linear_wgrad(dqkv, bs.xn1, Gr("qkv.weight"))
+            dxn = ops.linear_dgrad(dqkv, W("qkv.weight"))
         dX0 = ops.rmsnorm_mod_bwd(dxn, bs.X, Wo("norm1.weight"), mod, 0, D, bs.rstd1, dX1, dmod, Go("norm1.weight"),
                                   B, L)
         # --- adaLN modulation (model.py:89-94,107)
