@@ -74,18 +74,36 @@ int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);
  * bf16): layout VDS_NT only, A[M,K] and B[N,K] one byte per element (a_fmt / b_fmt: 0 = e4m3fn, 1 = e5m2; B must
  * be e4m3fn), K, lda, ldb multiples of 16.  C = epilogue((sum_k A B) * *scale_a * *scale_b) with per-tensor
  * dequantisation factors read from device memory (NULL = 1).  Runs v_mfma_f32_16x16x128_f8f6f4 (2x the bf16
- * MFMA rate).  Input / weight gradients are NT products of the transposed copies written by vds_quant_fp8. */
+ * MFMA rate).  Input / weight gradients are NT products of the transposed copies written by vds_quant_fp8.
+ *
+ * emit (may be NULL; VDS_EPI_BIAS_GELU / VDS_EPI_DGELU only): the epilogue also writes its result -- gelu(pre) resp.
+ * acc * gelu'(aux), rounded to bf16 first -- as fp8 for the next GEMMs, so that no separate quantisation pass reads
+ * it back: q[M,N] row-major and / or qt[N,M] transposed, scaled by fmax / *amax_in (delayed scaling: the caller
+ * passes the amax recorded by the previous step), *dq_out = *amax_in / fmax, *amax_out = max(*amax_out, max |result|)
+ * of this launch, colsum[n] += sum_m result[m,n] (bias gradient).  With emit, C2 (BIAS_GELU) / C (DGELU) may be NULL. */
+typedef struct vds_fp8_out {
+  void* q; int64_t ldq;
+  void* qt; int64_t ldqt;
+  const float* amax_in;
+  float* amax_out;
+  float* dq_out;
+  int32_t fmt;      /* 0 = e4m3fn, 1 = e5m2 */
+  float* colsum;    /* f32 [N] or NULL */
+} vds_fp8_out;
+
 int vds_gemm_fp8(const vds_gemm_args* args, const float* scale_a, const float* scale_b, int32_t a_fmt,
-                 int32_t b_fmt, vds_stream_t stream);
+                 int32_t b_fmt, const vds_fp8_out* emit, vds_stream_t stream);
 
 /* amax[0] = max(amax[0], max |x|) over a bf16 matrix x[M,K] (row stride ldx elements); the caller zeroes amax. */
 int vds_absmax(const void* x, int64_t ldx, int32_t M, int32_t K, float* amax, vds_stream_t stream);
 
 /* Per-tensor fp8 quantisation of a bf16 matrix: q[m,k] = sat(x[m,k] * fmax / *amax) (fmt 0: e4m3fn, fmax 448;
  * fmt 1: e5m2, fmax 57344), written row-major to q[M,K] (ldq, may be NULL) and / or transposed to qt[K,M] (ldt,
- * may be NULL); *dq_out = *amax / fmax is the factor vds_gemm_fp8 multiplies back in.  *amax == 0 -> scale 1. */
+ * may be NULL); *dq_out = *amax / fmax is the factor vds_gemm_fp8 multiplies back in.  *amax == 0 -> scale 1.
+ * amax_out (may be NULL): *amax_out = max(*amax_out, max |x|) -- with delayed scaling `amax` is the value a previous
+ * step recorded and this call records the next one, so that no separate vds_absmax pass reads x. */
 int vds_quant_fp8(const void* x, int64_t ldx, int32_t M, int32_t K, int32_t fmt, const float* amax, void* q,
-                  int64_t ldq, void* qt, int64_t ldt, float* dq_out, vds_stream_t stream);
+                  int64_t ldq, void* qt, int64_t ldt, float* dq_out, float* amax_out, vds_stream_t stream);
 
 /* --------------------------------------------------------------- attention (MFMA) ----
  * F.scaled_dot_product_attention(q,k,v) full/non-causal (model.py:136,157), flash style.

@@ -35,6 +35,12 @@ def test_quant_matches_torch_float8(ops, fmt, M, K):
     assert torch.equal(q.cpu().view(torch.uint8), want.view(torch.uint8))
     assert torch.equal(qt.cpu().view(torch.uint8), want.view(torch.uint8).t().contiguous())
     assert abs(dq.item() - amax.item() / fmax) <= 1e-7 * dq.item()
+    # delayed scaling: quantise with a given (older) amax while recording the current one in the same pass
+    rec = torch.zeros(1, device="cuda")
+    old = amax * 0.75
+    q3, _, _ = ops.quant_fp8(x.cuda(), fmt, old, amax_out=rec)
+    want3 = (x.float() * (torch.tensor(fmax, dtype=f32) / old.cpu())).clamp(-fmax, fmax).to(ops.fp8_dtypes[fmt])
+    assert torch.equal(q3.cpu().view(torch.uint8), want3.view(torch.uint8)) and rec.item() == amax.item()
     # strided source (a column block of a wider matrix), transposed copy only
     wide = gen(M, K + 64, seed=7, scale=2.0).cuda()
     am2 = ops.absmax(wide[:, 8:8 + K])
@@ -93,3 +99,41 @@ def test_linear_fp8_close_to_bf16_linear(ops):
     ref_q = (xq.cpu().float() * sx.cpu()) @ (Wq.cpu().float() * sw.cpu()).t()
     err_q = ((y.cpu().float() - ref_q).norm() / ref_q.norm()).item()
     assert err_q <= 3e-3, err_q
+
+
+@pytest.mark.parametrize("M,N,K", [(304, 264, 144), (1024, 4608, 1152)])
+def test_gemm_epilogue_emits_fp8_copies(ops, M, N, K):
+    """vds_fp8_out: the fc1 epilogue (bias + GELU) and the fc2-dgrad epilogue (gelu') write their result as fp8
+    row-major + transposed, record its amax and (dgrad) its column sums -- bit-identical to quantising the bf16
+    result in a separate pass with the same scale."""
+    from video_diffusion_speedrun_amd import fp8 as F8
+    x, W, b = gen(M, K, seed=11), gen(N, K, seed=12, scale=0.05), gen(N, seed=13, scale=0.1)
+    xq, wq = F8.Q(x.cuda(), 0, True, True), F8.Q(W.cuda(), 0, True, True)
+    pre, act = F8.fwd_gelu(xq, wq, b.cuda())
+    amax = ops.absmax(act)
+    rec = torch.zeros(1, device="cuda")
+    pre2, qa = F8.fwd_gelu_emit(xq, wq, b.cuda(), amax, rec, True)
+    q_ref, qt_ref, s_ref = ops.quant_fp8(act, 0, amax, True, True)
+    assert torch.equal(pre2, pre)
+    assert torch.equal(qa.q.view(torch.uint8), q_ref.view(torch.uint8))
+    assert torch.equal(qa.t.view(torch.uint8), qt_ref.view(torch.uint8))
+    assert qa.s.item() == s_ref.item() and rec.item() == amax.item()
+    # a stale (smaller) amax saturates instead of overflowing
+    half = amax * 0.5
+    _, qs = F8.fwd_gelu_emit(xq, wq, b.cuda(), half, rec, False)
+    assert qs.t is None and qs.q.float().abs().max().item() == 448.0 and torch.isfinite(qs.q.float()).all()
+    # backward of the following linear: dh = (dy W2) * gelu'(pre), dy [M, N2], W2 [N2, N]
+    N2 = 144
+    dy, W2 = gen(M, N2, seed=14), gen(N2, N, seed=15, scale=0.05)
+    dyq, w2q = F8.Q(dy.cuda(), 1, True, True), F8.Q(W2.cuda(), 0, True, True)
+    dh = F8.dgrad(dyq, w2q, pre=pre)
+    amax_dh = ops.absmax(dh)
+    rec.zero_()
+    cs = torch.zeros(N, device="cuda")
+    qd = F8.dgrad_gelu_emit(dyq, w2q, pre, amax_dh, rec, cs)
+    q_ref, qt_ref, s_ref = ops.quant_fp8(dh, 1, amax_dh, True, True)
+    assert torch.equal(qd.q.view(torch.uint8), q_ref.view(torch.uint8))
+    assert torch.equal(qd.t.view(torch.uint8), qt_ref.view(torch.uint8))
+    assert qd.s.item() == s_ref.item() and rec.item() == amax_dh.item()
+    want = dh.float().sum(0)
+    assert ((cs - want).abs().max() / want.abs().max()).item() <= 1e-5

@@ -52,3 +52,26 @@ for name, N, K in (("qkv", 3 * D, D), ("proj", D, D), ("fc1", 4 * D, D), ("fc2",
     tq = timeit(lambda: ops.quant_fp8(x, 0, sx, True, True))
     ta = timeit(lambda: ops.absmax(x))
     print(f"quant+T {name:5s} [{M},{K}]: {tq*1e6:7.1f} us {4*M*K/tq/1e9:7.0f} GB/s ; absmax {ta*1e6:7.1f} us {2*M*K/ta/1e9:7.0f} GB/s")
+
+# fused fp8 emission from the fc1 / fc2-dgrad epilogues
+from video_diffusion_speedrun_amd import fp8 as F8
+x, w1, b1 = rnd(M, D), rnd(4 * D, D, scale=0.03), rnd(4 * D, scale=0.1)
+xq, w1q = F8.Q(x, 0, True, True), F8.Q(w1, 0, True, True)
+pre, act = F8.fwd_gelu(xq, w1q, b1)
+amax = ops.absmax(act)
+rec = torch.zeros(1, device=dev)
+t0 = timeit(lambda: F8.fwd_gelu(xq, w1q, b1))
+t1 = timeit(lambda: F8.fwd_gelu_emit(xq, w1q, b1, amax, rec, False))
+t2 = timeit(lambda: F8.fwd_gelu_emit(xq, w1q, b1, amax, rec, True))
+t3 = timeit(lambda: F8.Q(act, 0, True, True))
+print(f"fc1 fwd: plain {t0*1e6:.0f} us | emit q {t1*1e6:.0f} us | emit q+T {t2*1e6:.0f} us | separate absmax+quant {t3*1e6:.0f} us")
+dy, w2 = rnd(M, D), rnd(D, 4 * D, scale=0.03)
+dyq, w2q = F8.Q(dy, 1, True, True), F8.Q(w2, 0, True, True)
+dh = F8.dgrad(dyq, w2q, pre=pre)
+amax = ops.absmax(dh)
+cs = torch.zeros(4 * D, device=dev)
+t0 = timeit(lambda: F8.dgrad(dyq, w2q, pre=pre))
+t1 = timeit(lambda: F8.dgrad_gelu_emit(dyq, w2q, pre, amax, rec, None))
+t2 = timeit(lambda: F8.dgrad_gelu_emit(dyq, w2q, pre, amax, rec, cs))
+t3 = timeit(lambda: ops.colsum(dh, cs))
+print(f"fc2 dgrad: plain {t0*1e6:.0f} us | emit q+T {t1*1e6:.0f} us | emit q+T+colsum {t2*1e6:.0f} us | separate colsum {t3*1e6:.0f} us")

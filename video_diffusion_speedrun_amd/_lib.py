@@ -38,6 +38,12 @@ class AttnArgs(C.Structure):
                 ("delta", c_vp), ("kv_pad_ones", c_i32)]
 
 
+class Fp8Out(C.Structure):  # vds_fp8_out
+    _fields_ = [("q", C.c_void_p), ("ldq", C.c_int64), ("qt", C.c_void_p), ("ldqt", C.c_int64),
+                ("amax_in", C.c_void_p), ("amax_out", C.c_void_p), ("dq_out", C.c_void_p), ("fmt", C.c_int32),
+                ("colsum", C.c_void_p)]
+
+
 class ProfStat(C.Structure):
     _fields_ = [("launches", c_i64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
@@ -85,9 +91,9 @@ SIGNATURES = {
     "vds_adamw_multi_dev": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_f32, c_vp],
     "vds_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
     "vds_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
-    "vds_gemm_fp8": [C.POINTER(GemmArgs), c_vp, c_vp, c_i32, c_i32, c_vp],
+    "vds_gemm_fp8": [C.POINTER(GemmArgs), c_vp, c_vp, c_i32, c_i32, c_vp, c_vp],
     "vds_absmax": [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
-    "vds_quant_fp8": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "vds_quant_fp8": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp],
     "vds_selftest_lanemaps": [c_vp, c_vp],
     "vds_prof_enable": [C.c_uint32],
     "vds_prof_collect": [c_vp],

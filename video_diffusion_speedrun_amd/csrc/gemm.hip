@@ -48,6 +48,9 @@ struct GemmP {
   int group_m;
   const float* sa; const float* sb;  // fp8 path: per-tensor dequantisation factors (device), else unused
   double prof_k;                      // contraction length in elements (profiler flop count)
+  // fp8 path, optional: the epilogue also emits its result (gelu output / gelu' product) as fp8 (vds_fp8_out)
+  unsigned char* e_q; long e_ldq; unsigned char* e_qt; long e_ldqt;
+  const float* e_amax_in; float* e_amax_out; float* e_dq_out; int e_fmt; float* e_colsum;
 };
 
 // ---- swizzles -------------------------------------------------------------------------
@@ -127,8 +130,26 @@ __device__ __forceinline__ i32x8 frag_kc8(const char* tile, int row0, int lane) 
 
 // Shared epilogue: a wave's staged 64x64 fp32 sub-tile (stg, EPI_LD floats per row) -> global memory
 // with the fused elementwise work.  (row0, col0) = global coordinates of the sub-tile.
-template <int EPI>
-__device__ __forceinline__ void epilogue_64x64(const GemmP& p, const float* stg, int row0, int col0, int lane) {
+__device__ __forceinline__ unsigned cvt4_fp8(int fmt, float a, float b, float c, float d) {
+  int w = 0;
+  if (fmt == 0) {
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  } else {
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+  }
+  return (unsigned)w;
+}
+
+// EMIT (fp8 path, BIAS_GELU / DGELU): the bf16-rounded result is additionally written as fp8, row-major and / or
+// transposed, scaled by fmax / *e_amax_in (delayed scaling: the amax of the previous step), its current amax is
+// recorded, and (DGELU) its column sums are accumulated -- the consumers' quantisation and bias-gradient passes
+// disappear.  The fp8 bytes of the tile are also returned in `ew` (row it*8 + lane/8, columns 8*(lane%8)..+7) for
+// the caller's transposed copy.
+template <int EPI, bool EMIT = false>
+__device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int row0, int col0, int lane,
+                                               float (&cs)[8], u32x2 (&ew)[8]) {
   if constexpr (EPI == VDS_EPI_F32) {
     if (p.atomic) {
       // split-K / accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256
@@ -144,12 +165,23 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, const float* stg,
   }
   const int c8 = lane & 7, rin = lane >> 3;
   const int gcol = col0 + c8 * 8;
-  if (gcol >= p.N) return;
+  if constexpr (!EMIT) {
+    if (gcol >= p.N) return;
+  }
+  const bool col_ok = gcol < p.N;
+  [[maybe_unused]] float e_max = 0.f, e_scale = 1.f, e_fmax = 448.f;
+  [[maybe_unused]] const bool emit = EMIT && (p.e_q || p.e_qt);
+  if constexpr (EMIT) {
+    e_fmax = p.e_fmt == 0 ? 448.0f : 57344.0f;
+    const float ain = (emit && p.e_amax_in) ? *p.e_amax_in : 0.f;
+    e_scale = ain > 0.f ? e_fmax / ain : 1.0f;
+    if (emit && p.e_dq_out && row0 == 0 && col0 == 0 && lane == 0) *p.e_dq_out = ain > 0.f ? ain / e_fmax : 1.0f;
+  }
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
   if constexpr (EPI != VDS_EPI_F32 && EPI != VDS_EPI_DGELU) {
-    if (p.bias) {
+    if (p.bias && col_ok) {
       u32x4 bv = *reinterpret_cast<const u32x4*>(p.bias + gcol);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bias8[2 * e] = bflo(bv[e]); bias8[2 * e + 1] = bfhi(bv[e]); }
@@ -159,7 +191,9 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, const float* stg,
   for (int it = 0; it < 8; ++it) {
     const int row = it * 8 + rin;
     const long grow = row0 + row;
-    if (grow >= p.M) continue;
+    if constexpr (EMIT) ew[it] = u32x2{0u, 0u};
+    if (grow >= p.M || !col_ok) continue;
+    [[maybe_unused]] u32x4 ev;  // bf16 pairs of the emitted result
     const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + c8 * 8);
     const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + c8 * 8 + 4);
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -181,7 +215,8 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, const float* stg,
         o2[e] = pack_bf2(gelu_f(a), gelu_f(b));
       }
       *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + grow * p.ldc2 + gcol) = o2;
+      if (p.C2) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + grow * p.ldc2 + gcol) = o2;
+      if constexpr (EMIT) ev = o2;
     } else if constexpr (EPI == VDS_EPI_GATE_RES) {
       const int b = (int)(grow / p.rows_per_batch);
       const float* gp = p.gate + (long)b * p.ldgate + gcol;
@@ -204,7 +239,36 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, const float* stg,
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         o[e] = pack_bf2(v[2 * e] * dgelu_f(bflo(pr[e])), v[2 * e + 1] * dgelu_f(bfhi(pr[e])));
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
+      if (p.C) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
+      if constexpr (EMIT) ev = o;
+    }
+    if constexpr (EMIT) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f[2 * e] = bflo(ev[e]); f[2 * e + 1] = bfhi(ev[e]); }
+      if (p.e_colsum)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += f[e];
+      if (emit) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          e_max = fmaxf(e_max, fabsf(f[e]));
+          f[e] = fminf(fmaxf(f[e] * e_scale, -e_fmax), e_fmax);
+        }
+        const u32x2 w = {cvt4_fp8(p.e_fmt, f[0], f[1], f[2], f[3]), cvt4_fp8(p.e_fmt, f[4], f[5], f[6], f[7])};
+        ew[it] = w;
+        if (p.e_q) *reinterpret_cast<u32x2*>(p.e_q + grow * p.e_ldq + gcol) = w;
+      }
+    }
+  }
+  if constexpr (EMIT) {
+    if (emit) {
+      if (p.e_amax_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e_max = fmaxf(e_max, __shfl_xor(e_max, o));
+        unsigned* a = reinterpret_cast<unsigned*>(p.e_amax_out);
+        if (lane == 0 && __float_as_uint(e_max) > __atomic_load_n(a, __ATOMIC_RELAXED)) atomicMax(a, __float_as_uint(e_max));
+      }
     }
   }
 }
@@ -308,7 +372,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own wave's region only, no barrier needed
   __builtin_amdgcn_wave_barrier();
 
-  epilogue_64x64<EPI>(p, stg, m0 + wm * 64, n0 + wn * 64, lane);
+  float cs_unused[8];
+  u32x2 ew_unused[8];
+  epilogue_64x64<EPI>(p, stg, m0 + wm * 64, n0 + wn * 64, lane, cs_unused, ew_unused);
 }
 
 // =====================================================================================
@@ -538,6 +604,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
   float dq = 1.0f;
   if constexpr (FMT != 0) dq = (p.sa ? *p.sa : 1.0f) * (p.sb ? *p.sb : 1.0f);
+  constexpr bool EMIT = FMT != 0 && (EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU);
+  float cs[8];  // EMIT: per-lane partial column sums of the emitted result over both quadrant rows
+  u32x2 ew[2][8];  // EMIT: the fp8 bytes of both quadrant rows (for the transposed copy)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa) {
 #pragma unroll
@@ -550,8 +621,69 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
               FMT != 0 ? acc[qa * 4 + i][j][r] * dq : acc[qa * 4 + i][j][r];
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_wave_barrier();
-    epilogue_64x64<EPI>(p, stg, m0 + wr * 128 + qa * 64, n0 + wc * 64, lane);
+    epilogue_64x64<EPI, EMIT>(p, stg, m0 + wr * 128 + qa * 64, n0 + wc * 64, lane, cs, ew[qa]);
     __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
+  }
+  if constexpr (EMIT) {
+    if (p.e_qt) {
+      // transposed fp8 copy of the wave's 128 x 64 outputs: the staging area (fp32 tiles consumed) becomes a
+      // [128 m][64 k] byte tile (72-byte rows), read back as 4x4 byte blocks, transposed in registers (v_perm_b32)
+      // and stored as 128 contiguous bytes per k row and instruction
+      constexpr int TLD = 72;
+      unsigned char* bt = reinterpret_cast<unsigned char*>(stg);
+      const int c8 = lane & 7, rin = lane >> 3;
+#pragma unroll
+      for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x2*>(bt + (qa * 64 + it * 8 + rin) * TLD + c8 * 8) = ew[qa][it];
+      VDS_WAIT_LGKM0();
+      __builtin_amdgcn_wave_barrier();
+      const int mq = lane & 31;
+      const long m = m0 + wr * 128 + 4 * mq;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int kq = (lane >> 5) + 2 * it;
+        unsigned r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const unsigned*>(bt + (4 * mq + i) * TLD + 4 * kq);
+        const unsigned t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
+        const unsigned t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+        const unsigned c[4] = {__builtin_amdgcn_perm(t2, t0, 0x05040100u), __builtin_amdgcn_perm(t2, t0, 0x07060302u),
+                               __builtin_amdgcn_perm(t3, t1, 0x05040100u), __builtin_amdgcn_perm(t3, t1, 0x07060302u)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = n0 + wc * 64 + 4 * kq + j;
+          if (col >= p.N || m >= p.M) continue;
+          unsigned char* dst = p.e_qt + (long)col * p.e_ldqt + m;
+          if (m + 4 <= p.M) *reinterpret_cast<unsigned*>(dst) = c[j];
+          else
+            for (int i = 0; i < (int)(p.M - m); ++i) dst[i] = (unsigned char)(c[j] >> (8 * i));
+        }
+      }
+      VDS_WAIT_LGKM0();
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (p.e_colsum) {
+      // column sums of the workgroup's 256 rows: lanes sharing a column chunk differ in lane bits 3..5, the two
+      // wave rows meet through LDS -> one atomic per column and workgroup
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        cs[e] += __shfl_xor(cs[e], 8);
+        cs[e] += __shfl_xor(cs[e], 16);
+        cs[e] += __shfl_xor(cs[e], 32);
+      }
+      if (wr == 1 && lane < 8)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) stg[lane * 8 + e] = cs[e];
+      __syncthreads();
+      if (wr == 0 && lane < 8) {
+        const float* other = reinterpret_cast<const float*>(smem) + (wave + 4) * 64 * EPI_LD;
+        const int gcol = n0 + wc * 64 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (gcol + e < p.N) atomicAdd(p.e_colsum + gcol + e, cs[e] + other[lane * 8 + e]);
+      }
+    }
   }
 }
 
@@ -609,6 +741,8 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   p.atomic = (a->split_k > 1 || a->split_k < 0) ? 1 : 0;
   p.sa = p.sb = nullptr;
   p.prof_k = a->K;
+  p.e_q = p.e_qt = nullptr; p.e_ldq = p.e_ldqt = 0;
+  p.e_amax_in = nullptr; p.e_amax_out = p.e_dq_out = p.e_colsum = nullptr; p.e_fmt = 0;
   p.tiles_m = cdiv(a->M, BM);
   p.tiles_n = cdiv(a->N, BN);
   size_t abytes, bbytes;
@@ -685,7 +819,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
 // OCP fp8 GEMM, NT only: C[M,N] = (sum_k A[m,k] B[n,k]) * scale_a * scale_b with A, B one byte per element
 // (a_fmt / b_fmt: 0 = e4m3fn, 1 = e5m2; B must be e4m3), always on the 256^2 kernel.
 extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const float* scale_b, int32_t a_fmt,
-                            int32_t b_fmt, vds_stream_t stream) {
+                            int32_t b_fmt, const vds_fp8_out* emit, vds_stream_t stream) {
   if (!a || !a->A || !a->B || a->M <= 0 || a->N <= 0 || a->K <= 0) return VDS_ERR_ARG;
   if (a->layout != VDS_NT || b_fmt != 0 || (a_fmt != 0 && a_fmt != 1)) return VDS_ERR_UNSUPPORTED;
   if ((a->N & 7) || (a->K & 15) || (a->lda & 15) || (a->ldb & 15)) return VDS_ERR_ARG;
@@ -709,8 +843,19 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   p.a_bytes = (unsigned)abytes;
   p.b_bytes = (unsigned)bbytes;
   p.group_m = GROUP_M;
+  p.e_q = p.e_qt = nullptr; p.e_ldq = p.e_ldqt = 0;
+  p.e_amax_in = nullptr; p.e_amax_out = p.e_dq_out = p.e_colsum = nullptr; p.e_fmt = 0;
+  if (emit) {
+    if (a->epilogue != VDS_EPI_BIAS_GELU && a->epilogue != VDS_EPI_DGELU) return VDS_ERR_ARG;
+    if ((emit->q && (emit->ldq & 7)) || (emit->qt && (emit->ldqt & 3)) || (emit->fmt != 0 && emit->fmt != 1)) return VDS_ERR_ARG;
+    if ((emit->q || emit->qt) && !emit->amax_in) return VDS_ERR_ARG;
+    p.e_q = (unsigned char*)emit->q; p.e_ldq = emit->ldq;
+    p.e_qt = (unsigned char*)emit->qt; p.e_ldqt = emit->ldqt;
+    p.e_amax_in = emit->amax_in; p.e_amax_out = emit->amax_out; p.e_dq_out = emit->dq_out;
+    p.e_fmt = emit->fmt; p.e_colsum = emit->colsum;
+  }
   if (p.atomic && a->epilogue != VDS_EPI_F32) return VDS_ERR_ARG;
-  if (!a->C && a->epilogue != VDS_EPI_GATE_RES) return VDS_ERR_ARG;
+  if (!a->C && a->epilogue != VDS_EPI_GATE_RES && !(emit && a->epilogue == VDS_EPI_DGELU)) return VDS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
 #define GOF(E, F) if (a->epilogue == E && a_fmt == F - 1) return big::launch<VDS_NT, E, F>(p, s);
   GOF(VDS_EPI_STORE, 1)

@@ -73,8 +73,10 @@ __device__ __forceinline__ unsigned cvt4(float a, float b, float c, float d) {
 template <int FMT, bool TRANS>
 __global__ __launch_bounds__(256) void quant_kernel(const bf16_t* x, long ldx, int M, int K, const float* amax,
                                                     unsigned char* q, long ldq, unsigned char* qt, long ldt,
-                                                    float* dq_out) {
+                                                    float* dq_out, float* amax_out) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[TRANS ? QT * QLD : 16];
+  __shared__ unsigned red[4];
+  unsigned mx = 0u;  // amax_out: max |x| of this tile (bf16 bit patterns), for the next step's scale
   const int tid = threadIdx.x;
   const int m0 = blockIdx.y * QT, k0 = blockIdx.x * QT;
   const float fmax = fp8_max(FMT);
@@ -89,7 +91,11 @@ __global__ __launch_bounds__(256) void quant_kernel(const bf16_t* x, long ldx, i
     u32x2 w = {0u, 0u};
     if (m < M && k < K) {  // K is a multiple of 8: chunks are all-in or all-out
       float v[8];
-      unpack8(*reinterpret_cast<const u32x4*>(x + (long)m * ldx + k), v);
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (long)m * ldx + k);
+      unpack8(raw, v);
+      if (amax_out)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = max(mx, max((raw[e] << 16) & 0x7fffffffu, raw[e] & 0x7fff0000u));
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * scale, -fmax), fmax);
       w[0] = cvt4<FMT>(v[0], v[1], v[2], v[3]);
@@ -98,8 +104,18 @@ __global__ __launch_bounds__(256) void quant_kernel(const bf16_t* x, long ldx, i
     }
     if constexpr (TRANS) *reinterpret_cast<u32x2*>(tile + r * QLD + 8 * c) = w;
   }
+  if (amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+  }
+  if (TRANS || amax_out) __syncthreads();
+  if (amax_out && tid == 0) {
+    mx = max(max(red[0], red[1]), max(red[2], red[3]));
+    unsigned* a = reinterpret_cast<unsigned*>(amax_out);
+    if (mx > __atomic_load_n(a, __ATOMIC_RELAXED)) atomicMax(a, mx);
+  }
   if constexpr (TRANS) {
-    __syncthreads();
     const int mq = tid & 31;  // 4 consecutive m per lane: a wave's 32 lanes cover the tile's 128 m of one k row
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -136,7 +152,8 @@ extern "C" int vds_absmax(const void* x, int64_t ldx, int32_t M, int32_t K, floa
 }
 
 extern "C" int vds_quant_fp8(const void* x, int64_t ldx, int32_t M, int32_t K, int32_t fmt, const float* amax,
-                             void* q, int64_t ldq, void* qt, int64_t ldt, float* dq_out, vds_stream_t stream) {
+                             void* q, int64_t ldq, void* qt, int64_t ldt, float* dq_out, float* amax_out,
+                             vds_stream_t stream) {
   if (!x || !amax || (!q && !qt) || M < 1 || K < 8 || (K & 7) || (ldx & 7) || (fmt != 0 && fmt != 1)) return VDS_ERR_ARG;
   if ((q && (ldq & 7)) || (qt && (ldt & 3))) return VDS_ERR_ARG;
   const dim3 grid((K + QT - 1) / QT, (M + QT - 1) / QT);
@@ -144,7 +161,7 @@ extern "C" int vds_quant_fp8(const void* x, int64_t ldx, int32_t M, int32_t K, i
 #define GOQ(F, T)                                                                                                  \
   if (fmt == F && (qt != nullptr) == T) {                                                                          \
     hipLaunchKernelGGL((quant_kernel<F, T>), grid, dim3(256), 0, s, (const bf16_t*)x, (long)ldx, M, K, amax,      \
-                       (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, dq_out);                       \
+                       (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, dq_out, amax_out);             \
     return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;                                              \
   }
   GOQ(0, false) GOQ(0, true) GOQ(1, false) GOQ(1, true)

@@ -7,8 +7,12 @@ The reference trains in bf16 only (model.py:516-518), so the recipe is this buil
     gradient and weight gradient; attention, the K=N=1152 projections (whose quantisation passes would cost more
     than the faster GEMM returns), norms, modulation, residuals, loss and the optimizer stay as in the bf16 path;
   * OCP e4m3fn for activations and weights, e5m2 for gradients, fp32 accumulation, bf16 / fp32 outputs;
-  * per-tensor scaling, computed from the current tensor (amax pass) -- nothing is carried between steps, so a
-    step is a pure function of its inputs, like the bf16 path; saturating casts;
+  * per-tensor scaling with saturating casts.  Weights are scaled by their current amax.  Activations and
+    gradients use delayed scaling in training: the scale comes from the amax the previous step recorded
+    (`AmaxHistory`, one device table, no host synchronisation), and the pass that quantises a tensor records its
+    current amax for the next step -- one read of the tensor instead of two.  The two widest tensors -- gelu(fc1)
+    and the fc2 input gradient, [tokens, 4D] -- are not re-read at all: the producing GEMM's epilogue emits them
+    as fp8 (`emit`).  The first step (no history) and no-grad forwards compute each tensor's own amax first;
   * every operand is quantised once per use site into a row-major copy and, where the backward pass contracts
     over its other index, a transposed copy, so that all three products of a linear layer are NT GEMMs:
         y  = x_q  W_q^T          dx = dy_q (W_q^T)^T         dW = dy_q^T^T ... = (dy^T)_q (x^T)_q^T
@@ -32,9 +36,60 @@ class Q:
     """a quantised matrix: row-major copy `q` [M,K], transposed copy `t` [K,M] (either may be None), factor `s`"""
     __slots__ = ("q", "t", "s", "rows", "cols")
 
-    def __init__(self, x: torch.Tensor, fmt: int, rowmajor: bool, transposed: bool):
+    def __init__(self, x: torch.Tensor = None, fmt: int = 0, rowmajor: bool = True, transposed: bool = False,
+                 hist: "AmaxHistory" = None, row: int = 0):
+        """hist / row: this tensor's slot in the delayed-scaling table.  With a history the single quantisation pass
+        scales by the previous step's amax and records the current one; without (first step, weights, inference)
+        the tensor's own amax is computed first (and recorded, so that the next step has a history)."""
+        if x is None:
+            return
         self.rows, self.cols = x.shape
-        self.q, self.t, self.s = ops.quant_fp8(x, fmt, ops.absmax(x), rowmajor, transposed)
+        if hist is not None and hist.ready:
+            self.q, self.t, self.s = ops.quant_fp8(x, fmt, hist.prev(row), rowmajor, transposed, amax_out=hist.cur(row))
+            return
+        amax = ops.absmax(x)
+        if hist is not None:
+            torch.maximum(hist.cur(row), amax, out=hist.cur(row))
+        self.q, self.t, self.s = ops.quant_fp8(x, fmt, amax, rowmajor, transposed)
+
+    @classmethod
+    def empty(cls, M: int, K: int, fmt: int, rowmajor: bool, transposed: bool, device):
+        """uninitialised buffers for a GEMM epilogue to fill (`emit_args`)"""
+        o = cls()
+        o.rows, o.cols = M, K
+        o.q = torch.empty(M, K, dtype=ops.fp8_dtypes[fmt], device=device) if rowmajor else None
+        o.t = torch.empty(K, M, dtype=ops.fp8_dtypes[fmt], device=device) if transposed else None
+        o.s = torch.empty(1, dtype=f32, device=device)
+        return o
+
+    def emit_args(self, fmt: int, amax_in, amax_out, colsum=None):
+        return dict(q=self.q, qt=self.t, amax_in=amax_in, amax_out=amax_out, dq_out=self.s, fmt=fmt, colsum=colsum)
+
+
+class AmaxHistory:
+    """Delayed-scaling state of the epilogue-emitted tensors: one (previous, current) amax pair per tensor in a
+    single device table; `roll()` at the start of a training forward makes the last step's amax the scale source
+    of this step.  No host synchronisation anywhere."""
+
+    def __init__(self, n: int, device):
+        self.tab = torch.zeros(n, 2, dtype=f32, device=device)
+        self.ready = False   # True once a complete training step has recorded every amax
+        self._armed = False
+
+    def roll(self):
+        if self._armed:
+            cur = self.tab[:, 1]
+            # a tensor that recorded nothing last step (a forward whose backward never ran) keeps its older scale
+            self.tab[:, 0].copy_(torch.where(cur > 0, cur, self.tab[:, 0]))
+            cur.zero_()
+            self.ready = True
+        self._armed = True
+
+    def prev(self, i: int):
+        return self.tab[i, 0:1]
+
+    def cur(self, i: int):
+        return self.tab[i, 1:2]
 
 
 def supported(M: int, N: int, K: int) -> bool:
@@ -52,6 +107,16 @@ def fwd_gelu(xq: Q, wq: Q, bias):
     pre = torch.empty(M, N, dtype=bf16, device=xq.q.device)
     act = torch.empty(M, N, dtype=bf16, device=xq.q.device)
     ops.gemm_fp8(EPI_BIAS_GELU, M, N, K, xq.q, wq.q, xq.s, wq.s, E4M3, pre, N, act, N, bias=bias)
+    return pre, act
+
+
+def fwd_gelu_emit(xq: Q, wq: Q, bias, amax_in, amax_out, transposed: bool):
+    """pre (bf16) and gelu(pre) directly as fp8 (row-major [+ transposed]); no bf16 activation is written"""
+    M, K, N = xq.rows, xq.cols, wq.rows
+    pre = torch.empty(M, N, dtype=bf16, device=xq.q.device)
+    act = Q.empty(M, N, E4M3, True, transposed, xq.q.device)
+    ops.gemm_fp8(EPI_BIAS_GELU, M, N, K, xq.q, wq.q, xq.s, wq.s, E4M3, pre, N, None, 0, bias=bias,
+                 emit=act.emit_args(E4M3, amax_in, amax_out))
     return pre, act
 
 
@@ -73,6 +138,16 @@ def dgrad(dyq: Q, wq: Q, pre=None):
     else:
         ops.gemm_fp8(EPI_DGELU, M, K, N, dyq.q, wq.t, dyq.s, wq.s, E5M2, dx, K, aux=pre, ldaux=pre.stride(0))
     return dx
+
+
+def dgrad_gelu_emit(dyq: Q, wq: Q, pre, amax_in, amax_out, colsum):
+    """dh = (dy W) * gelu'(pre) directly as e5m2 (row-major + transposed) with its column sums (the bias gradient)
+    accumulated into `colsum`; no bf16 dh is written"""
+    M, N, K = dyq.rows, dyq.cols, wq.cols
+    dh = Q.empty(M, K, E5M2, True, True, dyq.q.device)
+    ops.gemm_fp8(EPI_DGELU, M, K, N, dyq.q, wq.t, dyq.s, wq.s, E5M2, None, 0, aux=pre, ldaux=pre.stride(0),
+                 emit=dh.emit_args(E5M2, amax_in, amax_out, colsum))
+    return dh
 
 
 def wgrad(dyq: Q, xq: Q, dW: torch.Tensor, n_cu: int = 256):

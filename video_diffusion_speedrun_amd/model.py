@@ -30,9 +30,13 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import nn
 
+import os
+
 from . import fp8 as F8
 from . import ops
 from .params import FlatGroup
+
+_NO_EMIT = os.environ.get("VDS_FP8_NO_EMIT") == "1"  # experiments: quantise every fp8 operand in a separate pass
 
 bf16, f32 = torch.bfloat16, torch.float32
 N_REG = 16  # register tokens (model.py:316,362,386)
@@ -211,6 +215,7 @@ class DiT(nn.Module):
         """Run the qkv and MLP linears of every block in OCP fp8 (e4m3 activations / weights, e5m2 gradients,
         per-tensor current scaling; fp8.py states the recipe).  The reference has no such mode."""
         self.fp8 = bool(on)
+        self._fp8_hist = None  # fp8.AmaxHistory: 6 rows per block (gelu(fc1), d fc2-in, xn1, xn3, d mlp-out, d qkv)
         return self
 
     # --------------------------------------------------------------------- parameters ----
@@ -300,6 +305,11 @@ class DiT(nn.Module):
         Lc, Cc = context.shape[1], context.shape[2]
         ctx2d = context.view(B * Lc, Cc)
         sv = _Saved() if save else None
+        if self.fp8:
+            if getattr(self, "_fp8_hist", None) is None or self._fp8_hist.tab.device != dev:
+                self._fp8_hist = F8.AmaxHistory(6 * self.depth, dev)
+            if save:
+                self._fp8_hist.roll()
 
         # patch embed + register tokens -> token buffer X [B*L, D]   (model.py:360-362)
         patches = ops.patchify(x, pt, p)
@@ -370,7 +380,8 @@ class DiT(nn.Module):
         if self.fp8 and not f8:
             raise ValueError(f"fp8 linears need B*L ({B * L}) and hidden size ({D}) to be multiples of 16")
         if f8:
-            q_xn1 = F8.Q(xn1, F8.E4M3, True, save)
+            hist = self._fp8_hist if save else None
+            q_xn1 = F8.Q(xn1, F8.E4M3, True, save, hist, 6 * i + 2)
             q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save)
             qkv = torch.empty(B * L, 3 * D, dtype=bf16, device=dev)
             F8.fwd(q_xn1, q_wqkv, qkv, Wo("qkv.bias"))
@@ -400,10 +411,14 @@ class DiT(nn.Module):
         # --- MLP (model.py:163-165)
         xn3, rstd3 = ops.rmsnorm_mod_fwd(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L)
         if f8:
-            q_xn3 = F8.Q(xn3, F8.E4M3, True, save)
+            q_xn3 = F8.Q(xn3, F8.E4M3, True, save, hist, 6 * i + 3)
             q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save)
-            hpre, hact = F8.fwd_gelu(q_xn3, q_w1, W("mlp.0.bias"))
-            q_hact = F8.Q(hact, F8.E4M3, True, save)
+            if hist is not None and hist.ready and not _NO_EMIT:  # gelu(fc1) leaves the GEMM as fp8
+                hpre, q_hact = F8.fwd_gelu_emit(q_xn3, q_w1, W("mlp.0.bias"), hist.prev(6 * i), hist.cur(6 * i), save)
+                hact = None
+            else:
+                hpre, hact = F8.fwd_gelu(q_xn3, q_w1, W("mlp.0.bias"))
+                q_hact = F8.Q(hact, F8.E4M3, True, save, hist, 6 * i)
             q_w2 = F8.Q(W("mlp.2.weight"), F8.E4M3, True, save)
             y_mlp, X3 = F8.fwd_gate_res(q_hact, q_w2, W("mlp.2.bias"), mod, 8 * D, X2, L)
         else:
@@ -498,12 +513,18 @@ class DiT(nn.Module):
         # --- MLP
         dy = ops.gate_bwd(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L)
         if bs.f8:
-            q_dy = F8.Q(dy, F8.E5M2, True, True)
+            hist = self._fp8_hist
+            q_dy = F8.Q(dy, F8.E5M2, True, True, hist, 6 * i + 4)
             F8.wgrad(q_dy, bs.q_hact, Gr("mlp.2.weight"))
-            dh = F8.dgrad(q_dy, bs.q_w2, pre=bs.hpre)
-            q_dh = F8.Q(dh, F8.E5M2, True, True)
+            if hist.ready and not _NO_EMIT:  # the fc2 input gradient leaves the GEMM as e5m2 (+ transposed, + bias gradient)
+                dh = None
+                q_dh = F8.dgrad_gelu_emit(q_dy, bs.q_w2, bs.hpre, hist.prev(6 * i + 1), hist.cur(6 * i + 1),
+                                          Gr("mlp.0.bias"))
+            else:
+                dh = F8.dgrad(q_dy, bs.q_w2, pre=bs.hpre)
+                q_dh = F8.Q(dh, F8.E5M2, True, True, hist, 6 * i + 1)
+                ops.colsum(dh, Gr("mlp.0.bias"))
             F8.wgrad(q_dh, bs.q_xn3, Gr("mlp.0.weight"))
-            ops.colsum(dh, Gr("mlp.0.bias"))
             dxn = F8.dgrad(q_dh, bs.q_w1)
             del q_dy, q_dh
         else:
@@ -557,7 +578,7 @@ class DiT(nn.Module):
         if G.has(pre + "qkv.bias"):
             ops.colsum(dqkv, Gr("qkv.bias"))
         if bs.f8:
-            q_dqkv = F8.Q(dqkv, F8.E5M2, True, True)
+            q_dqkv = F8.Q(dqkv, F8.E5M2, True, True, self._fp8_hist, 6 * i + 5)
             F8.wgrad(q_dqkv, bs.q_xn1, Gr("qkv.weight"))
             dxn = F8.dgrad(q_dqkv, bs.q_wqkv)
             del q_dqkv

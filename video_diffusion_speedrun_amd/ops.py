@@ -103,26 +103,35 @@ def absmax(x: torch.Tensor, amax: Optional[torch.Tensor] = None) -> torch.Tensor
     return amax
 
 
-def quant_fp8(x: torch.Tensor, fmt: int, amax: torch.Tensor, rowmajor: bool = True, transposed: bool = False):
-    """bf16 [M,K] -> (q [M,K] fp8 | None, qt [K,M] fp8 | None, dq f32[1]) with per-tensor scale fmax / amax."""
+def quant_fp8(x: torch.Tensor, fmt: int, amax: torch.Tensor, rowmajor: bool = True, transposed: bool = False,
+              amax_out: Optional[torch.Tensor] = None):
+    """bf16 [M,K] -> (q [M,K] fp8 | None, qt [K,M] fp8 | None, dq f32[1]) with per-tensor scale fmax / amax;
+    amax_out (f32[1]) additionally accumulates max |x| (delayed scaling: the next step's `amax`)."""
     ld, K = _rows(x)
     M = x.shape[0]
     assert (M % 4 == 0 or not transposed) and K % 8 == 0
     q = torch.empty(M, K, dtype=fp8_dtypes[fmt], device=x.device) if rowmajor else None
     qt = torch.empty(K, M, dtype=fp8_dtypes[fmt], device=x.device) if transposed else None
     dq = torch.empty(1, dtype=f32, device=x.device)
-    check(_lib.load().vds_quant_fp8(_p(x), ld, M, K, fmt, _p(amax), _p(q), K, _p(qt), M, _p(dq), _stream()),
-          "vds_quant_fp8")
+    check(_lib.load().vds_quant_fp8(_p(x), ld, M, K, fmt, _p(amax), _p(q), K, _p(qt), M, _p(dq), _p(amax_out),
+                                    _stream()), "vds_quant_fp8")
     return q, qt, dq
 
 
 def gemm_fp8(epi: int, M: int, N: int, K: int, A, B, sa, sb, a_fmt: int, Cp=None, ldc=0, C2=None, ldc2=0, bias=None,
-             aux=None, ldaux=0, gate=None, ldgate=0, rows_per_batch=0, split_k=1):
-    """C = epilogue((A[M,K] . B[N,K]^T) * sa * sb), A / B contiguous fp8 (A e4m3 or e5m2, B e4m3)."""
+             aux=None, ldaux=0, gate=None, ldgate=0, rows_per_batch=0, split_k=1, emit=None):
+    """C = epilogue((A[M,K] . B[N,K]^T) * sa * sb), A / B contiguous fp8 (A e4m3 or e5m2, B e4m3).
+    emit = dict(q=, qt=, amax_in=, amax_out=, dq_out=, fmt=, colsum=): fp8 copies of the epilogue result (vds_fp8_out)."""
     assert A.is_contiguous() and B.is_contiguous() and A.shape == (M, K) and B.shape == (N, K)
     a = GemmArgs(VDS_NT, epi, M, N, K, _p(A), K, _p(B), K, _p(Cp), ldc, _p(C2), ldc2, _p(bias), _p(aux), ldaux,
                  _p(gate), ldgate, rows_per_batch, split_k)
-    check(_lib.load().vds_gemm_fp8(C.byref(a), _p(sa), _p(sb), a_fmt, 0, _stream()),
+    e = None
+    if emit is not None:
+        q, qt = emit.get("q"), emit.get("qt")
+        assert (q is None or q.shape == (M, N)) and (qt is None or qt.shape == (N, M))
+        e = C.byref(_lib.Fp8Out(_p(q), N, _p(qt), M, _p(emit.get("amax_in")), _p(emit.get("amax_out")),
+                                _p(emit.get("dq_out")), int(emit.get("fmt", 0)), _p(emit.get("colsum"))))
+    check(_lib.load().vds_gemm_fp8(C.byref(a), _p(sa), _p(sb), a_fmt, 0, e, _stream()),
           f"vds_gemm_fp8(epi={epi},M={M},N={N},K={K})")
 
 
