@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0
 # name -> (DiT kwargs, latent [C,T,H,W], default per-GPU batch, description)
 WORKLOADS = {
     # the seq~8k DiT-XL step the metric's target is quoted on (fits one GPU)
-    "c3b": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 6,
+    "c3b": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 12,
             "C3b DiT-XL/2 bf16, latents [16,16,64,64] pt=2 -> 8192+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[1]
     "c2": (dict(hidden_size=768, depth=12, num_heads=12, time_patch_size=1), (16, 16, 32, 32), 8,
@@ -47,7 +47,7 @@ WORKLOADS = {
     "c4": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=1), (16, 33, 64, 64), 1,
            "C4 DiT-XL/2 bf16, latents [16,33,64,64] pt=1 -> 33792+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[4]: the C3b shapes with the qkv / MLP GEMMs on the fp8 MFMA path (fp8.py)
-    "c5": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 6,
+    "c5": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 12,
            "C5 DiT-XL/2 fp8 (e4m3 activations/weights, e5m2 gradients in the qkv + MLP GEMMs; rest bf16), "
            "latents [16,16,64,64] pt=2 -> 8192+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[0] shape, on the GPU
@@ -249,6 +249,7 @@ def main():
                        "step_tflop_per_sample": flops / 1e12},
             "mfma_util_step": value * flops / (world * PEAK_BF16_TFLOPS * 1e12),
             "loss": loss_val,
+            "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
         }
         if dom:
             mfma_bound = dom["flops"] > 0
