@@ -592,3 +592,88 @@ def test_fp8_step_close_to_oracle(vds, D, H, lat):
             assert rel(p.grad, g1[k]) <= 1e-4, (k, rel(p.grad, g1[k]))
     with pytest.raises(ValueError):  # 4*(2*4*4 + 16) is fine, but an odd token count is not: clear error, no fallback
         m(torch.randn(1, 16, 2, 6, 6).cuda(), ctx[:1].cuda(), t[:1].cuda(), rope_start=start)
+
+
+def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch):
+    """The sharded train step with world_size 2 on ONE GPU: two replicas (rank 0, rank 1) of the same model live in
+    this process with the real shard layout, stream / event choreography, HIP kernels and sharded optimizer; only
+    the two collectives are replaced by an in-process exchange (RCCL refuses two ranks on one device).  Each rank
+    takes its own micro-batch; after one step the concatenated parameter shards must equal the unsharded model
+    stepped on the concatenated batch (gradient = average over ranks, model.py:516-519)."""
+    from video_diffusion_speedrun_amd import params as PM
+    from video_diffusion_speedrun_amd.fsdp import apply_fsdp
+    W = 2
+    cfg = O.DiTConfig(in_channels=16, hidden_size=128, depth=3, num_heads=2, cross_attn_input_size=64,
+                      residual_v=True, train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=61, randomize_zero_init=True, init_std_factor=1.0)
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(4, 16, 4, 8, 8, generator=g).to(bf16).cuda()
+    ctx = torch.randn(4, 16, 64, generator=g).to(bf16).cuda()
+    t = torch.tensor([0.2, 0.5, 0.7, 0.9]).to(bf16).cuda()
+    v = torch.randn(4, 16, 4, 8, 8, generator=g).to(bf16).cuda()
+    start = (1, 2, 3)
+
+    def step(m, sl):
+        groups, _ = m.get_mup_setup(3e-3, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
+        opt = vds["optim"].MuAdamW(groups, betas=(0.95, 0.99))
+        out = m(x[sl], ctx[sl], t[sl], rope_start=start)
+        loss, _ = vds["train"].flow_loss(out, v[sl])
+        loss.backward()
+        return opt, loss
+
+    ref = build(vds, cfg, P)
+    opt, loss_ref = step(ref, slice(0, 4))
+    opt.step()
+    want = ref.full_state_dict()
+
+    reps, tokens = [], [object() for _ in range(W)]
+    pending = {}
+
+    def find(buf, attr):
+        for r, m in enumerate(reps):
+            for gi, grp in enumerate(m._groups):
+                if getattr(grp, attr).data_ptr() == buf.data_ptr():
+                    return r, gi
+        raise AssertionError("collective on an unknown buffer")
+
+    def fake_all_gather(out, inp, group=None):
+        _, gi = find(inp, "shadow")
+        parts = out.view(W, -1)
+        for r2, m2 in enumerate(reps):  # what rank r2 contributes: the bf16 cast of its fp32 master shard
+            parts[r2].copy_(m2._groups[gi].master.to(bf16))
+
+    def fake_reduce_scatter(out, inp, group=None):
+        r, gi = find(inp, "gfull")
+        pending.setdefault(gi, {})[r] = inp.clone()
+        if len(pending[gi]) == W:
+            avg = sum(pending[gi].values()) / W
+            for r2, m2 in enumerate(reps):
+                m2._groups[gi].gshard.copy_(avg.view(W, -1)[r2])
+
+    monkeypatch.setattr(PM, "all_gather_flat", fake_all_gather)
+    monkeypatch.setattr(PM, "reduce_scatter_avg", fake_reduce_scatter)
+    for r in range(W):
+        m = build(vds, cfg, P)
+        reps.append(apply_fsdp(m, torch.bfloat16, torch.float32, process_group=tokens[r], world_rank=(W, r)))
+        assert m._fsdp is not None and m._groups[1].world == W and m._groups[1].rank == r
+    opts, losses = [], []
+    for r in range(W):
+        o, l = step(reps[r], slice(2 * r, 2 * r + 2))
+        opts.append(o)
+        losses.append(l.item())
+    torch.cuda.synchronize()  # rank 0's gradient shards were completed while rank 1 ran its backward
+    assert all(len(d) == W for d in pending.values()) and len(pending) == 1 + cfg.depth
+    assert abs(sum(losses) / W - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    for o in opts:
+        o.step()
+    torch.cuda.synchronize()
+    for gi, grp0 in enumerate(reps[0]._groups):
+        flat = torch.cat([m._groups[gi].master for m in reps])
+        for n in grp0.names:
+            o0 = grp0.offsets[n]
+            got = flat[o0:o0 + want[n].numel()].view(want[n].shape)
+            assert rel(got, want[n]) <= 1e-4, (n, rel(got, want[n]))
+    # every parameter of a sharded replica is this rank's 1-D piece, and the pieces tile the tensor
+    for n, p0 in reps[0].named_parameters():
+        p1 = dict(reps[1].named_parameters())[n]
+        assert p0.dim() == 1 and p0.numel() + p1.numel() == want[n].numel()

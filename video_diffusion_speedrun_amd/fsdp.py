@@ -124,7 +124,7 @@ class _Null:
 
 
 def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32, process_group=None,
-               device=None, cast_fn=None, force_runtime=False):
+               device=None, cast_fn=None, force_runtime=False, world_rank=None):
     """Shard `dit_model` over the ranks of `process_group` (default: the world) and return it
     -- the same object, still callable, still exposing get_mup_setup / named_parameters
     (model.py:512-542).  After this call every nn.Parameter is this rank's 1-D fp32 piece of
@@ -134,7 +134,12 @@ def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32
     are the only values the kernels implement."""
     if param_dtype != torch.bfloat16 or reduce_dtype != torch.float32:
         raise ValueError("apply_fsdp: the HIP path implements param_dtype=bf16, reduce_dtype=fp32 only")
-    if dist.is_initialized():
+    if world_rank is not None:
+        # explicit (world, rank) without a torch.distributed group: the caller supplies the collectives by
+        # replacing params.all_gather_flat / params.reduce_scatter_avg (single-GPU emulation of W ranks in
+        # tests/test_model_gpu.py::test_two_emulated_ranks_on_one_gpu)
+        world, rank = world_rank
+    elif dist.is_initialized():
         world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
     else:
         world, rank = 1, 0
@@ -154,7 +159,7 @@ def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32
     root, blocks = dit_model._group_members()
     groups = [FlatGroup("root", root, world, rank)]
     groups += [FlatGroup(f"blocks.{i}", m, world, rank) for i, m in enumerate(blocks)]
-    run = world > 1 or (force_runtime and dist.is_initialized())
+    run = world > 1 or (force_runtime and (dist.is_initialized() or world_rank is not None))
     for g in groups:
         g.materialize(device, full_values, separate=run)  # W=1 + runtime: real collectives into separate buffers
     for name, buf in dit_model.named_buffers():
