@@ -38,13 +38,13 @@ WORKLOADS = {
     "c3b": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 12,
             "C3b DiT-XL/2 bf16, latents [16,16,64,64] pt=2 -> 8192+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[1]
-    "c2": (dict(hidden_size=768, depth=12, num_heads=12, time_patch_size=1), (16, 16, 32, 32), 8,
+    "c2": (dict(hidden_size=768, depth=12, num_heads=12, time_patch_size=1), (16, 16, 32, 32), 16,
            "C2 DiT-B/2 bf16, latents [16,16,32,32] pt=1 -> 4096+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[2] literal shape
-    "c3a": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=1), (16, 17, 32, 32), 2,
+    "c3a": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=1), (16, 17, 32, 32), 16,
             "C3a DiT-XL/2 bf16, latents [16,17,32,32] pt=1 -> 4352+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[3]
-    "c4": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=1), (16, 33, 64, 64), 1,
+    "c4": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=1), (16, 33, 64, 64), 2,
            "C4 DiT-XL/2 bf16, latents [16,33,64,64] pt=1 -> 33792+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[4]: the C3b shapes with the qkv / MLP GEMMs on the fp8 MFMA path (fp8.py)
     "c5": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 12,
