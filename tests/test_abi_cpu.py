@@ -44,6 +44,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.GemmArgs) == 5 * 4 + 4 + 8 * 13 + 4 + 4  # 5 int32 + pad, 13 pointer/int64, 2 int32
     assert C.sizeof(_lib.AttnArgs) == 5 * 4 + 4 + 8 * (4 * 4 + 1 + 4 * 4 + 1) + 8  # + kv_pad_ones (padded)
     assert C.sizeof(_lib.ProfStat) == 32
+    assert C.sizeof(_lib.Fp8Out) == 7 * 8 + 4 + 4 + 8  # 7 pointer/int64, fmt + pad, colsum
+    assert _lib.Fp8Out.colsum.offset == 64 and _lib.Fp8Out.fmt.offset == 56
 
 
 def test_host_side_argument_checks(lib):
@@ -55,6 +57,17 @@ def test_host_side_argument_checks(lib):
     assert lib.vds_adamw_multi(None, None, None, 1, 1024, 0.9, 0.99, 1e-8, 1, 1.0, 1.0, None) == -1
     assert lib.vds_prof_collect(None) == -1
     assert lib.vds_prof_class_name(0) == b"gemm_nt"
+    assert lib.vds_prof_class_name(_lib.PROF_NCLASS - 1) == b"gemm_fp8" and lib.vds_prof_class_name(_lib.PROF_NCLASS) == b""
+    # fp8 entry points: null operands / bad alignment / unsupported layout are refused before any launch
+    assert lib.vds_gemm_fp8(C.byref(a), None, None, 0, 0, None, None) == -1
+    g = _lib.GemmArgs(1, 0, 16, 16, 16, 8, 16, 8, 16, 8, 16)   # layout NN: fp8 operands are NT only
+    assert lib.vds_gemm_fp8(C.byref(g), None, None, 0, 0, None, None) == -2
+    g = _lib.GemmArgs(0, 0, 16, 16, 24, 8, 24, 8, 24, 8, 16)   # K not a multiple of 16
+    assert lib.vds_gemm_fp8(C.byref(g), None, None, 0, 0, None, None) == -1
+    assert lib.vds_quant_fp8(None, 0, 1, 8, 0, None, None, 0, None, 0, None, None, None) == -1
+    assert lib.vds_absmax(None, 0, 1, 8, None, None) == -1
+    assert lib.vds_rope_rows_dev(None, None, None, None, 1, 1, 1, 1, 1, None, 0, None, None, None) == -1
+    assert lib.vds_adamw_multi_dev(None, None, None, 1, 1024, 0.9, 0.99, 1e-8, None, 1.0, None) == -1
 
 
 def test_product_package_never_imports_the_oracle():
