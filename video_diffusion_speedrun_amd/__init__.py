@@ -5,7 +5,7 @@ Drop-in host API of the reference's model.py / train.py hot path:
 The package has no CPU / eager-torch compute fallback: importing the compute modules without
 the built `libvds_hip.so` raises.
 """
-__all__ = ["DiT", "DiTBlock", "apply_fsdp", "forward", "MuAdamW", "generate_latents"]
+__all__ = ["DiT", "DiTBlock", "apply_fsdp", "forward", "MuAdamW", "generate_latents", "GraphedTrainStep"]
 
 
 def __getattr__(name):  # lazy: `import video_diffusion_speedrun_amd` itself stays light
@@ -21,6 +21,9 @@ def __getattr__(name):  # lazy: `import video_diffusion_speedrun_amd` itself sta
     if name == "generate_latents":
         from . import sampling
         return sampling.generate_latents
+    if name == "GraphedTrainStep":
+        from . import graph
+        return graph.GraphedTrainStep
     if name == "MuAdamW":
         from . import optim
         return optim.MuAdamW
