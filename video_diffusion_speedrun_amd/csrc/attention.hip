@@ -23,6 +23,7 @@
 // image swizzle applied to the per-lane source address), one tile ahead, double-buffered, one
 // barrier per tile; the forward pass uses a lazy-rescale online softmax per 32-key sub-block.
 #include "common.h"
+#include <type_traits>
 #include "prof.h"
 #include "../../include/vds.h"
 #include <cstdlib>
@@ -280,13 +281,14 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd_kernel(AttnP p) {
   VDS_WAIT_VM(0);
   __syncthreads();  // tile 0 landed (DMA waited above: the compiler does not see it)
 
-  for (int j = 0; j < nkt; ++j) {
+  auto kv_tile = [&](int j, auto PAR) {  // unrolled by two: compile-time LDS buffer parity (see the wide kernel)
+    constexpr int par = decltype(PAR)::value;
     if (j + 1 < nkt) {
-      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
+      char* nk = smem + (par ^ 1) * 2 * TILE;
       dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
       dv.issue(rv, nk + TILE, (unsigned)(j + 1) * v_step, wave);
     }
-    const char* kt = smem + (j & 1) * 2 * TILE;
+    const char* kt = smem + par * 2 * TILE;
     const char* vt = kt + TILE;
     const bool ragged = (j == nkt - 1) && (p.Lk & 63);
     if constexpr (PIPE) {
@@ -343,6 +345,10 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd_kernel(AttnP p) {
     }
     VDS_WAIT_VM(0);
     __syncthreads();  // next tile landed, everyone done reading this one
+  };
+  for (int j = 0; j < nkt; j += 2) {
+    kv_tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
   }
 
   const float lt = add_with_other_half(l);
@@ -457,13 +463,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(AttnP p) {
   VDS_WAIT_VM(0);
   __syncthreads();
 
-  for (int j = 0; j < nkt; ++j) {
+  // the KV loop is unrolled by two so that the LDS buffer parity is a compile-time constant: every fragment
+  // read becomes base register + immediate offset instead of one address add per read
+  auto kv_tile = [&](int j, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
     if (j + 1 < nkt) {
-      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
+      char* nk = smem + (par ^ 1) * 2 * TILE;
       dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
       dv.issue(rv, nk + TILE, (unsigned)(j + 1) * v_step, wave);
     }
-    const char* kt = smem + (j & 1) * 2 * TILE;
+    const char* kt = smem + par * 2 * TILE;
     const char* vt = kt + TILE;
     const bool ragged = (j == nkt - 1) && (p.Lk & 63);
 #pragma unroll
@@ -506,6 +515,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(AttnP p) {
     }
     VDS_WAIT_VM(0);
     __syncthreads();
+  };
+  for (int j = 0; j < nkt; j += 2) {
+    kv_tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
   }
 
 #pragma unroll
@@ -676,13 +689,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   VDS_WAIT_VM(0);
   __syncthreads();  // tile 0 landed
 
-  for (int j = 0; j < nkt; ++j) {
+  auto kv_tile = [&](int j, auto PAR) {  // unrolled by two: compile-time LDS buffer parity (see the forward kernel)
+    constexpr int par = decltype(PAR)::value;
     if (j + 1 < nkt) {
-      char* nk = smem + ((j + 1) & 1) * 2 * TILE;
+      char* nk = smem + (par ^ 1) * 2 * TILE;
       dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
       dv.issue(rv, nk + TILE, (unsigned)(j + 1) * v_step, wave);
     }
-    const char* kt = smem + (j & 1) * 2 * TILE;
+    const char* kt = smem + par * 2 * TILE;
     const char* vt = kt + TILE;
     // keys past Lk need no mask: their K rows are zero-filled, so whatever dS they get multiplies a
     // zero row of K in dQ^T += K^T dS^T
@@ -717,6 +731,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     }
     VDS_WAIT_VM(0);
     __syncthreads();
+  };
+  for (int j = 0; j < nkt; j += 2) {
+    kv_tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
   }
   if (qrow < p.Lq)
     store_rows<NDB>(p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl, dq, p.scale, p.hd, h);
@@ -762,18 +780,18 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void att
   dq_.init(p.q_sl, hd_q, wave, lane);
   dd_.init(p.do_sl, p.hd, wave, lane);
   const unsigned q_step = (unsigned)(64 * p.q_sl * 2), do_step = (unsigned)(64 * p.do_sl * 2);
-  auto issue_tile = [&](int j) {
-    char* nb = qbuf + (j & 1) * 2 * Q_TILE;
+  auto issue_tile = [&](int j, int par) {
+    char* nb = qbuf + par * 2 * Q_TILE;
     dq_.issue(rq, nb, (unsigned)j * q_step, wave);
     dd_.issue(rdo, nb + Q_TILE, (unsigned)j * do_step, wave);
     if (wave == 0) {  // 64 rows x 4 B each: lse2 then delta
-      char* st = stats + (j & 1) * 512;
+      char* st = stats + par * 512;
       const unsigned sa = lds_addr_of(st);
       lds_dma4(rl2, sa, (unsigned)((j * 64 + lane) * 4));
       lds_dma4(rdl, sa + 256, (unsigned)((j * 64 + lane) * 4));
     }
   };
-  issue_tile(0);
+  issue_tile(0, 0);
 
   // this lane's key row as B-operand fragments (rows past Lk / columns past hd read as zero)
   bf16x8 kf[KSQ], vf[KSQ];
@@ -804,11 +822,12 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void att
   VDS_WAIT_VM(0);
   __syncthreads();  // tile 0 landed
 
-  for (int j = 0; j < nqt; ++j) {
-    if (j + 1 < nqt) issue_tile(j + 1);
-    const char* qt = qbuf + (j & 1) * 2 * Q_TILE;
+  auto q_tile = [&](int j, auto PAR) {  // unrolled by two: compile-time LDS buffer parity (see the forward kernel)
+    constexpr int par = decltype(PAR)::value;
+    if (j + 1 < nqt) issue_tile(j + 1, par ^ 1);
+    const char* qt = qbuf + par * 2 * Q_TILE;
     const char* dot = qt + Q_TILE;
-    const float* stl = reinterpret_cast<const float*>(stats + (j & 1) * 512);
+    const float* stl = reinterpret_cast<const float*>(stats + par * 512);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16 s = zero16(), dp;
@@ -863,6 +882,10 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void att
     }
     VDS_WAIT_VM(0);
     __syncthreads();
+  };
+  for (int j = 0; j < nqt; j += 2) {
+    q_tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nqt) q_tile(j + 1, std::integral_constant<int, 1>{});
   }
   if (krow < p.Lk) {
     store_rows<NDB>(p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl, dk, p.scale, p.hd, h);
