@@ -1,0 +1,44 @@
+"""bench.py without a GPU: the workload table prices a step at the algorithmic FLOPs SURVEY.md 8(d) states, and the
+CLI keeps the driver's contract (flags, defaults)."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(REPO, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("name,tflop", [("c2", 4.78), ("c3a", 22.70), ("c3b", 54.15), ("c4", 555.5), ("c5", 54.15)])
+def test_step_flops_match_the_survey_table(name, tflop):
+    b = load_bench()
+    kw, latent, batch, desc = b.WORKLOADS[name]
+    assert abs(b.step_flops(kw, latent) / 1e12 - tflop) / tflop < 2e-3
+    assert 1 <= batch <= 16 and desc.startswith(name.upper()[:2])
+
+
+def test_default_workload_is_the_seq8k_dit_xl_step():
+    b = load_bench()
+    kw, latent, batch, desc = b.WORKLOADS["c3b"]
+    assert kw == dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2) and latent == (16, 16, 64, 64)
+    assert b.PEAK_BF16_TFLOPS == 2500.0 and b.PEAK_HBM_GBS == 8000.0
+
+
+def test_cli_flags_and_gpu_requirement():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--help"], capture_output=True, text=True)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--workload", "--graph"):
+        assert flag in out.stdout
+    import torch
+    if not torch.cuda.is_available():  # no silent CPU path: the bench refuses to run without the HIP device
+        out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0"],
+                             capture_output=True, text=True)
+        assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
