@@ -156,7 +156,8 @@ def attn_ref(q, k, v, do=None):
 
 
 @pytest.mark.parametrize("hd,Lq,Lk", [(64, 272, 272), (64, 130, 512), (128, 200, 333), (72, 272, 272),
-                                      (72, 129, 512), (128, 64, 64), (64, 1040, 1040)])
+                                      (72, 129, 512), (128, 64, 64), (64, 1040, 1040), (64, 2100, 300),
+                                      (72, 2100, 300)])  # Lq >= 2048: the 64-queries-per-wave forward kernels
 def test_attention_fwd_bwd(ops, hd, Lq, Lk):
     B, H = 2, 3
     hdp = {64: 64, 72: 96, 128: 128}[hd]

@@ -934,25 +934,30 @@ int run_fwd(AttnP p, hipStream_t s) {
   static bool once = false;
   if (!once) {
     set_lds(attn_fwd_kernel<HDP, HDQ, 2, true>, LDS);
-    if constexpr (HDP == 96) {
-      set_lds(attn_fwd_wide_kernel<HDP, HDQ, false>, LDS);
-      set_lds(attn_fwd_wide_kernel<HDP, HDQ, true>, LDS);
-    }
+    if constexpr (HDP <= 96) set_lds(attn_fwd_wide_kernel<HDP, HDQ, false>, LDS);
+    if constexpr (HDP == 96) set_lds(attn_fwd_wide_kernel<HDP, HDQ, true>, LDS);
     once = true;
   }
-  static int wide = -1;  // VDS_ATTN_FWD_WIDE=0/1 forces (experiments); default: head_dim 72, long query sequences
+  static int wide = -1;  // VDS_ATTN_FWD_WIDE=0/1 forces (experiments); default: head_dim 64 / 72, long query sequences
   if (wide < 0) {
     const char* e = getenv("VDS_ATTN_FWD_WIDE");
     wide = e ? atoi(e) : 2;
   }
   bool use_wide = false;
   if constexpr (HDP == 96) use_wide = wide == 1 || (wide == 2 && p.Lq >= 2048);
+  if constexpr (HDP == 64) use_wide = wide == 1 || (wide == 2 && p.Lq >= 2048);  // +2.7 % at head_dim 64
   p.n_rt = cdiv(p.Lq, use_wide ? 256 : 128);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
   const bool ones_fwd = HDP == 96 && use_wide && p.kv_pad_ones && p.hd == 72;
   vdsprof::Scope ps(ones_fwd ? VDS_PROF_ATTN_FWD : VDS_PROF_ATTN_FWD_PLAIN, s, fl,
                     2.0 * p.B * p.H * p.hd * (2.0 * p.Lq + 2.0 * p.Lk));
+  if constexpr (HDP == 64) {
+    if (use_wide) {
+      hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS, s, p);
+      return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+    }
+  }
   if constexpr (HDP == 96) {
     if (use_wide) {
       if (p.kv_pad_ones && p.hd == 72)
