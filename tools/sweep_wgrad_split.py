@@ -1,5 +1,6 @@
+"""Sweep the split-K factor of the weight-gradient GEMMs at the DiT-XL shapes against ops._wgrad_split's choice."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_diffusion_speedrun_amd import ops
 from video_diffusion_speedrun_amd._lib import EPI_F32, VDS_TN
