@@ -64,6 +64,28 @@ def test_gemm_nt_store_bias(ops, M, N, K):
     close("nt", y2, x.float() @ w.float().t(), 4e-3)
 
 
+@pytest.mark.parametrize("N", [1152, 3456, 1096, 1280])
+def test_gemm_large_m_ragged_last_column_tile(ops, N):
+    """problems big enough for the 256^2 kernel whose N does not fill the last column of tiles (1152 = 4.5 tiles,
+    3456 = 13.5, 1096 = 4 tiles + 72 columns; 1280 = 5 full tiles as the control): forward (bias), gate + residual
+    epilogue and input gradient, ragged M (49248 = 192.4 tiles)"""
+    B, L, K = 6, 8208, 192
+    M = B * L
+    x, w, b = gen(M, K, seed=31), gen(N, K, seed=32, scale=0.05), gen(N, seed=33)
+    ref = x.float() @ w.float().t()
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
+    close("stripe.nt+bias", y, ref + b.float(), 4e-3)
+    res, mod = gen(M, N, seed=34), gen(B, 3 * N, seed=35, dtype=f32)
+    y2, xn = ops.linear_fwd_gate_res(x.cuda(), w.cuda(), None, mod.cuda(), 2 * N, res.cuda(), L)
+    close("stripe.gate.y", y2, ref, 4e-3)
+    close("stripe.gate.xnew", xn, res.float() + ref * mod[:, 2 * N:].repeat_interleave(L, dim=0), 4e-3)
+    # input gradient of a [K2 -> N] ... as NN: dy [M, K2] @ W2 [K2, N]
+    K2 = 256
+    dy, w2 = gen(M, K2, seed=36), gen(K2, N, seed=37, scale=0.05)
+    dx = ops.linear_dgrad(dy.cuda(), w2.cuda())
+    close("stripe.nn", dx, dy.float() @ w2.float(), 4e-3)
+
+
 def test_gemm_nt_asymmetric_identity(ops):
     """A = I against an asymmetric B catches transposed / permuted fragment maps."""
     K = 128
