@@ -233,6 +233,11 @@ int vds_noise_latents(const void* x, const void* noise, const float* t, void* z_
  * loss_out[0] += ... (pre-zeroed), per_sample[b] +=.  dout = bf16( 2 (out - v) * gscale/(B*per_sample) ). */
 int vds_flow_loss(const void* v, const void* out, float* loss_out, float* per_sample, void* dout,
                   float gscale, int32_t B, int64_t per_sample_n, vds_stream_t stream);
+/* its backward for an arbitrary upstream gradient (autograd of train.py:121-125 under `(loss * s).backward()`,
+ * loss scaling, micro-batch accumulation): dout = bf16( 2 (out - v) * *gloss_dev / (B*per_sample) ), the upstream
+ * scalar read from device memory (no host synchronisation; graph-capturable).  B*per_sample % 8 == 0. */
+int vds_flow_loss_bwd(const void* v, const void* out, const float* gloss_dev, void* dout, int32_t B,
+                      int64_t per_sample_n, vds_stream_t stream);
 
 /* ------------------------------------------------------------ sampler --
  * One Euler step of sampling/sample.py:139-146:  out = uncond + cfg_scale*(cond - uncond) in bf16

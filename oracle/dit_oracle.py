@@ -191,10 +191,62 @@ def apply_rotary(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
 def attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
     """softmax(q k^T / sqrt(hd)) v, full, no mask (F.scaled_dot_product_attention,
     model.py:136,157).  Scores/softmax in fp32 (what flash kernels do), output in q.dtype."""
+    if q.shape[:-2].numel() * q.shape[-2] * k.shape[-2] > CHUNKED_ATTENTION_ABOVE:
+        return _ChunkedAttention.apply(q, k, v)  # same math, scores never materialised for all queries at once
     scale = 1.0 / math.sqrt(q.shape[-1])
     s = (q.float() @ k.float().transpose(-1, -2)) * scale
     p = torch.softmax(s, dim=-1)
     return (p @ v.float()).to(q.dtype)
+
+
+CHUNKED_ATTENTION_ABOVE = 1 << 29  # score elements (2 GiB of fp32): BASELINE config 4 (33 808 tokens) needs 73 GB otherwise
+
+
+def attention_chunked(q: Tensor, k: Tensor, v: Tensor, do: Optional[Tensor] = None, chunk: int = 1024):
+    """The same softmax(q k^T / sqrt(hd)) v (model.py:136,157) evaluated one block of `chunk` query rows at
+    a time in fp32, with the closed-form backward of SDPA (dV = P^T dO, dP = dO V^T,
+    dS = P o (dP - rowsum(dO o O)), dQ = dS K / sqrt(hd), dK = dS^T Q / sqrt(hd)).
+    Returns (o, lse) or (o, lse, dq, dk, dv), all fp32.  Pinned against `attention` + autograd by
+    tests/test_oracle_golden.py."""
+    qf, kf, vf = q.float(), k.float(), v.float()
+    scale = 1.0 / math.sqrt(q.shape[-1])
+    Lq = q.shape[-2]
+    o = torch.empty_like(qf)
+    lse = torch.empty(q.shape[:-1], dtype=torch.float32)
+    if do is not None:
+        dof = do.float()
+        dq, dk, dv = torch.empty_like(qf), torch.zeros_like(kf), torch.zeros_like(vf)
+    for r0 in range(0, Lq, chunk):
+        r1 = min(Lq, r0 + chunk)
+        s = (qf[..., r0:r1, :] @ kf.transpose(-1, -2)) * scale
+        l = torch.logsumexp(s, dim=-1)
+        p = torch.exp(s - l[..., None])
+        oc = p @ vf
+        o[..., r0:r1, :], lse[..., r0:r1] = oc, l
+        if do is not None:
+            doc = dof[..., r0:r1, :]
+            dv += p.transpose(-1, -2) @ doc
+            ds = p * (doc @ vf.transpose(-1, -2) - (doc * oc).sum(-1, keepdim=True))
+            dq[..., r0:r1, :] = (ds @ kf) * scale
+            dk += (ds.transpose(-1, -2) @ qf[..., r0:r1, :]) * scale
+    return (o, lse) if do is None else (o, lse, dq, dk, dv)
+
+
+class _ChunkedAttention(torch.autograd.Function):
+    """`attention` for sequences whose score matrix does not fit in host memory (autograd wrapper of
+    attention_chunked; the backward recomputes the probabilities chunk by chunk)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        o, _ = attention_chunked(q, k, v)
+        ctx.save_for_backward(q, k, v)
+        return o.to(q.dtype)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v = ctx.saved_tensors
+        _, _, dq, dk, dv = attention_chunked(q, k, v, do)
+        return dq.to(q.dtype), dk.to(k.dtype), dv.to(v.dtype)
 
 
 def split_heads(x: Tensor, n: int, H: int) -> Tuple[Tensor, ...]:

@@ -11,7 +11,8 @@ def test_amax_history_rolls_without_losing_scales():
     h.roll()                       # first training forward: nothing recorded yet, still no history
     assert not h.ready and float(h.tab.abs().sum()) == 0
     h.cur(0).fill_(2.0)
-    h.cur(1).fill_(5.0)            # row 2 recorded nothing (e.g. its backward never ran)
+    h.cur(1).fill_(5.0)            # row 2 recorded nothing
+    h.backward_done()              # the step completed (DiT._backward_impl)
     h.roll()
     assert h.ready
     assert h.prev(0).item() == 2.0 and h.prev(1).item() == 5.0 and h.prev(2).item() == 0.0
@@ -22,6 +23,21 @@ def test_amax_history_rolls_without_losing_scales():
     # views alias the table (the kernels write through them)
     torch.maximum(h.cur(2), torch.tensor([7.0]), out=h.cur(2))
     assert h.tab[2, 1].item() == 7.0
+
+
+def test_amax_history_needs_a_completed_backward_before_delayed_scaling():
+    """a grad-enabled forward whose backward never ran (validation loss outside no_grad, an exception) leaves
+    the gradient rows without an amax: delayed scaling must stay off until a full step has been recorded"""
+    h = F8.AmaxHistory(2, "cpu")
+    h.roll()
+    h.cur(0).fill_(1.5)            # forward row only; the backward (row 1) never happens
+    h.roll()
+    assert not h.ready and h.prev(0).item() == 1.5 and h.prev(1).item() == 0.0
+    h.cur(0).fill_(2.5)
+    h.cur(1).fill_(1e-5)
+    h.backward_done()
+    h.roll()
+    assert h.ready and abs(h.prev(1).item() - 1e-5) < 1e-9
 
 
 def test_alignment_rule_of_the_fp8_linears():

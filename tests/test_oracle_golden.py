@@ -178,3 +178,25 @@ def test_g5_sampler_euler_cfg(golden_dir):
     acc1 = O.sample_euler_cfg(P, cfg, r["latents0"], ctx, torch.zeros_like(ctx), 2, 1.0, r["rope_starts"],
                               dtype=torch.float32)
     assert torch.isfinite(acc1).all()
+
+
+def test_chunked_attention_equals_plain_attention(monkeypatch):
+    """the long-sequence path of the oracle (query-chunked SDPA with its closed-form backward, used above
+    2^29 score elements: BASELINE config 4) equals the plain softmax(QK^T)V + autograd path"""
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(2, 3, n, 72, generator=g) for n in (301, 217, 217))
+    do = torch.randn(2, 3, 301, 72, generator=g)
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o_ref = O.attention(qa, ka, va)
+    o_ref.backward(do)
+    o, lse, dq, dk, dv = O.attention_chunked(q, k, v, do, chunk=64)
+    s = (q @ k.transpose(-1, -2)) / 72 ** 0.5
+    assert rel(o, o_ref.detach()) < 1e-6 and rel(lse, torch.logsumexp(s, -1)) < 1e-6
+    assert rel(dq, qa.grad) < 1e-5 and rel(dk, ka.grad) < 1e-5 and rel(dv, va.grad) < 1e-5
+    # and `attention` itself switches to it (autograd wrapper) above the threshold
+    monkeypatch.setattr(O, "CHUNKED_ATTENTION_ABOVE", 1000)
+    qb, kb, vb = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o2 = O.attention(qb, kb, vb)
+    o2.backward(do)
+    assert rel(o2.detach(), o_ref.detach()) < 1e-6 and rel(qb.grad, qa.grad) < 1e-5
+    assert rel(kb.grad, ka.grad) < 1e-5 and rel(vb.grad, va.grad) < 1e-5

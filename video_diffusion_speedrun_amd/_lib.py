@@ -86,6 +86,7 @@ SIGNATURES = {
     "vds_registers_bwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp],
     "vds_noise_latents": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
     "vds_flow_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i64, c_vp],
+    "vds_flow_loss_bwd": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
     "vds_cfg_euler_step": [c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i64, c_vp],
     "vds_adamw_multi": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32, c_vp],
     "vds_adamw_multi_dev": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_f32, c_vp],

@@ -22,14 +22,23 @@ import torch
 import torch.distributed as dist
 
 
-def _rank_world():
+def _rank_world(model=None):
+    """(rank, world) of the communicator the model is sharded over (apply_fsdp's process_group; the
+    default group when none was given)."""
+    if model is not None and getattr(model, "_world", 1) > 1:
+        return model._rank, model._world
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 
 
+def _barrier(model=None):
+    if dist.is_initialized():
+        dist.barrier(group=getattr(model, "_pg", None))
+
+
 def save_checkpoint(path: str, model, optimizer=None, step: int = 0, dcp: bool = False) -> None:
-    rank, world = _rank_world()
+    rank, world = _rank_world(model)
     os.makedirs(path, exist_ok=True)
     state = model.full_state_dict()  # collective when sharded: every rank calls it
     if rank == 0:
@@ -41,36 +50,41 @@ def save_checkpoint(path: str, model, optimizer=None, step: int = 0, dcp: bool =
     if optimizer is not None:
         torch.save({"optimizer": optimizer.state_dict(), "step": int(step), "rank": rank, "world": world},
                    os.path.join(path, f"optim_rank{rank}_of{world}.pt"))
-    if dist.is_initialized():
-        dist.barrier()
+    _barrier(model)
 
 
-def read_model_state(path: str) -> Dict[str, torch.Tensor]:
-    """full fp32 tensors keyed like the reference state dict, from model.pt, a reference
-    `temp.pt` (plain state dict) or a DCP directory (ours or the reference's)."""
+def _read(path: str, model=None):
+    """(state dict of full fp32 tensors, stored step) from model.pt, a reference `temp.pt` (plain state
+    dict) or a DCP directory (ours or the reference's).  Every file is read with weights_only=True: the
+    stored objects are tensors, numbers, tuples, lists and dicts only."""
     if os.path.isfile(path):
-        obj = torch.load(path, map_location="cpu", weights_only=False)
+        obj = torch.load(path, map_location="cpu", weights_only=True)
     elif os.path.isfile(os.path.join(path, "model.pt")):
-        obj = torch.load(os.path.join(path, "model.pt"), map_location="cpu", weights_only=False)
+        obj = torch.load(os.path.join(path, "model.pt"), map_location="cpu", weights_only=True)
     else:
         from torch.distributed.checkpoint.format_utils import dcp_to_torch_save
         d = os.path.join(path, "dcp") if os.path.isdir(os.path.join(path, "dcp")) else path
         tmp = os.path.join(path, "temp.pt")  # the reference's own conversion target (train.py:298-300)
-        if _rank_world()[0] == 0 and not os.path.exists(tmp):
+        if _rank_world(model)[0] == 0 and not os.path.exists(tmp):
             dcp_to_torch_save(d, tmp)
-        if dist.is_initialized():
-            dist.barrier()
-        obj = torch.load(tmp, map_location="cpu", weights_only=False)
-    state = obj["model"] if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict) else obj
+        _barrier(model)
+        obj = torch.load(tmp, map_location="cpu", weights_only=True)
+    wrapped = isinstance(obj, dict) and isinstance(obj.get("model"), dict)
+    state = obj["model"] if wrapped else obj
+    step = int(obj.get("step", 0)) if wrapped else 0
     # strip the wrappers' prefixes like train.py:305-310
-    return {k.replace("module.", "").replace("_orig_mod.", ""): v for k, v in state.items() if torch.is_tensor(v)}
+    return {k.replace("module.", "").replace("_orig_mod.", ""): v for k, v in state.items() if torch.is_tensor(v)}, step
+
+
+def read_model_state(path: str) -> Dict[str, torch.Tensor]:
+    return _read(path)[0]
 
 
 def load_checkpoint(path: str, model, optimizer=None) -> int:
     """Loads the weights into `model` (plain or already sharded) and, when present for this
     rank / world size, the optimizer shard.  Returns the stored step (0 for reference checkpoints)."""
-    rank, world = _rank_world()
-    state = read_model_state(path)
+    rank, world = _rank_world(model)
+    state, step = _read(path, model)
     own = dict(model.named_parameters())
     missing = [k for k in own if k not in state]
     if missing:
@@ -88,15 +102,11 @@ def load_checkpoint(path: str, model, optimizer=None) -> int:
                         continue
                     g0 = g.rank * g.shard + lo - g.offsets[n]
                     g.master[lo:hi].copy_(state[n].reshape(-1)[g0:g0 + (hi - lo)].to(g.master.device, torch.float32))
-                g.shadow_fresh = False
-    step = 0
-    meta = os.path.join(path, "model.pt") if os.path.isdir(path) else None
-    if meta and os.path.isfile(meta):
-        step = int(torch.load(meta, map_location="cpu", weights_only=False).get("step", 0))
+                g.invalidate_shadow()  # the master was written behind the parameters' version counters
     if optimizer is not None and os.path.isdir(path):
         f = os.path.join(path, f"optim_rank{rank}_of{world}.pt")
         if os.path.isfile(f):
-            blob = torch.load(f, map_location="cpu", weights_only=False)
+            blob = torch.load(f, map_location="cpu", weights_only=True)
             optimizer.load_state_dict(blob["optimizer"])
             step = int(blob.get("step", step))
     return step

@@ -694,6 +694,21 @@ __global__ __launch_bounds__(256) void flow_loss_kernel(const bf16_t* v, const b
   }
 }
 
+// d(loss)/d(out) for an upstream gradient held in device memory; 8 elements per thread, 16-byte accesses
+__global__ __launch_bounds__(256) void flow_loss_bwd_kernel(const bf16_t* v, const bf16_t* out, const float* gloss,
+                                                            bf16_t* dout, float inv_n, long n8) {
+  const float k = 2.0f * gloss[0] * inv_n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    float a[8], b[8];
+    unpack8(*reinterpret_cast<const u32x4*>(out + i * 8), a);
+    unpack8(*reinterpret_cast<const u32x4*>(v + i * 8), b);
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = pack_bf2((a[2 * e] - b[2 * e]) * k, (a[2 * e + 1] - b[2 * e + 1]) * k);
+    *reinterpret_cast<u32x4*>(dout + i * 8) = w;
+  }
+}
+
 // Euler + classifier-free-guidance update of the sampler (sampling/sample.py:139-146), with the
 // reference's bf16 rounding points: out = bf16(u + bf16(cfg * bf16(c - u))) when guided, acc(f32) += dt * out,
 // latents = bf16(acc).  8 elements per thread, 16-byte accesses.
@@ -994,6 +1009,17 @@ extern "C" int vds_flow_loss(const void* v, const void* out, float* loss_out, fl
   if (bps > 256) bps = 256;
   hipLaunchKernelGGL(flow_loss_kernel, dim3(bps, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v,
                      (const bf16_t*)out, loss_out, per_sample, (bf16_t*)dout, gscale, B, (long)per_sample_n, bps);
+  return ok();
+}
+
+extern "C" int vds_flow_loss_bwd(const void* v, const void* out, const float* gloss_dev, void* dout, int32_t B,
+                                 int64_t per_sample_n, vds_stream_t stream) {
+  const long n = (long)B * per_sample_n;
+  if (!v || !out || !gloss_dev || !dout || n <= 0 || (n & 7)) return VDS_ERR_ARG;
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(flow_loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)v, (const bf16_t*)out, gloss_dev, (bf16_t*)dout, 1.0f / (float)n, n / 8);
   return ok();
 }
 

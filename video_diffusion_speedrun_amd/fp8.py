@@ -67,23 +67,32 @@ class Q:
 
 
 class AmaxHistory:
-    """Delayed-scaling state of the epilogue-emitted tensors: one (previous, current) amax pair per tensor in a
-    single device table; `roll()` at the start of a training forward makes the last step's amax the scale source
-    of this step.  No host synchronisation anywhere."""
+    """Delayed-scaling state of the quantised tensors: one (previous, current) amax pair per tensor in a single
+    device table; `roll()` at the start of a training forward makes the last step's amax the scale source of
+    this step.  No host synchronisation anywhere.
+
+    `ready` (quantise with the previous step's amax) turns on only after a COMPLETE step -- forward and backward --
+    has been recorded: the gradient rows are written in backward only, so a grad-enabled forward that is never
+    followed by its backward (a validation loss outside no_grad, an exception) must not arm delayed scaling with
+    amax 0 for them.  Once on, a row that recorded nothing in some later step keeps its older scale."""
 
     def __init__(self, n: int, device):
         self.tab = torch.zeros(n, 2, dtype=f32, device=device)
-        self.ready = False   # True once a complete training step has recorded every amax
-        self._armed = False
+        self.ready = False
+        self._fwd_seen = False   # a training forward recorded its rows since the last roll
+        self._bwd_seen = False   # ... and its backward completed (host flag set by DiT._backward_impl)
 
     def roll(self):
-        if self._armed:
+        if self._fwd_seen:
             cur = self.tab[:, 1]
-            # a tensor that recorded nothing last step (a forward whose backward never ran) keeps its older scale
             self.tab[:, 0].copy_(torch.where(cur > 0, cur, self.tab[:, 0]))
             cur.zero_()
-            self.ready = True
-        self._armed = True
+            if self._bwd_seen:
+                self.ready = True
+        self._fwd_seen, self._bwd_seen = True, False
+
+    def backward_done(self):
+        self._bwd_seen = True
 
     def prev(self, i: int):
         return self.tab[i, 0:1]

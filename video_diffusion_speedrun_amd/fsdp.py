@@ -157,8 +157,9 @@ def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32
     full_values = {n: p.data.detach().clone() for n, p in dit_model.named_parameters()}
     dit_model._world, dit_model._rank, dit_model._pg = world, rank, process_group
     root, blocks = dit_model._group_members()
-    groups = [FlatGroup("root", root, world, rank)]
-    groups += [FlatGroup(f"blocks.{i}", m, world, rank) for i, m in enumerate(blocks)]
+    pg = process_group if world_rank is None else None
+    groups = [FlatGroup("root", root, world, rank, pg)]
+    groups += [FlatGroup(f"blocks.{i}", m, world, rank, pg) for i, m in enumerate(blocks)]
     run = world > 1 or (force_runtime and (dist.is_initialized() or world_rank is not None))
     for g in groups:
         g.materialize(device, full_values, separate=run)  # W=1 + runtime: real collectives into separate buffers

@@ -101,6 +101,11 @@ class GraphedTrainStep:
                 self._capture()
             self._draw_rope()
             self.opt.advance()
+            # the captured step holds no fp32 -> bf16 cast (the optimizer kernel writes both copies): parameters
+            # written from outside since the last step (load_state_dict, EMA swap, p.mul_()) are re-cast here
+            from . import ops
+            for g in self.model._groups:
+                g.refresh_shadow(ops.cast_f32_bf16)
             self.graph.replay()
             self.n_replays += 1
             loss = self.loss.detach()

@@ -24,7 +24,6 @@ There is no CPU fallback: a CPU tensor or a missing libvds_hip.so raises.
 from __future__ import annotations
 
 import math
-from collections import defaultdict
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -236,8 +235,8 @@ class DiT(nn.Module):
         if self._groups is not None and self._world > 1:
             raise RuntimeError("parameters of a sharded DiT were replaced; re-apply apply_fsdp")
         root, blocks = self._group_members()
-        groups = [FlatGroup("root", root, self._world, self._rank)]
-        groups += [FlatGroup(f"blocks.{i}", m, self._world, self._rank) for i, m in enumerate(blocks)]
+        groups = [FlatGroup("root", root, self._world, self._rank, self._pg)]
+        groups += [FlatGroup(f"blocks.{i}", m, self._world, self._rank, self._pg) for i, m in enumerate(blocks)]
         for g in groups:
             g.materialize(device, full_values)
         self._groups = groups
@@ -447,6 +446,17 @@ class DiT(nn.Module):
         dev = dout.device
         fs = self._fsdp
         R = self.root_group
+        # gradients already held in p.grad (a second backward before zero_grad: micro-batch accumulation, like
+        # autograd's accumulate-into-.grad in the reference loop) are set aside and added back at the end
+        held = None
+        if any(p.grad is not None for g in self._groups for p in g.params.values()):
+            for g in self._groups:
+                for p in g.params.values():
+                    if p.grad is not None and p.grad.data_ptr() != p._vds_grad_view.data_ptr():
+                        raise RuntimeError("DiT backward: a parameter's .grad was replaced by a foreign tensor; "
+                                           "call zero_grad(set_to_none=True) before backward")
+            held = [g.gshard.clone() if any(p.grad is not None for p in g.params.values()) else None
+                    for g in self._groups]
         for g in self._groups:
             g.gfull.zero_()
         if fs is not None:
@@ -497,6 +507,12 @@ class DiT(nn.Module):
         else:
             for g in self._groups:
                 g.publish_grads()
+        if held is not None:
+            for g, h in zip(self._groups, held):
+                if h is not None:
+                    g.gshard.add_(h)
+        if self.fp8 and getattr(self, "_fp8_hist", None) is not None:
+            self._fp8_hist.backward_done()
 
     def _block_bwd(self, i, bs, dX, sv, dc, dv0, B, L, Lc):
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
@@ -594,49 +610,54 @@ class DiT(nn.Module):
 
     # ------------------------------------------------------------------- muP table ----
     def get_mup_setup(self, learning_rate, weight_decay, constant_param_classes):
-        """Per-parameter lr / weight-decay groups, same rule cascade and return value as the
-        reference (model.py:404-465)."""
-        no_decay_name_list = ["bias", "norm", "lambda"]
-        custom_lr_multipliers = {"bias": 0.01, "norm": 0.01, "lambda": 0.01}
-        final_optimizer_settings = {}
-        param_groups = defaultdict(lambda: {"params": [], "weight_decay": None, "lr": None})
-        for n, p in self.named_parameters():
-            n = n.replace("_fsdp_wrapped_module.", "")
-            status = self.paramstatus[n]
-            if not status["requires_grad"]:
+        """muP-style per-parameter (lr, weight decay) table; same contract as the reference
+        (model.py:404-465): returns (optimizer param groups -- one per distinct (lr, wd) pair, in first-use
+        order --, {name: {"lr", "wd", "shape"}}).  The cascade, later stages overriding earlier ones:
+          1. vectors / scalars (name has bias | norm | lambda): lr/100, no decay; matrices: lr * 32/fan_in and
+             wd * fan_in/1024, fan_in = last dim of the FULL tensor shape;
+          2. names containing one of `constant_param_classes`: lr/100, no decay;
+          3. names containing "time", then "modulation": lr/10 (decay untouched)."""
+        table, buckets = {}, {}
+        for name, p in self.named_parameters():
+            name = name.replace("_fsdp_wrapped_module.", "")  # the prefix the reference strips (model.py:417)
+            info = self.paramstatus[name]
+            if not info["requires_grad"]:
                 continue
-            if any(k in n for k in no_decay_name_list):
-                for k in no_decay_name_list:
-                    if k in n:
-                        lr_value = learning_rate * custom_lr_multipliers[k]
-                        break
-                wd_value = 0.0
+            fan_in = info["shape"][-1]
+            if "bias" in name or "norm" in name or "lambda" in name:
+                lr, wd = learning_rate * 0.01, 0.0
             else:
-                hidden_dim = status["shape"][-1]
-                lr_value = learning_rate * (32 / hidden_dim)
-                wd_value = weight_decay * hidden_dim / 1024
-            if any(cls in n for cls in constant_param_classes):
-                lr_value = learning_rate * 0.01
-                wd_value = 0.0
-            if "time" in n:
-                lr_value = learning_rate * 0.1
-            if "modulation" in n:
-                lr_value = learning_rate * 0.1
-            key = (lr_value, wd_value)
-            param_groups[key]["params"].append(p)
-            param_groups[key]["weight_decay"] = wd_value
-            param_groups[key]["lr"] = lr_value
-            final_optimizer_settings[n] = {"lr": lr_value, "wd": wd_value, "shape": status["shape"]}
-        return [v for v in param_groups.values()], final_optimizer_settings
+                lr, wd = learning_rate * (32 / fan_in), weight_decay * fan_in / 1024
+            if any(c in name for c in constant_param_classes):
+                lr, wd = learning_rate * 0.01, 0.0
+            for tag in ("time", "modulation"):
+                if tag in name:
+                    lr = learning_rate * 0.1
+            bucket = buckets.setdefault((lr, wd), {"params": [], "weight_decay": wd, "lr": lr})
+            bucket["params"].append(p)
+            table[name] = {"lr": lr, "wd": wd, "shape": info["shape"]}
+        return list(buckets.values()), table
+
+    # --------------------------------------------------------------- state / copies ----
+    def invalidate_compute_copy(self):
+        """Force the next forward to re-cast the fp32 masters into the bf16 compute copies.  In-place writes
+        through the nn.Parameters are detected by themselves (FlatGroup.mark_shadow_fresh); call this after
+        writing parameter memory some other way (`p.data.xxx_()`, raw pointers, custom kernels)."""
+        for g in self._groups or []:
+            g.invalidate_shadow()
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        r = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self.invalidate_compute_copy()
+        return r
 
     def full_state_dict(self) -> Dict[str, torch.Tensor]:
-        """fp32 full tensors keyed like the reference state dict (gathers when sharded)."""
+        """fp32 full tensors keyed like the reference state dict (one all-gather per group when sharded)."""
         if self._groups is None:
             return {k: v.detach().clone() for k, v in self.state_dict().items()}
         out = {}
         for g in self._groups:
-            for n in g.names:
-                out[n] = g.full_tensor(n)
+            out.update(g.full_tensors())
         return out
 
 

@@ -361,6 +361,16 @@ def flow_loss(v, out, want_grad: bool, gscale: float = 1.0):
     return acc[0], acc[1:], dout
 
 
+def flow_loss_bwd(v, out, gloss):
+    """d loss / d out = 2 (out - v) gloss / numel, bf16; gloss: f32 device scalar (the upstream gradient)"""
+    B = v.shape[0]
+    assert gloss.is_cuda and gloss.dtype == f32 and gloss.numel() == 1 and out.is_contiguous() and v.is_contiguous()
+    dout = torch.empty_like(out)
+    check(_lib.load().vds_flow_loss_bwd(_p(v), _p(out), _p(gloss), _p(dout), B, v.numel() // B, _stream()),
+          "vds_flow_loss_bwd")
+    return dout
+
+
 def cfg_euler_step(cond, uncond, acc, latents, cfg_scale: float, dt: float):
     """acc (f32) += dt * (uncond + cfg*(cond-uncond)) [bf16 math like the reference]; latents = bf16(acc)."""
     n = cond.numel()

@@ -155,5 +155,5 @@ class MuAdamW(torch.optim.Optimizer):
         # the bf16 shadows of these flat groups are now current: the next forward skips its cast pass
         for g in {id(getattr(p, "_vds_group", None)): getattr(p, "_vds_group", None) for p, _ in plist}.values():
             if g is not None:
-                g.shadow_fresh = True
+                g.mark_shadow_fresh()
         return None

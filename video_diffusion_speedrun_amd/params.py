@@ -37,8 +37,9 @@ def _numel(shape) -> int:
 
 class FlatGroup:
     def __init__(self, name: str, named_params: Sequence[Tuple[str, torch.nn.Parameter]], world: int = 1,
-                 rank: int = 0):
+                 rank: int = 0, process_group=None):
         self.name, self.world, self.rank = name, world, rank
+        self.pg = process_group  # the shard group's communicator (None = the default group)
         self.names: List[str] = []
         self.shapes: Dict[str, Tuple[int, ...]] = {}
         self.offsets: Dict[str, int] = {}
@@ -57,7 +58,7 @@ class FlatGroup:
         self.device: Optional[torch.device] = None
         self.master = self.shadow = self.full = self.gfull = self.gshard = None
         self.gathered = False
-        self.shadow_fresh = False  # set by MuAdamW when it has written the bf16 shadow itself
+        self._fresh_versions = None  # see mark_shadow_fresh
 
     # ---- layout -------------------------------------------------------------------------
     def local_range(self, name: str) -> Tuple[int, int]:
@@ -101,7 +102,7 @@ class FlatGroup:
             self.gshard = torch.zeros(self.shard, dtype=torch.float32, device=device)
         self._repoint()
         self.gathered = False
-        self.shadow_fresh = False
+        self._fresh_versions = None
 
     def _repoint(self):
         for n in self.names:
@@ -131,12 +132,36 @@ class FlatGroup:
                 return False
         return True
 
+    # ---- bf16 compute copy bookkeeping ----------------------------------------------------
+    def mark_shadow_fresh(self):
+        """The writer of the fp32 master (MuAdamW's kernel) has written the bf16 shadow too, so the next
+        `gather` may skip its cast pass.  The claim is tied to the autograd version counters of the
+        parameters: any later in-place write through the nn.Parameters (`load_state_dict`, `p.mul_()`,
+        `clip_grad`-style `p.copy_()`, an EMA swap ...) bumps a counter and voids it.  Writers that bypass the
+        counters (`p.data.xxx_()`, raw pointers) must call `invalidate_shadow()` / `DiT.invalidate_compute_copy()`."""
+        self._fresh_versions = tuple(p._version for p in self.params.values())
+
+    def invalidate_shadow(self):
+        self._fresh_versions = None
+
+    @property
+    def shadow_fresh(self) -> bool:
+        return (self._fresh_versions is not None and
+                self._fresh_versions == tuple(p._version for p in self.params.values()))
+
+    def refresh_shadow(self, cast_fn) -> bool:
+        """cast master -> shadow unless the shadow is known to be current; returns True when it cast"""
+        if self.shadow_fresh:
+            return False
+        cast_fn(self.master, self.shadow)
+        self.mark_shadow_fresh()
+        return True
+
     # ---- per-step operations ------------------------------------------------------------
     def gather(self, cast_fn: Callable[[torch.Tensor, torch.Tensor], None], group=None, skip_cast=False):
         """bf16 compute copy of the whole group: cast the local fp32 chunk, all-gather (C3)."""
-        if not (skip_cast or self.shadow_fresh):
-            cast_fn(self.master, self.shadow)
-        self.shadow_fresh = False
+        if not skip_cast:
+            self.refresh_shadow(cast_fn)
         if self.world > 1 or (self.full is not self.shadow):
             all_gather_flat(self.full, self.shadow, group)
         self.gathered = True
@@ -165,10 +190,21 @@ class FlatGroup:
         """fp32 full value of a parameter (all-gathers the master pieces when sharded)."""
         if self.world == 1:
             return self.params[name].data.detach().clone()
+        return self.full_tensors([name])[name]
+
+    def full_tensors(self, names: Optional[Sequence[str]] = None) -> Dict[str, torch.Tensor]:
+        """fp32 full values of the group's parameters with ONE all-gather of the master shards (on the
+        group's own communicator)."""
+        names = list(self.names if names is None else names)
+        if self.world == 1:
+            return {n: self.params[n].data.detach().clone() for n in names}
         full = torch.empty(self.padded, dtype=torch.float32, device=self.device)
-        all_gather_flat(full, self.master, None)
-        o = self.offsets[name]
-        return full[o:o + _numel(self.shapes[name])].view(self.shapes[name]).clone()
+        all_gather_flat(full, self.master, self.pg)
+        out = {}
+        for n in names:
+            o = self.offsets[n]
+            out[n] = full[o:o + _numel(self.shapes[n])].view(self.shapes[n]).clone()
+        return out
 
 
 # ---- collectives (RCCL via torch.distributed "nccl"; gloo emulation for the CPU tests) -------

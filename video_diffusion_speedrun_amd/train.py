@@ -37,22 +37,21 @@ def encode_prompt_with_t5(text_encoder, tokenizer, max_sequence_length=512, prom
 
 
 class _FlowLoss(torch.autograd.Function):
-    """mean_b mean_{chw} (v - out)^2 in fp32 (train.py:121-125); HIP kernel for value and gradient."""
+    """mean_b mean_{chw} (v - out)^2 in fp32 (train.py:121-125); HIP kernels for value and gradient.  The
+    backward honours the upstream gradient (`(loss / n).backward()`, loss scaling): it is read from device
+    memory by the kernel, so nothing synchronises and a captured step stays replayable."""
 
     @staticmethod
     def forward(ctx, out, v):
-        loss, per, dout = ops.flow_loss(v, out, want_grad=ctx.needs_input_grad[0])
-        ctx.dout = dout
+        loss, per, _ = ops.flow_loss(v, out, want_grad=False)
+        ctx.save_for_backward(out, v)
         ctx.mark_non_differentiable(per)
         return loss.reshape(()), per
 
     @staticmethod
     def backward(ctx, gloss, _gper):
-        dout = ctx.dout
-        ctx.dout = None
-        # d loss / d out was produced by the forward kernel with unit upstream gradient; the only
-        # upstream the train loop ever supplies is 1.0 (loss.backward()).
-        return dout, None
+        out, v = ctx.saved_tensors
+        return ops.flow_loss_bwd(v, out, gloss.to(f32).reshape(1).contiguous()), None
 
 
 def flow_loss(out, v):
