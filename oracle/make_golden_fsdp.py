@@ -114,8 +114,9 @@ def worker(rank, world, port, tmp):
     loss = flow_loss(out, v)
     opt.zero_grad()
     loss.backward()
-    reduced = {n: p.grad.full_tensor().clone() for n, p in m.named_parameters()}  # collective
-    grad_dtype = {str(p.grad.dtype) for p in m.parameters()}
+    # blocks.0.lambda_param takes no part in the forward (block 0 has no v_0 to mix with): its grad stays None
+    reduced = {n: p.grad.full_tensor().clone() for n, p in m.named_parameters() if p.grad is not None}  # collective
+    grad_dtype = {str(p.grad.dtype) for p in m.parameters() if p.grad is not None}
     opt.step()
     after = {n: p.full_tensor().detach().clone() for n, p in m.named_parameters()}  # collective
     losses = [torch.zeros(()) for _ in range(world)]
@@ -137,7 +138,7 @@ def worker(rank, world, port, tmp):
                 torch.manual_seed(rope_seed)
                 o = ms(zt_r.to(dtype), ctx_r.to(dtype), t_r.to(dtype))
                 flow_loss(o, v_r).backward()
-                per_rank.append({n: p.grad.float().clone() for n, p in ms.named_parameters()})
+                per_rank.append({n: p.grad.float().clone() for n, p in ms.named_parameters() if p.grad is not None})
             single[key] = {n: sum(g[n] for g in per_rank) / world for n in per_rank[0]}
 
         def rel(a, b):
@@ -151,8 +152,10 @@ def worker(rank, world, port, tmp):
               "rope_table": TABLE, "rope_start": (start_t, start_h, start_w), "batch": full,
               "local_shapes_rank0": local_shapes, "placements": placements, "grad_dtype": sorted(grad_dtype),
               "losses": [float(l) for l in losses],
-              "reduced_grads": reduced, "single_bf16_mean_grads": single["bf16"],
-              "single_fp32_mean_grads": single["fp32"], "params_after_step": after,
+              # the mean of the two single-process bf16 gradients is NOT stored: it equals `reduced_grads` to the
+              # worst relative error recorded here (0.0 = bit-identical); the fp32 truth is regenerated by the oracle
+              "reduced_grads": reduced, "reduced_vs_single_bf16_mean_worst_rel": worst,
+              "reduced_vs_single_fp32_mean_worst_rel": worst32, "params_after_step": after,
               "settings": {k.replace("_fsdp_wrapped_module.", ""): {"lr": s["lr"], "wd": s["wd"]}
                            for k, s in settings.items()}}
         torch.save(fx, os.path.join(tmp, "g6_fsdp.pt"))

@@ -69,3 +69,24 @@ def test_load_into_flat_groups(tmp_path):
     assert all(g.is_current() for g in groups)
     sd = m2.full_state_dict()
     assert all(torch.equal(sd[k], P[k]) for k in P)
+
+
+def test_loads_the_checkpoint_directory_the_reference_wrote(tmp_path, golden_dir):
+    """tests/golden/g6_dcp was written by the reference's own save path -- `get_model_state_dict(dit_model)` +
+    `dcp.save` on a 2-rank FSDP model (train.py:553,581-584; oracle/make_golden_fsdp.py) -- and holds Shard(0)
+    pieces of both ranks plus the persistent `rope.freqs_hwt_*` buffers.  It must load here, before the flat
+    groups exist, with the values the reference had after its optimizer step."""
+    import shutil
+    from video_diffusion_speedrun_amd import checkpoint as ck
+    from video_diffusion_speedrun_amd.model import DiT
+    fx = torch.load(os.path.join(golden_dir, "g6_fsdp.pt"), weights_only=False)
+    d = str(tmp_path / "ref_ckpt")
+    shutil.copytree(os.path.join(golden_dir, "g6_dcp"), d)   # the loader writes temp.pt next to the shards
+    state = ck.read_model_state(d)
+    assert {"rope.freqs_hwt_cos", "rope.freqs_hwt_sin"} <= set(state)          # reference buffers: present, ignored
+    for n, want in fx["params_after_step"].items():
+        assert torch.equal(state[n], want), n
+    m = DiT(**fx["cfg"])
+    assert ck.load_checkpoint(d, m) == 0                                        # the reference stores no step
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), fx["params_after_step"][n]), n

@@ -561,40 +561,13 @@ def test_fp8_step_close_to_oracle(vds, D, H, lat):
         m(torch.randn(1, 16, 2, 6, 6).cuda(), ctx[:1].cuda(), t[:1].cuda(), rope_start=start)
 
 
-def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch):
-    """The sharded train step with world_size 2 on ONE GPU: two replicas (rank 0, rank 1) of the same model live in
-    this process with the real shard layout, stream / event choreography, HIP kernels and sharded optimizer; only
-    the two collectives are replaced by an in-process exchange (RCCL refuses two ranks on one device).  Each rank
-    takes its own micro-batch; after one step the concatenated parameter shards must equal the unsharded model
-    stepped on the concatenated batch (gradient = average over ranks, model.py:516-519)."""
+def _emulate_ranks(vds, monkeypatch, cfg, P, W):
+    """W replicas of one model in this process with the real shard layout, stream / event choreography, HIP kernels
+    and sharded optimizer; only the two collectives are replaced by an in-process exchange (RCCL refuses two ranks on
+    one device).  Returns (replicas, pending reduce-scatter inputs per group)."""
     from video_diffusion_speedrun_amd import params as PM
     from video_diffusion_speedrun_amd.fsdp import apply_fsdp
-    W = 2
-    cfg = O.DiTConfig(in_channels=16, hidden_size=128, depth=3, num_heads=2, cross_attn_input_size=64,
-                      residual_v=True, train_bias_and_rms=False)
-    P = O.init_params(cfg, seed=61, randomize_zero_init=True, init_std_factor=1.0)
-    g = torch.Generator().manual_seed(62)
-    x = torch.randn(4, 16, 4, 8, 8, generator=g).to(bf16).cuda()
-    ctx = torch.randn(4, 16, 64, generator=g).to(bf16).cuda()
-    t = torch.tensor([0.2, 0.5, 0.7, 0.9]).to(bf16).cuda()
-    v = torch.randn(4, 16, 4, 8, 8, generator=g).to(bf16).cuda()
-    start = (1, 2, 3)
-
-    def step(m, sl):
-        groups, _ = m.get_mup_setup(3e-3, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
-        opt = vds["optim"].MuAdamW(groups, betas=(0.95, 0.99))
-        out = m(x[sl], ctx[sl], t[sl], rope_start=start)
-        loss, _ = vds["train"].flow_loss(out, v[sl])
-        loss.backward()
-        return opt, loss
-
-    ref = build(vds, cfg, P)
-    opt, loss_ref = step(ref, slice(0, 4))
-    opt.step()
-    want = ref.full_state_dict()
-
-    reps, tokens = [], [object() for _ in range(W)]
-    pending = {}
+    reps, tokens, pending = [], [object() for _ in range(W)], {}
 
     def find(buf, attr):
         for r, m in enumerate(reps):
@@ -623,6 +596,38 @@ def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch):
         m = build(vds, cfg, P)
         reps.append(apply_fsdp(m, torch.bfloat16, torch.float32, process_group=tokens[r], world_rank=(W, r)))
         assert m._fsdp is not None and m._groups[1].world == W and m._groups[1].rank == r
+    return reps, pending
+
+
+def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch):
+    """The sharded train step with world_size 2 on ONE GPU (see _emulate_ranks).  Each rank takes its own
+    micro-batch; after one step the concatenated parameter shards must equal the unsharded model stepped on the
+    concatenated batch (gradient = average over ranks, model.py:516-519)."""
+    W = 2
+    cfg = O.DiTConfig(in_channels=16, hidden_size=128, depth=3, num_heads=2, cross_attn_input_size=64,
+                      residual_v=True, train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=61, randomize_zero_init=True, init_std_factor=1.0)
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(4, 16, 4, 8, 8, generator=g).to(bf16).cuda()
+    ctx = torch.randn(4, 16, 64, generator=g).to(bf16).cuda()
+    t = torch.tensor([0.2, 0.5, 0.7, 0.9]).to(bf16).cuda()
+    v = torch.randn(4, 16, 4, 8, 8, generator=g).to(bf16).cuda()
+    start = (1, 2, 3)
+
+    def step(m, sl):
+        groups, _ = m.get_mup_setup(3e-3, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
+        opt = vds["optim"].MuAdamW(groups, betas=(0.95, 0.99))
+        out = m(x[sl], ctx[sl], t[sl], rope_start=start)
+        loss, _ = vds["train"].flow_loss(out, v[sl])
+        loss.backward()
+        return opt, loss
+
+    ref = build(vds, cfg, P)
+    opt, loss_ref = step(ref, slice(0, 4))
+    opt.step()
+    want = ref.full_state_dict()
+
+    reps, pending = _emulate_ranks(vds, monkeypatch, cfg, P, W)
     opts, losses = [], []
     for r in range(W):
         o, l = step(reps[r], slice(2 * r, 2 * r + 2))
@@ -644,6 +649,73 @@ def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch):
     for n, p0 in reps[0].named_parameters():
         p1 = dict(reps[1].named_parameters())[n]
         assert p0.dim() == 1 and p0.numel() + p1.numel() == want[n].numel()
+
+
+def test_sharded_hip_step_matches_the_reference_fsdp_run(vds, monkeypatch, golden_dir):
+    """SURVEY 8(c) G5 on the HIP path: the inputs of the REFERENCE's own 2-rank `apply_fsdp` train step
+    (tests/golden/g6_fsdp.pt, oracle/make_golden_fsdp.py) through two emulated ranks of this build: per-rank losses,
+    the reduce-scattered gradient and the parameters after the sharded MuAdamW step vs what the reference produced
+    (both sides compute in bf16: gradients within 3e-2, the AdamW update direction cosine >= 0.98)."""
+    fx = torch.load(os.path.join(golden_dir, "g6_fsdp.pt"), weights_only=False)
+    cfg = O.DiTConfig(**fx["cfg"])
+    P = O.init_params(cfg, seed=fx["param_seed"], randomize_zero_init=True, init_std_factor=1.0)
+    W = fx["world"]
+    reps, pending = _emulate_ranks(vds, monkeypatch, cfg, P, W)
+    b, opts = fx["batch"], []
+    for r, m in enumerate(reps):
+        sl = slice(2 * r, 2 * r + 2)
+        groups, _ = m.get_mup_setup(fx["lr"], fx["wd"], fx["consts"])
+        opts.append(vds["optim"].MuAdamW(groups, betas=(0.95, 0.99)))
+        tt = O.time_shift(b["z"][sl].to(bf16))
+        zt, v = vds["ops"].noise_latents(b["latent"][sl].to(bf16).cuda(), b["noise"][sl].to(bf16).cuda(),
+                                         tt.float().cuda())
+        out = m(zt, b["context"][sl].to(bf16).cuda(), tt.cuda(), rope_start=tuple(fx["rope_start"]))
+        loss, _ = vds["train"].flow_loss(out, v)
+        loss.backward()
+        assert abs(loss.item() - fx["losses"][r]) <= 1e-2 * fx["losses"][r]
+    torch.cuda.synchronize()
+    for o in opts:
+        o.step()
+    torch.cuda.synchronize()
+    for gi, grp0 in enumerate(reps[0]._groups):
+        gflat = torch.cat([m._groups[gi].gshard for m in reps])
+        pflat = torch.cat([m._groups[gi].master for m in reps])
+        for n in grp0.names:
+            if n not in fx["reduced_grads"] or n.endswith("lambda_param"):
+                continue
+            o0, want_g = grp0.offsets[n], fx["reduced_grads"][n]
+            got_g = gflat[o0:o0 + want_g.numel()].view(want_g.shape)
+            assert rel(got_g, want_g) <= 3e-2 and cosine(got_g, want_g) >= 0.999, (n, rel(got_g, want_g))
+            want_p = fx["params_after_step"][n]
+            got_p = pflat[o0:o0 + want_p.numel()].view(want_p.shape)
+            assert rel(got_p, want_p) <= 1e-3, (n, rel(got_p, want_p))
+            if want_p.numel() >= 1024:   # direction of the first AdamW update (~ lr * sign(g)): sensitive to small g
+                assert cosine(got_p.cpu() - P[n], want_p - P[n]) >= 0.98, n
+
+
+def test_reference_written_checkpoint_loads_on_the_gpu(vds, tmp_path, golden_dir):
+    """the DCP directory the reference wrote (tests/golden/g6_dcp: `get_model_state_dict` + `dcp.save` of its 2-rank
+    FSDP model, train.py:553,581-584) loaded into a live GPU model -- flat groups already materialised -- gives the
+    same forward as a model built directly from the reference's parameters"""
+    import shutil
+    from video_diffusion_speedrun_amd import checkpoint as ck
+    fx = torch.load(os.path.join(golden_dir, "g6_fsdp.pt"), weights_only=False)
+    cfg = O.DiTConfig(**fx["cfg"])
+    d = str(tmp_path / "ref_ckpt")
+    shutil.copytree(os.path.join(golden_dir, "g6_dcp"), d)
+    m = build(vds, cfg, O.init_params(cfg, seed=1234, randomize_zero_init=True, init_std_factor=1.0))
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 16, 4, 8, 8, generator=g).to(bf16).cuda()
+    ctx = torch.randn(2, 6, 64, generator=g).to(bf16).cuda()
+    t = torch.tensor([0.25, 0.75]).cuda()
+    with torch.no_grad():
+        m(x, ctx, t, rope_start=(1, 2, 3))                       # materialises the flat groups and bf16 copies
+        assert ck.load_checkpoint(d, m) == 0
+        got = m(x, ctx, t, rope_start=(1, 2, 3))
+        want = build(vds, cfg, fx["params_after_step"])(x, ctx, t, rope_start=(1, 2, 3))
+    assert torch.equal(got, want)
+    sd = m.full_state_dict()
+    assert all(torch.equal(sd[n].cpu(), w) for n, w in fx["params_after_step"].items())
 
 
 def test_parameter_writes_after_a_step_reach_the_next_forward(vds):

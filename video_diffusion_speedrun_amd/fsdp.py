@@ -38,6 +38,21 @@ def get_device_mesh(world_size: Optional[int] = None):
     return {"dp_replicate": 1, "dp_shard": w, "tp": 1}
 
 
+def reference_local_shape(shape, world: int, rank: int):
+    """Shape of the piece of a parameter that rank `rank` holds under the REFERENCE's wrap (FSDP2 `fully_shard`,
+    model.py:523-541: every parameter a `Shard(0)` DTensor, dim 0 cut into `world` chunks of ceil(dim0 / world)
+    rows, trailing ranks possibly empty).  This build shards differently on purpose -- contiguous chunks of one
+    flat buffer per group (params.FlatGroup) -- so this is only needed where the two layouts meet: reading or
+    writing `torch.distributed.checkpoint` shards, and the parity test against the reference's recorded shapes
+    (tests/golden/g6_fsdp.pt)."""
+    shape = tuple(int(s) for s in shape)
+    if not shape:
+        return shape
+    chunk = -(-shape[0] // world)
+    rows = max(0, min(shape[0], (rank + 1) * chunk) - rank * chunk)
+    return (rows,) + shape[1:]
+
+
 class ShardRuntime:
     """Stream / event choreography of the per-group collectives around DiT's explicit
     forward / backward kernel sequences (model.py hooks `pre_forward_*` ... `post_backward_*`)."""
