@@ -2,6 +2,7 @@
 """Train-step throughput of the HIP video-DiT hot path (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps K --warmup W                      # one GPU
+    python bench.py --gpus N --steps K --warmup W                      # starts N ranks itself (child torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W         # N GPUs, one rank each (RCCL)
 
@@ -28,6 +29,37 @@ if REPO not in sys.path:
 # multi-process GPU work on this pool needs dmabuf IPC; the HSA runtime reads this when the first HIP call
 # initialises it, so it is set before torch is imported
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+
+def _spawn_ranks_if_needed():
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves as a CHILD
+    `torch.distributed.run` (like run_debug.sh:12 of the reference) and relay its output and exit code.  This runs
+    before torch is imported, i.e. before anything in this process can have touched the GPU."""
+    if "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd))
+
+
+if __name__ == "__main__":
+    _spawn_ranks_if_needed()
 
 import torch
 import torch.distributed as dist
@@ -148,8 +180,10 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using {world} rank(s)", file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    if world > 1 and dist.get_world_size() != world:
+        raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {world}")
 
     from video_diffusion_speedrun_amd import ops
     from video_diffusion_speedrun_amd.fsdp import apply_fsdp
@@ -165,11 +199,13 @@ def main():
         model.enable_fp8()
     if world > 1:
         model = apply_fsdp(model, torch.bfloat16, torch.float32)
+        model._fsdp.measure = True
     elif args.force_shard_runtime:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
         model = apply_fsdp(model, torch.bfloat16, torch.float32, force_runtime=True)
+        model._fsdp.measure = True
     groups, _ = model.get_mup_setup(1e-4, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
     opt = MuAdamW(groups, betas=(0.95, 0.99))
     sched = get_schedule(opt, "cosine", 20, 10000)
@@ -216,6 +252,10 @@ def main():
 
     # ---- timed region: exactly K steps between barrier + synchronize --------------------------
     sync()
+    fs = getattr(model, "_fsdp", None)
+    if fs is not None:
+        fs.exposed_comm_ms()  # drop the warm-up's stall records
+        n_ag0, n_rs0 = fs.n_all_gather, fs.n_reduce_scatter
     if dominant is not None and graphed is None:
         ops.prof_enable(1 << names.index(dominant))  # events around the dominant kernel's launches only
     t0 = time.perf_counter()
@@ -228,6 +268,26 @@ def main():
     else:
         dom = ops.prof_collect().get(dominant) if dominant is not None else None
     ops.prof_enable(0)
+    comm_info = None
+    if fs is not None:  # sharded run: what the communicator saw, per rank
+        from video_diffusion_speedrun_amd import comm
+        mine = torch.tensor([dt / args.steps * 1e3, fs.exposed_comm_ms() / args.steps], device=device,
+                            dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        ci = comm.info()
+        gbytes = sum(g.padded for g in model._groups)
+        comm_info = {"backend": "vds_comm (RCCL from csrc/comm.hip)" if ci["active"] else "torch.distributed nccl",
+                     "communicator_world": ci["world"] if ci["active"] else dist.get_world_size(),
+                     "rccl_version": ci["rccl_version"], "reduce_scatter_schedule": ci["schedule"],
+                     "all_gathers_per_step": (fs.n_all_gather - n_ag0) / args.steps,
+                     "reduce_scatters_per_step": (fs.n_reduce_scatter - n_rs0) / args.steps,
+                     "all_gather_bytes_per_step": 2 * gbytes, "reduce_scatter_bytes_per_step": 4 * gbytes,
+                     "per_rank_ms_per_step": [round(float(t[0]), 3) for t in allr],
+                     "per_rank_exposed_comm_ms_per_step": [round(float(t[1]), 3) for t in allr]}
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -253,6 +313,9 @@ def main():
             "loss": loss_val,
             "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
         }
+        if comm_info is not None:
+            assert comm_info["communicator_world"] == world, comm_info
+            out["comm"] = comm_info
         if dom:
             mfma_bound = dom["flops"] > 0
             if mfma_bound:
@@ -288,6 +351,8 @@ def main():
     if world > 1:
         dist.barrier()
     if dist.is_initialized():
+        from video_diffusion_speedrun_amd import comm
+        comm.destroy()
         dist.destroy_process_group()
 
 

@@ -134,6 +134,8 @@ typedef struct vds_attn_args {
 
 int vds_attn_fwd(const vds_attn_args* args, vds_stream_t stream);
 int vds_attn_bwd(const vds_attn_args* args, vds_stream_t stream);
+/* bytes of the caller-allocated `delta` workspace vds_attn_bwd needs for these B, H, Lq (2*B*H*Lq floats) */
+size_t vds_attn_bwd_workspace_bytes(const vds_attn_args* args);
 
 /* ------------------------------------------------------ normalisation / modulation ---
  * y = bf16( rmsnorm(x)[*w] * (1 + scale[b]) + shift[b] ), rstd saved (model.py:34-41,123,144,164,389).
@@ -176,6 +178,14 @@ int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, const float
                      const float* sinb, const void* qkv_raw, const void* v0, const void* lam,
                      float* dv0_acc, float* dlam, void* dqkv, int32_t mix, int32_t add_dv0, int32_t B,
                      int32_t L, int32_t H, int32_t hd, int32_t hdp, vds_stream_t stream);
+
+/* apply_rotary_emb (model.py:266-275) on its own: y = rotate(x) for x, y [B,H,L,hd] bf16 addressed as
+ * base + b*sb + h*sh + l*sl (elements, multiples of 4; rows of hd contiguous), cos / sin f32 [L, hd/2];
+ * halves are (x1, x2) = (x[:hd/2], x[hd/2:]): y1 = x1 cos + x2 sin, y2 = x2 cos - x1 sin, fp32 math.
+ * inverse != 0 applies the transposed rotation (the backward of the forward).  hd % 8 == 0. */
+int vds_rope_apply(const void* x, int64_t x_sb, int64_t x_sh, int64_t x_sl, const float* cos, const float* sin,
+                   void* y, int64_t y_sb, int64_t y_sh, int64_t y_sl, int32_t B, int32_t H, int32_t L, int32_t hd,
+                   int32_t inverse, vds_stream_t stream);
 
 /* cos/sin rows [n_reg + t*h*w, nt + 2*ns] f32 of ThreeDimRotary.forward (model.py:219-263) for
  * the offsets (st,sh,sw): gathered from the per-axis tables tab_t_* [128, nt], tab_s_* [128, ns]
@@ -265,6 +275,41 @@ int vds_adamw_multi(const vds_adamw_tensor* desc_dev, const int32_t* chunk_tenso
 int vds_adamw_multi_dev(const vds_adamw_tensor* desc_dev, const int32_t* chunk_tensor_dev,
                         const int64_t* chunk_start_dev, int32_t n_chunks, int32_t chunk_elems, float beta1,
                         float beta2, float eps, const float* scalars_dev, float grad_scale, vds_stream_t stream);
+
+/* ------------------------------------------- parameter / gradient sharding (model.py:512-542) ------
+ * What the reference gets from FSDP2 `fully_shard` (apply_fsdp, model.py:512-542; mesh model.py:475-498): a bf16
+ * all-gather of a shard group's parameters before use and an fp32 reduce-scatter-AVERAGE of its gradients after its
+ * backward (MixedPrecisionPolicy(bf16, fp32), model.py:516-519), here straight on RCCL over xGMI, one process per
+ * GPU, ONE collective per flat group buffer.  RCCL is bound at run time (dlopen of librccl.so.1; VDS_RCCL_PATH
+ * overrides), so the library loads without it and these calls return VDS_ERR_UNSUPPORTED when it is missing.
+ *
+ *   rank 0:  vds_comm_unique_id(id, 128)  -> ship the 128 bytes to every rank (any host channel)
+ *   all:     vds_comm_init(rank, world, id, 128)     on the calling thread's current HIP device
+ *   per step and group:  vds_all_gather_bf16 / vds_reduce_scatter_f32_avg on the caller's communication stream
+ *   end:     vds_comm_destroy()
+ *
+ * One communicator per process (the only global mutable state of the library).  All collectives are asynchronous
+ * on `stream`; every rank must issue the same sequence.  shard_elems = elements per rank; the full buffer is
+ * world * shard_elems, rank r's part at offset r * shard_elems (in-place allowed: shard == full + rank*shard_elems).
+ * VDS_COMM_SCHEDULE=allpairs (read by vds_comm_init) switches the reduce-scatter from RCCL's algorithm to an explicit
+ * all-pairs exchange over the point-to-point xGMI mesh (one ncclSend/ncclRecv per peer + a local averaging kernel
+ * with a fixed summation order); it needs vds_reduce_scatter_workspace_bytes(shard_elems) bytes of caller memory. */
+#define VDS_COMM_ID_BYTES 128
+int vds_comm_unique_id(void* out, size_t bytes);
+int vds_comm_init(int32_t rank, int32_t world, const void* unique_id, size_t bytes);
+int vds_comm_info(int32_t* rank, int32_t* world, int32_t* rccl_version, int32_t* allpairs); /* NULLs allowed */
+int vds_comm_destroy(void);
+int vds_all_gather_bf16(const void* shard, void* full, int64_t shard_elems, vds_stream_t stream);
+int vds_all_gather_f32(const float* shard, float* full, int64_t shard_elems, vds_stream_t stream); /* fp32 masters: checkpoints */
+size_t vds_reduce_scatter_workspace_bytes(int64_t shard_elems); /* 0 unless the all-pairs schedule is on */
+int vds_reduce_scatter_f32_avg(const float* full, float* shard, int64_t shard_elems, void* workspace,
+                               size_t ws_bytes, vds_stream_t stream);
+/* the local half of the all-pairs schedule: out[i] = (sum over ranks r of chunk_r[i]) / world in rank order, where
+ * chunk_rank = own[n] and the other world-1 chunks lie in staged[(world-1) * n] in increasing rank order.  n % 4 == 0. */
+int vds_average_chunks_f32(const float* own, const float* staged, float* out, int64_t n, int32_t world,
+                           int32_t rank, vds_stream_t stream);
+/* utils.py:11-15 avg_scalar_across_ranks (loss logging): buf[i] = mean over ranks, in place */
+int vds_all_reduce_f32_avg(float* buf, int64_t n, vds_stream_t stream);
 
 /* f32 -> bf16 cast (FSDP param_dtype cast before all-gather, model.py:516-518) */
 int vds_cast_f32_bf16(const float* src, void* dst, int64_t n, vds_stream_t stream);

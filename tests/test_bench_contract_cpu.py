@@ -42,3 +42,27 @@ def test_cli_flags_and_gpu_requirement():
         out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0"],
                              capture_output=True, text=True)
         assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
+
+
+def test_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher environment must start 2 ranks (child torch.distributed.run) and
+    relay their exit code; here, without a GPU, every rank refuses to run -- which proves they were started"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    text = out.stderr + out.stdout
+    assert "starting 2 ranks" in text and "--nproc-per-node=2" in text
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and text.count("needs a GPU") >= 2
+
+
+def test_launcher_world_size_must_match_gpus_flag():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    b = load_bench()
+    assert b._spawn_ranks_if_needed.__doc__  # importable without side effects (the spawn runs under __main__ only)
+    import torch
+    if torch.cuda.is_available():
+        out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"],
+                             capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)

@@ -452,3 +452,57 @@ def test_registers_noise_loss_cast(ops):
     d = torch.empty(a.numel(), dtype=bf16, device="cuda")
     ops.cast_f32_bf16(a.cuda(), d)
     assert torch.equal(d.cpu(), a.to(bf16))
+
+
+# ------------------------------------------------------------------ sharding runtime ----
+def test_comm_c_abi_on_a_one_rank_communicator(ops):
+    """vds_comm_* (csrc/comm.hip: RCCL driven from the library, model.py:512-542's collectives) on the one GPU of
+    this box: unique id -> init -> bf16 / fp32 all-gather, fp32 reduce-scatter-average and all-reduce on a side
+    stream -> destroy.  At world 1 every collective must be an exact copy."""
+    import ctypes as C
+    from video_diffusion_speedrun_amd import _lib
+    lib = _lib.load()
+    ident = (C.c_ubyte * 128)()
+    _lib.check(lib.vds_comm_unique_id(ident, 128), "vds_comm_unique_id")
+    assert any(ident)
+    assert lib.vds_all_gather_bf16(None, None, 4, None) != 0 and b"vds_comm_init" in lib.vds_last_error()
+    _lib.check(lib.vds_comm_init(0, 1, ident, 128), "vds_comm_init")
+    try:
+        assert lib.vds_comm_init(0, 1, ident, 128) != 0                      # one communicator per process
+        r, w, v = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(lib.vds_comm_info(C.byref(r), C.byref(w), C.byref(v), None), "vds_comm_info")
+        assert (r.value, w.value) == (0, 1) and v.value > 20000
+        side = torch.cuda.Stream()
+        x16, x32 = gen(4096, seed=1).cuda(), gen(4096, seed=2, dtype=f32).cuda()
+        o16, o32, rs = torch.zeros_like(x16), torch.zeros_like(x32), torch.zeros_like(x32)
+        side.wait_stream(torch.cuda.current_stream())
+        s = side.cuda_stream
+        _lib.check(lib.vds_all_gather_bf16(x16.data_ptr(), o16.data_ptr(), 4096, s), "ag16")
+        _lib.check(lib.vds_all_gather_f32(x32.data_ptr(), o32.data_ptr(), 4096, s), "ag32")
+        assert lib.vds_reduce_scatter_workspace_bytes(4096) == 0
+        _lib.check(lib.vds_reduce_scatter_f32_avg(x32.data_ptr(), rs.data_ptr(), 4096, None, 0, s), "rs")
+        ar = x32.clone()
+        side.wait_stream(torch.cuda.current_stream())
+        _lib.check(lib.vds_all_reduce_f32_avg(ar.data_ptr(), 4096, s), "ar")
+        side.synchronize()
+        assert torch.equal(o16, x16) and torch.equal(o32, x32) and torch.equal(rs, x32) and torch.equal(ar, x32)
+    finally:
+        _lib.check(lib.vds_comm_destroy(), "vds_comm_destroy")
+    assert lib.vds_comm_destroy() == 0                                       # idempotent
+
+
+@pytest.mark.parametrize("W,rank", [(2, 0), (8, 3), (8, 7), (1, 0)])
+def test_allpairs_average_kernel(ops, W, rank):
+    """local half of the all-pairs reduce-scatter (VDS_COMM_SCHEDULE=allpairs): mean of W chunks in rank order"""
+    from video_diffusion_speedrun_amd import _lib
+    n = 4 * 1000 + 8
+    chunks = [gen(n, seed=50 + r, dtype=f32) for r in range(W)]
+    staged = torch.cat([c for r, c in enumerate(chunks) if r != rank]).cuda() if W > 1 else None
+    out = torch.zeros(n, dtype=f32, device="cuda")
+    _lib.check(_lib.load().vds_average_chunks_f32(chunks[rank].cuda().data_ptr(),
+                                                  staged.data_ptr() if staged is not None else None, out.data_ptr(),
+                                                  n, W, rank, torch.cuda.current_stream().cuda_stream), "avg")
+    want = torch.zeros(n)
+    for c in chunks:                      # the same left-to-right fp32 summation order
+        want = want + c
+    assert torch.equal(out.cpu(), want / W) or rel(out, want / W) < 1e-7

@@ -312,7 +312,11 @@ def test_shard_runtime_on_one_gpu_matches_unsharded(vds):
         assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
         for k in p0:
             assert rel(p1[k], p0[k]) <= 2e-4, (k, rel(p1[k], p0[k]))
+        from video_diffusion_speedrun_amd import comm
+        assert comm.info()["active"] and comm.info()["world"] == 1  # the collectives went through vds_comm_*
     finally:
+        from video_diffusion_speedrun_amd import comm
+        comm.destroy()
         dist.destroy_process_group()
 
 

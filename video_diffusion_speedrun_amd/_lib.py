@@ -63,6 +63,7 @@ SIGNATURES = {
     "vds_gemm_bf16": [C.POINTER(GemmArgs), c_vp],
     "vds_attn_fwd": [C.POINTER(AttnArgs), c_vp],
     "vds_attn_bwd": [C.POINTER(AttnArgs), c_vp],
+    "vds_attn_bwd_workspace_bytes": [C.POINTER(AttnArgs)],
     "vds_rmsnorm_mod_fwd": [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                             c_f32, c_vp],
     "vds_rmsnorm_mod_bwd": [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp,
@@ -73,6 +74,8 @@ SIGNATURES = {
     "vds_qkv_rope_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_qkv_rope_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                          c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_rope_apply": [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32,
+                       c_i32, c_vp],
     "vds_rope_rows": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
                       c_vp, c_vp],
     "vds_rope_rows_dev": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp],
@@ -90,6 +93,16 @@ SIGNATURES = {
     "vds_cfg_euler_step": [c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i64, c_vp],
     "vds_adamw_multi": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32, c_vp],
     "vds_adamw_multi_dev": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_f32, c_vp],
+    "vds_comm_unique_id": [c_vp, C.c_size_t],
+    "vds_comm_init": [c_i32, c_i32, c_vp, C.c_size_t],
+    "vds_comm_info": [c_vp, c_vp, c_vp, c_vp],
+    "vds_comm_destroy": [],
+    "vds_all_gather_bf16": [c_vp, c_vp, c_i64, c_vp],
+    "vds_all_gather_f32": [c_vp, c_vp, c_i64, c_vp],
+    "vds_reduce_scatter_workspace_bytes": [c_i64],
+    "vds_reduce_scatter_f32_avg": [c_vp, c_vp, c_i64, c_vp, C.c_size_t, c_vp],
+    "vds_average_chunks_f32": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp],
+    "vds_all_reduce_f32_avg": [c_vp, c_i64, c_vp],
     "vds_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
     "vds_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
     "vds_gemm_fp8": [C.POINTER(GemmArgs), c_vp, c_vp, c_i32, c_i32, c_vp, c_vp],
@@ -122,7 +135,8 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name in ("vds_last_error", "vds_prof_class_name") else C.c_int
+        fn.restype = (C.c_char_p if name in ("vds_last_error", "vds_prof_class_name") else
+                      C.c_size_t if name.endswith("_workspace_bytes") else C.c_int)
     _lib = lib
     return lib
 

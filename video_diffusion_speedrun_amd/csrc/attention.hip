@@ -1038,6 +1038,11 @@ extern "C" int vds_attn_fwd(const vds_attn_args* a, vds_stream_t stream) {
   }
 }
 
+extern "C" size_t vds_attn_bwd_workspace_bytes(const vds_attn_args* a) {
+  if (!a || a->B <= 0 || a->H <= 0 || a->Lq <= 0) return 0;
+  return (size_t)2 * a->B * a->H * a->Lq * sizeof(float);
+}
+
 extern "C" int vds_attn_bwd(const vds_attn_args* a, vds_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || !a->d_o || !a->dq || !a->dk || !a->dv || !a->delta)
     return VDS_ERR_ARG;

@@ -110,5 +110,12 @@ __device__ __forceinline__ void lds_dma4(srd_t srd, unsigned lds, unsigned voff)
 #define VDS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define VDS_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// last error message of the host-side entry points (comm.hip); vds_last_error() reports it
+namespace vdserr {
+void set(const char* fmt, ...);
+const char* get();
+void clear();
+}  // namespace vdserr
+
 static inline unsigned clamp_u32(size_t v) { return v > 0xffffffffull ? 0xffffffffu : (unsigned)v; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

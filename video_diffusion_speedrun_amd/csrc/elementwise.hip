@@ -357,6 +357,39 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_kernel(const bf16_t* qkv, co
   }
 }
 
+// stand-alone apply_rotary_emb (model.py:266-275): y1 = x1 c + x2 s, y2 = x2 c - x1 s on the two halves of every
+// head row, fp32 math, bf16 out; inverse = the transposed rotation (its backward).  One thread = 4 + 4 elements.
+__global__ __launch_bounds__(256) void rope_apply_kernel(const bf16_t* x, long x_sb, long x_sh, long x_sl,
+                                                         const float* cosb, const float* sinb, bf16_t* y, long y_sb,
+                                                         long y_sh, long y_sl, int B, int H, int L, int hd,
+                                                         int inverse) {
+  const int hq = hd >> 3, half = hd >> 1;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)B * H * L * hq) return;
+  const int i = (int)(gid % hq);
+  const long row = gid / hq;
+  const int l = (int)(row % L), h = (int)((row / L) % H), b = (int)(row / ((long)L * H));
+  const bf16_t* src = x + b * x_sb + h * x_sh + l * x_sl + 4 * i;
+  bf16_t* dst = y + b * y_sb + h * y_sh + l * y_sl + 4 * i;
+  const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosb + (long)l * half + 4 * i);
+  f32x4 s4 = *reinterpret_cast<const f32x4*>(sinb + (long)l * half + 4 * i);
+  if (inverse) s4 = -s4;
+  const u32x2 lo = *reinterpret_cast<const u32x2*>(src);
+  const u32x2 hi = *reinterpret_cast<const u32x2*>(src + half);
+  const float x1[4] = {bflo(lo[0]), bfhi(lo[0]), bflo(lo[1]), bfhi(lo[1])};
+  const float x2[4] = {bflo(hi[0]), bfhi(hi[0]), bflo(hi[1]), bfhi(hi[1])};
+  float y1[4], y2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    y1[e] = x1[e] * c4[e] + x2[e] * s4[e];
+    y2[e] = x2[e] * c4[e] - x1[e] * s4[e];
+  }
+  const u32x2 w1 = {pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])};
+  const u32x2 w2 = {pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])};
+  *reinterpret_cast<u32x2*>(dst) = w1;
+  *reinterpret_cast<u32x2*>(dst + half) = w2;
+}
+
 // backward of the above
 __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* dq, const bf16_t* dk, const bf16_t* dv,
                                                            const float* cosb, const float* sinb,
@@ -1009,6 +1042,18 @@ extern "C" int vds_flow_loss(const void* v, const void* out, float* loss_out, fl
   if (bps > 256) bps = 256;
   hipLaunchKernelGGL(flow_loss_kernel, dim3(bps, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v,
                      (const bf16_t*)out, loss_out, per_sample, (bf16_t*)dout, gscale, B, (long)per_sample_n, bps);
+  return ok();
+}
+
+extern "C" int vds_rope_apply(const void* x, int64_t x_sb, int64_t x_sh, int64_t x_sl, const float* cos,
+                              const float* sin, void* y, int64_t y_sb, int64_t y_sh, int64_t y_sl, int32_t B,
+                              int32_t H, int32_t L, int32_t hd, int32_t inverse, vds_stream_t stream) {
+  if (!x || !cos || !sin || !y || B <= 0 || H <= 0 || L <= 0 || hd <= 0 || (hd & 7)) return VDS_ERR_ARG;
+  if ((x_sb | x_sh | x_sl | y_sb | y_sh | y_sl) & 3) return VDS_ERR_ARG;  // 8-byte accesses
+  const long n = (long)B * H * L * (hd >> 3);
+  hipLaunchKernelGGL(rope_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (long)x_sb, (long)x_sh, (long)x_sl, cos, sin, (bf16_t*)y, (long)y_sb,
+                     (long)y_sh, (long)y_sl, B, H, L, hd, inverse);
   return ok();
 }
 

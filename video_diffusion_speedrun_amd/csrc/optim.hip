@@ -5,6 +5,7 @@
 // shadow copy that feeds the next step's all-gather / compute (model.py:516-518), fused here so
 // that no separate cast pass runs.  Also the library-level helpers (version, last error, lane-map
 // self test).
+#include <string.h>
 #include "common.h"
 #include "prof.h"
 #include "../../include/vds.h"
@@ -207,6 +208,12 @@ thread_local char g_last_error[256] = "";
 
 extern "C" int vds_version(void) { return 1; }
 extern "C" const char* vds_last_error(void) {
+  if (vdserr::get()[0]) {  // message of the last failing host-side call (sharding runtime); reported once
+    static thread_local char once[512];
+    strncpy(once, vdserr::get(), sizeof(once) - 1);
+    vdserr::clear();
+    return once;
+  }
   hipError_t e = hipPeekAtLastError();
   return e == hipSuccess ? "" : hipGetErrorString(e);
 }

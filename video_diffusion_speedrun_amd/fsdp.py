@@ -66,6 +66,33 @@ class ShardRuntime:
         self.gather_ev = [None] * len(model._groups)
         self.n_all_gather = 0
         self.n_reduce_scatter = 0
+        # measure=True: bracket every point where the compute stream waits for the communication stream with an
+        # event pair ON THE COMPUTE STREAM; the time between the two is the stall, i.e. communication that was not
+        # hidden under compute (bench.py's exposed-comm figure).  Off by default (no events).
+        self.measure = False
+        self._stalls = []
+
+    def _stall_begin(self):
+        if self.measure and self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        return None
+
+    def _stall_end(self, ev0):
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self._stalls.append((ev0, ev1))
+
+    def exposed_comm_ms(self) -> float:
+        """sum of the compute stream's stalls on the communication stream since the last call (synchronises)"""
+        if not self._stalls:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._stalls)
+        self._stalls = []
+        return ms
 
     # ---- helpers --------------------------------------------------------------------------
     def _on_comm(self):
@@ -78,7 +105,9 @@ class ShardRuntime:
     def _compute_waits(self, gi: int):
         ev = self.gather_ev[gi]
         if ev is not None:
+            t0 = self._stall_begin()
             torch.cuda.current_stream().wait_event(ev)
+            self._stall_end(t0)
             self.gather_ev[gi] = None
 
     def _reduce(self, gi: int):
@@ -125,7 +154,9 @@ class ShardRuntime:
     def post_backward_root(self):
         self._reduce(0)
         if self.cuda:
+            t0 = self._stall_begin()
             torch.cuda.current_stream().wait_stream(self.comm)
+            self._stall_end(t0)
         for g in self.model._groups:
             g.publish_grads()
 
@@ -184,5 +215,8 @@ def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32
     # force_runtime: run the stream / event / collective choreography even at world_size 1 (a 1-rank
     # process group must be initialised) -- used to test it on a single GPU
     if run:
+        if device.type == "cuda" and world_rank is None and dist.is_initialized():
+            from . import comm
+            comm.ensure(process_group)  # the library's own RCCL communicator (vds_comm_*); collective call
         dit_model._fsdp = ShardRuntime(dit_model, cast_fn, process_group)
     return dit_model

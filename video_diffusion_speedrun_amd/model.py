@@ -83,22 +83,131 @@ class _Act(nn.Module):
         self.kind = kind
 
 
+def _bf16_copy(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """bf16 compute copy of a stand-alone module's fp32 parameter (cast kernel, not a torch op)"""
+    if p is None:
+        return None
+    if p.dtype == bf16:
+        return p.detach().contiguous()
+    out = torch.empty(p.shape, dtype=bf16, device=p.device)
+    ops.cast_f32_bf16(p.detach().to(f32).contiguous(), out)
+    return out
+
+
+def _need_gpu(x, what):
+    if not x.is_cuda:
+        raise RuntimeError(f"video_diffusion_speedrun_amd.{what} runs on the GPU only (no CPU fallback)")
+
+
+class _RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D).to(bf16).contiguous()
+        rows = x2.shape[0]
+        mod = torch.zeros(1, 2 * D, dtype=f32, device=x.device)  # shift = scale = 0: the bare norm of model.py:34-41
+        w = _bf16_copy(weight)
+        y, rstd = ops.rmsnorm_mod_fwd(x2, w, mod, 0, D, 1, rows, eps)
+        ctx.save_for_backward(x2, w, mod, rstd)
+        ctx.meta = (x.shape, x.dtype, weight.dtype if weight is not None else None)
+        return y.view(x.shape).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, mod, rstd = ctx.saved_tensors
+        shape, xdt, wdt = ctx.meta
+        D = shape[-1]
+        dmod = torch.zeros(1, 2 * D, dtype=f32, device=dy.device)
+        dw = torch.zeros(D, dtype=f32, device=dy.device) if w is not None else None
+        dx = ops.rmsnorm_mod_bwd(dy.reshape(-1, D).to(bf16).contiguous(), x2, w, mod, 0, D, rstd, None, dmod, dw, 1,
+                                 x2.shape[0])
+        return dx.view(shape).to(xdt), (dw.to(wdt) if dw is not None else None), None
+
+
 class RMSNorm(nn.Module):
-    """model.py:25-41.  Holder; the math runs fused with the modulation in the HIP kernel."""
+    """model.py:25-41: y = (x.float() * rsqrt(mean(x^2) + eps) [* weight]).to(x.dtype), over the last dim.
+    Inside DiT the norm runs fused with the adaLN modulation (`vds_rmsnorm_mod_fwd` with the block's shift / scale);
+    called on its own it is the same kernel with zero shift / scale, differentiable through `vds_rmsnorm_mod_bwd`."""
 
     def __init__(self, dim, eps=1e-6, trainable=False):
         super().__init__()
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(dim)) if trainable else None
 
+    def forward(self, x):
+        _need_gpu(x, "RMSNorm")
+        return _RMSNormFn.apply(x, self.weight, self.eps)
+
+
+class _RotaryFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cos, sin):
+        hd = x.shape[-1]
+        cos2 = cos.reshape(-1, hd // 2).to(f32).contiguous()
+        sin2 = sin.reshape(-1, hd // 2).to(f32).contiguous()
+        ctx.save_for_backward(cos2, sin2)
+        ctx.xdt = x.dtype
+        xb = x if x.dtype == bf16 and x.stride(-1) == 1 else x.to(bf16).contiguous()
+        return ops.rope_apply(xb, cos2, sin2).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cos2, sin2 = ctx.saved_tensors
+        dyb = dy if dy.dtype == bf16 and dy.stride(-1) == 1 else dy.to(bf16).contiguous()
+        return ops.rope_apply(dyb, cos2, sin2, inverse=True).to(ctx.xdt), None, None
+
+
+def apply_rotary_emb(x, cos, sin):
+    """model.py:266-275: rotate the two halves of every head row, x [B,H,L,hd], cos / sin broadcastable
+    [1,1,L,hd/2]; fp32 math, result in x.dtype.  (Inside DiTBlock the rotation is fused with the qkv head split.)"""
+    _need_gpu(x, "apply_rotary_emb")
+    if x.dim() != 4 or cos.numel() != x.shape[2] * (x.shape[3] // 2) or sin.numel() != cos.numel():
+        raise ValueError(f"apply_rotary_emb: x {tuple(x.shape)} needs cos / sin of L x hd/2 = "
+                         f"{x.shape[2]} x {x.shape[3] // 2} elements, got {tuple(cos.shape)}")
+    return _RotaryFn.apply(x, cos, sin)
+
+
+class _PatchEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, pt, p):
+        if x.requires_grad:
+            raise NotImplementedError("PatchEmbed: the gradient w.r.t. the input latents is not implemented (the "
+                                      "train step never needs it: the latents are data)")
+        B = x.shape[0]
+        D = weight.shape[0]
+        patches = ops.patchify(x.to(bf16).contiguous(), pt, p)           # [B*N, C*pt*p*p], tokens in (h w t) order
+        y = ops.linear_fwd(patches, _bf16_copy(weight).view(D, -1), _bf16_copy(bias))
+        ctx.save_for_backward(patches)
+        ctx.meta = (weight.shape, weight.dtype, bias.dtype)
+        return y.view(B, -1, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        wshape, wdt, bdt = ctx.meta
+        D = wshape[0]
+        dy2 = dy.reshape(-1, D).to(bf16).contiguous()
+        dW = torch.zeros(D, patches.shape[1], dtype=f32, device=dy.device)
+        ops.linear_wgrad(dy2, patches, dW)
+        db = torch.zeros(D, dtype=f32, device=dy.device)
+        ops.colsum(dy2, db)
+        return None, dW.view(wshape).to(wdt), db.to(bdt), None, None
+
 
 class PatchEmbed(nn.Module):
-    """model.py:170-186."""
+    """model.py:170-186: Conv3d(kernel = stride = (pt, p, p)) + bias, tokens ordered (h w t): [B,C,T,H,W] ->
+    [B, N, D] bf16.  A conv whose kernel equals its stride is a GEMM over gathered patches: `vds_patchify` +
+    `vds_gemm_bf16`; backward = weight-gradient GEMM + column sums."""
 
     def __init__(self, patch_size=16, in_channels=3, embed_dim=768, time_patch_size=16):
         super().__init__()
         self.patch_proj = _Conv3dParams(in_channels, embed_dim, (time_patch_size, patch_size, patch_size))
         self.patch_size, self.time_patch_size = patch_size, time_patch_size
+
+    def forward(self, x):
+        _need_gpu(x, "PatchEmbed")
+        return _PatchEmbedFn.apply(x, self.patch_proj.weight, self.patch_proj.bias, self.time_patch_size,
+                                   self.patch_size)
 
 
 class ThreeDimRotary(nn.Module):
@@ -138,7 +247,9 @@ class ThreeDimRotary(nn.Module):
 
 
 class DiTBlock(nn.Module):
-    """model.py:44-94 (parameters); the computation is DiT._block_fwd / _block_bwd."""
+    """model.py:44-167.  `forward(x, context, c, v_0=None, rope=None) -> (x, v)` has the reference's signature and
+    runs the block's HIP kernel sequence (`_fwd`) under one autograd node whose backward is `_bwd`; DiT.forward
+    drives the same two methods for all blocks inside its own whole-model node."""
 
     def __init__(self, hidden_size, cross_attn_input_size, num_heads, mlp_ratio=4.0, qkv_bias=True,
                  residual_v=False):
@@ -164,6 +275,212 @@ class DiTBlock(nn.Module):
         self.adaLN_modulation = nn.Sequential(_Act("silu"), _Linear(hidden_size, 9 * hidden_size, bias=True))
         self.adaLN_modulation[-1].weight.data.zero_()
         self.adaLN_modulation[-1].bias.data.zero_()
+
+    # ---- stand-alone call (reference signature, model.py:96-167) ---------------------------------------
+    _own_group: Optional[FlatGroup] = None
+
+    def _group_and_prefix(self, device):
+        """the FlatGroup that holds this block's parameters + the name prefix they carry in it: the enclosing
+        DiT's block group when there is a current one, else a group of its own (built on first use)"""
+        named = list(self.named_parameters())
+        g = getattr(named[0][1], "_vds_group", None)
+        if g is not None and g.master is not None and g.is_current() and g.device == device:
+            if g.world > 1:
+                raise RuntimeError("DiTBlock.forward on a block of a sharded DiT: call the model (the sharding "
+                                   "runtime gathers / reduces per block inside DiT.forward)")
+            full0 = named[0][1]._vds_name
+            pre = full0[:len(full0) - len(named[0][0])]
+            if all(getattr(p, "_vds_group", None) is g and p._vds_name == pre + n for n, p in named):
+                return g, pre
+        g = FlatGroup("block", named)
+        g.materialize(device)
+        self._own_group = g
+        return g, ""
+
+    def forward(self, x, context, c, v_0=None, rope=None):
+        """x [B,L,D], context [B,Lc,Cc] (None without cross-attention), c [B,D] conditioning, v_0 [B,H,L,hd] (block
+        0's v; None in block 0), rope = (cos, sin) each [1,1,L,hd/2] or None -> (x [B,L,D], v [B,H,L,hd]) in bf16.
+        Gradients flow to x, c, v_0 and the block's parameters (fp32 .grad); `context` is data (the frozen text
+        encoder's output, train.py:70-87) and gets none."""
+        _need_gpu(x, "DiTBlock")
+        params = [p for p in self.parameters()]
+        save = torch.is_grad_enabled()  # (always off inside an autograd.Function's forward: decided here)
+        return _BlockFunction.apply(self, save, x, context, c, v_0, rope[0] if rope is not None else None,
+                                    rope[1] if rope is not None else None, *params)
+
+    # ---- the kernel sequence of one block (used by DiT's whole-model autograd node and by `forward`) ----
+    def _fwd(self, G, pre, X, ctx2d, cvec, v0, cos, sin, B, L, Lc, save, fp8=None):
+        """X [B*L, D] bf16 token buffer -> (X_out, v [B,H,L,hdp], saved).  G: the FlatGroup holding this block's
+        parameters under the name prefix `pre`; cvec f32 [B, D]; v0: block 0's v in the padded head-major layout
+        or None; cos / sin f32 [L, hd/2]; fp8 = (AmaxHistory | None, block index) when the fp8 linears are on."""
+        D, H, hd = self.hidden_size, self.num_heads, self.head_dim
+        hdp = {64: 64, 72: 96, 128: 128}[hd]
+        use_fp8 = fp8 is not None
+        fp8_hist, i = fp8 if use_fp8 else (None, 0)
+        W = lambda n: G.w(pre + n)
+        Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
+        dev = X.device
+        mod = ops.small_linear_fwd(cvec, W("adaLN_modulation.1.weight"), W("adaLN_modulation.1.bias"), 1)
+        # --- self attention (model.py:122-139)
+        xn1, rstd1 = ops.rmsnorm_mod_fwd(X, Wo("norm1.weight"), mod, 0, D, B, L)
+        f8 = use_fp8 and F8.supported(B * L, 3 * D, D)
+        if use_fp8 and not f8:
+            raise ValueError(f"fp8 linears need B*L ({B * L}) and hidden size ({D}) to be multiples of 16")
+        if f8:
+            hist = fp8_hist if save else None
+            q_xn1 = F8.Q(xn1, F8.E4M3, True, save, hist, 6 * i + 2)
+            q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save)
+            qkv = torch.empty(B * L, 3 * D, dtype=bf16, device=dev)
+            F8.fwd(q_xn1, q_wqkv, qkv, Wo("qkv.bias"))
+        else:
+            qkv = ops.linear_fwd(xn1, W("qkv.weight"), Wo("qkv.bias"))
+        mix = self.residual_v and v0 is not None
+        q, k, v = ops.qkv_rope_fwd(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None, B, L, H,
+                                   hd, hdp)
+        attn = torch.empty(B * L, D, dtype=bf16, device=dev)
+        lse1 = torch.empty(B, H, L, dtype=f32, device=dev)
+        ops.attn_fwd(q[..., :hd], k[..., :hd], v[..., :hd], ops.heads_view(attn, B, L, H, hd), lse1,
+                     kv_pad_ones=(hdp - hd) >= 8)
+        y_sa, X1 = ops.linear_fwd_gate_res(attn, W("attn_proj.weight"), None, mod, 2 * D, X, L)
+        # --- cross attention (model.py:142-160)
+        has_cross = G.has(pre + "q_cross.weight")
+        if has_cross:
+            xn2, rstd2 = ops.rmsnorm_mod_fwd(X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, B, L)
+            qc = ops.linear_fwd(xn2, W("q_cross.weight"), Wo("q_cross.bias"))
+            ckv = ops.linear_fwd(ctx2d, W("context_kv.weight"), Wo("context_kv.bias"))
+            catt = torch.empty(B * L, D, dtype=bf16, device=dev)
+            lse2 = torch.empty(B, H, L, dtype=f32, device=dev)
+            ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), ops.heads_view(ckv, B, Lc, H, hd, 0),
+                         ops.heads_view(ckv, B, Lc, H, hd, D), ops.heads_view(catt, B, L, H, hd), lse2)
+            y_ca, X2 = ops.linear_fwd_gate_res(catt, W("cross_proj.weight"), None, mod, 5 * D, X1, L)
+        else:
+            X2 = X1
+        # --- MLP (model.py:163-165)
+        xn3, rstd3 = ops.rmsnorm_mod_fwd(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L)
+        if f8:
+            q_xn3 = F8.Q(xn3, F8.E4M3, True, save, hist, 6 * i + 3)
+            q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save)
+            if hist is not None and hist.ready and not _NO_EMIT:  # gelu(fc1) leaves the GEMM as fp8
+                hpre, q_hact = F8.fwd_gelu_emit(q_xn3, q_w1, W("mlp.0.bias"), hist.prev(6 * i), hist.cur(6 * i), save)
+                hact = None
+            else:
+                hpre, hact = F8.fwd_gelu(q_xn3, q_w1, W("mlp.0.bias"))
+                q_hact = F8.Q(hact, F8.E4M3, True, save, hist, 6 * i)
+            q_w2 = F8.Q(W("mlp.2.weight"), F8.E4M3, True, save)
+            y_mlp, X3 = F8.fwd_gate_res(q_hact, q_w2, W("mlp.2.bias"), mod, 8 * D, X2, L)
+        else:
+            hpre, hact = ops.linear_fwd_gelu(xn3, W("mlp.0.weight"), W("mlp.0.bias"))
+            y_mlp, X3 = ops.linear_fwd_gate_res(hact, W("mlp.2.weight"), W("mlp.2.bias"), mod, 8 * D, X2, L)
+        bs = None
+        if save:
+            bs = _Saved()
+            bs.mod, bs.X, bs.X1, bs.X2 = mod, X, X1, X2
+            bs.xn1, bs.rstd1, bs.qkv, bs.q, bs.k, bs.v, bs.attn, bs.lse1, bs.y_sa = xn1, rstd1, qkv, q, k, v, attn, lse1, y_sa
+            bs.mix, bs.has_cross = mix, has_cross
+            if has_cross:
+                bs.xn2, bs.rstd2, bs.qc, bs.ckv, bs.catt, bs.lse2, bs.y_ca = xn2, rstd2, qc, ckv, catt, lse2, y_ca
+            bs.xn3, bs.rstd3, bs.hpre, bs.hact, bs.y_mlp = xn3, rstd3, hpre, hact, y_mlp
+            bs.f8 = f8
+            if f8:  # the backward contracts the fp8 copies: the bf16 GEMM inputs need not be kept
+                bs.q_xn1, bs.q_wqkv, bs.q_xn3, bs.q_w1, bs.q_hact, bs.q_w2 = q_xn1, q_wqkv, q_xn3, q_w1, q_hact, q_w2
+                bs.xn1 = bs.xn3 = bs.hact = None
+        return X3, v, bs
+
+
+    def _bwd(self, G, pre, bs, dX, sv, dc, dv0, B, L, Lc, first, fp8=None):
+        """backward of `_fwd`: dX [B*L, D] bf16 -> d(input tokens); parameter gradients go to G's fp32 gradient
+        buffer; dc (f32 [B, D]) and dv0 (f32 [B,H,L,hdp]) accumulate the conditioning / residual-V gradients.
+        sv carries cos, sin, v0, ctx2d, cvec.  first: this is the block whose v was handed out as v_0."""
+        D, H, hd = self.hidden_size, self.num_heads, self.head_dim
+        hdp = {64: 64, 72: 96, 128: 128}[hd]
+        fp8_hist, i = fp8 if fp8 is not None else (None, 0)
+        W = lambda n: G.w(pre + n)
+        Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
+        Gr = lambda n: G.g(pre + n)
+        Go = lambda n: G.g(pre + n) if G.has(pre + n) else None
+        dev = dX.device
+        mod = bs.mod
+        dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
+        # --- MLP
+        dy = ops.gate_bwd(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L)
+        if bs.f8:
+            hist = fp8_hist
+            q_dy = F8.Q(dy, F8.E5M2, True, True, hist, 6 * i + 4)
+            F8.wgrad(q_dy, bs.q_hact, Gr("mlp.2.weight"))
+            if hist.ready and not _NO_EMIT:  # the fc2 input gradient leaves the GEMM as e5m2 (+ transposed, + bias gradient)
+                dh = None
+                q_dh = F8.dgrad_gelu_emit(q_dy, bs.q_w2, bs.hpre, hist.prev(6 * i + 1), hist.cur(6 * i + 1),
+                                          Gr("mlp.0.bias"))
+            else:
+                dh = F8.dgrad(q_dy, bs.q_w2, pre=bs.hpre)
+                q_dh = F8.Q(dh, F8.E5M2, True, True, hist, 6 * i + 1)
+                ops.colsum(dh, Gr("mlp.0.bias"))
+            F8.wgrad(q_dh, bs.q_xn3, Gr("mlp.0.weight"))
+            dxn = F8.dgrad(q_dh, bs.q_w1)
+            del q_dy, q_dh
+        else:
+            ops.linear_wgrad(dy, bs.hact, Gr("mlp.2.weight"))
+            dh = ops.linear_dgrad(dy, W("mlp.2.weight"), pre=bs.hpre)
+            ops.linear_wgrad(dh, bs.xn3, Gr("mlp.0.weight"))
+            ops.colsum(dh, Gr("mlp.0.bias"))
+            dxn = ops.linear_dgrad(dh, W("mlp.0.weight"))
+        del dh
+        dX2 = ops.rmsnorm_mod_bwd(dxn, bs.X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, bs.rstd3, dX, dmod,
+                                  Go("norm3.weight"), B, L)
+        # --- cross attention
+        if bs.has_cross:
+            dy = ops.gate_bwd(dX2, bs.y_ca, mod, 5 * D, dmod, None, B, L)
+            ops.linear_wgrad(dy, bs.catt, Gr("cross_proj.weight"))
+            dcatt = ops.linear_dgrad(dy, W("cross_proj.weight"))
+            dqc = torch.empty(B * L, D, dtype=bf16, device=dev)
+            dckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
+            delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
+            ops.attn_bwd(ops.heads_view(bs.qc, B, L, H, hd), ops.heads_view(bs.ckv, B, Lc, H, hd, 0),
+                         ops.heads_view(bs.ckv, B, Lc, H, hd, D), ops.heads_view(bs.catt, B, L, H, hd), bs.lse2,
+                         ops.heads_view(dcatt, B, L, H, hd), ops.heads_view(dqc, B, L, H, hd),
+                         ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), delta)
+            ops.linear_wgrad(dckv, sv.ctx2d, Gr("context_kv.weight"))
+            if G.has(pre + "context_kv.bias"):
+                ops.colsum(dckv, Gr("context_kv.bias"))
+            ops.linear_wgrad(dqc, bs.xn2, Gr("q_cross.weight"))
+            if G.has(pre + "q_cross.bias"):
+                ops.colsum(dqc, Gr("q_cross.bias"))
+            dxn = ops.linear_dgrad(dqc, W("q_cross.weight"))
+            dX1 = ops.rmsnorm_mod_bwd(dxn, bs.X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, bs.rstd2, dX2, dmod,
+                                      Go("norm2.weight"), B, L)
+        else:
+            dX1 = dX2
+        # --- self attention
+        dy = ops.gate_bwd(dX1, bs.y_sa, mod, 2 * D, dmod, None, B, L)
+        ops.linear_wgrad(dy, bs.attn, Gr("attn_proj.weight"))
+        dattn = ops.linear_dgrad(dy, W("attn_proj.weight"))
+        dq = torch.empty(B, H, L, hdp, dtype=bf16, device=dev)
+        dk = torch.empty_like(dq)
+        dv = torch.empty_like(dq)
+        delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
+        ops.attn_bwd(bs.q[..., :hd], bs.k[..., :hd], bs.v[..., :hd], ops.heads_view(bs.attn, B, L, H, hd), bs.lse1,
+                     ops.heads_view(dattn, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta,
+                     kv_pad_ones=(hdp - hd) >= 8)
+        dqkv = ops.qkv_rope_bwd(dq, dk, dv, sv.cos, sv.sin, bs.qkv if bs.mix else None, sv.v0 if bs.mix else None,
+                                W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),
+                                Gr("lambda_param") if bs.mix else None, bs.mix,
+                                first and dv0 is not None, B, L, H, hd, hdp)
+        if G.has(pre + "qkv.bias"):
+            ops.colsum(dqkv, Gr("qkv.bias"))
+        if bs.f8:
+            q_dqkv = F8.Q(dqkv, F8.E5M2, True, True, fp8_hist, 6 * i + 5)
+            F8.wgrad(q_dqkv, bs.q_xn1, Gr("qkv.weight"))
+            dxn = F8.dgrad(q_dqkv, bs.q_wqkv)
+            del q_dqkv
+        else:
+            ops.linear_wgrad(dqkv, bs.xn1, Gr("qkv.weight"))
+            dxn = ops.linear_dgrad(dqkv, W("qkv.weight"))
+        dX0 = ops.rmsnorm_mod_bwd(dxn, bs.X, Wo("norm1.weight"), mod, 0, D, bs.rstd1, dX1, dmod, Go("norm1.weight"),
+                                  B, L)
+        # --- adaLN modulation (model.py:89-94,107)
+        ops.small_linear_bwd(dmod, sv.cvec, W("adaLN_modulation.1.weight"), Gr("adaLN_modulation.1.weight"),
+                             Gr("adaLN_modulation.1.bias"), dc, 1)
+        return dX0
 
 
 class _Saved:
@@ -335,7 +652,8 @@ class DiT(nn.Module):
         for i in range(self.depth):
             if fs is not None:
                 fs.pre_forward_block(i)
-            X, v, bs = self._block_fwd(i, X, ctx2d, cvec, v0, cos, sin, B, L, Lc, save)
+            X, v, bs = self.blocks[i]._fwd(self.block_group(i), f"blocks.{i}.", X, ctx2d, cvec, v0, cos, sin, B, L, Lc,
+                                           save, (self._fp8_hist, i) if self.fp8 else None)
             if v0 is None:
                 v0 = v
             if save:
@@ -363,80 +681,6 @@ class DiT(nn.Module):
         if fs is not None:
             fs.post_forward_root()
         return out, sv
-
-    def _block_fwd(self, i, X, ctx2d, cvec, v0, cos, sin, B, L, Lc, save):
-        D, H, hd = self.hidden_size, self.num_heads, self.head_dim
-        hdp = {64: 64, 72: 96, 128: 128}[hd]
-        G = self.block_group(i)
-        pre = f"blocks.{i}."
-        W = lambda n: G.w(pre + n)
-        Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
-        dev = X.device
-        mod = ops.small_linear_fwd(cvec, W("adaLN_modulation.1.weight"), W("adaLN_modulation.1.bias"), 1)
-        # --- self attention (model.py:122-139)
-        xn1, rstd1 = ops.rmsnorm_mod_fwd(X, Wo("norm1.weight"), mod, 0, D, B, L)
-        f8 = self.fp8 and F8.supported(B * L, 3 * D, D)
-        if self.fp8 and not f8:
-            raise ValueError(f"fp8 linears need B*L ({B * L}) and hidden size ({D}) to be multiples of 16")
-        if f8:
-            hist = self._fp8_hist if save else None
-            q_xn1 = F8.Q(xn1, F8.E4M3, True, save, hist, 6 * i + 2)
-            q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save)
-            qkv = torch.empty(B * L, 3 * D, dtype=bf16, device=dev)
-            F8.fwd(q_xn1, q_wqkv, qkv, Wo("qkv.bias"))
-        else:
-            qkv = ops.linear_fwd(xn1, W("qkv.weight"), Wo("qkv.bias"))
-        mix = self.residual_v and v0 is not None
-        q, k, v = ops.qkv_rope_fwd(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None, B, L, H,
-                                   hd, hdp)
-        attn = torch.empty(B * L, D, dtype=bf16, device=dev)
-        lse1 = torch.empty(B, H, L, dtype=f32, device=dev)
-        ops.attn_fwd(q[..., :hd], k[..., :hd], v[..., :hd], ops.heads_view(attn, B, L, H, hd), lse1,
-                     kv_pad_ones=(hdp - hd) >= 8)
-        y_sa, X1 = ops.linear_fwd_gate_res(attn, W("attn_proj.weight"), None, mod, 2 * D, X, L)
-        # --- cross attention (model.py:142-160)
-        has_cross = G.has(pre + "q_cross.weight")
-        if has_cross:
-            xn2, rstd2 = ops.rmsnorm_mod_fwd(X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, B, L)
-            qc = ops.linear_fwd(xn2, W("q_cross.weight"), Wo("q_cross.bias"))
-            ckv = ops.linear_fwd(ctx2d, W("context_kv.weight"), Wo("context_kv.bias"))
-            catt = torch.empty(B * L, D, dtype=bf16, device=dev)
-            lse2 = torch.empty(B, H, L, dtype=f32, device=dev)
-            ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), ops.heads_view(ckv, B, Lc, H, hd, 0),
-                         ops.heads_view(ckv, B, Lc, H, hd, D), ops.heads_view(catt, B, L, H, hd), lse2)
-            y_ca, X2 = ops.linear_fwd_gate_res(catt, W("cross_proj.weight"), None, mod, 5 * D, X1, L)
-        else:
-            X2 = X1
-        # --- MLP (model.py:163-165)
-        xn3, rstd3 = ops.rmsnorm_mod_fwd(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L)
-        if f8:
-            q_xn3 = F8.Q(xn3, F8.E4M3, True, save, hist, 6 * i + 3)
-            q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save)
-            if hist is not None and hist.ready and not _NO_EMIT:  # gelu(fc1) leaves the GEMM as fp8
-                hpre, q_hact = F8.fwd_gelu_emit(q_xn3, q_w1, W("mlp.0.bias"), hist.prev(6 * i), hist.cur(6 * i), save)
-                hact = None
-            else:
-                hpre, hact = F8.fwd_gelu(q_xn3, q_w1, W("mlp.0.bias"))
-                q_hact = F8.Q(hact, F8.E4M3, True, save, hist, 6 * i)
-            q_w2 = F8.Q(W("mlp.2.weight"), F8.E4M3, True, save)
-            y_mlp, X3 = F8.fwd_gate_res(q_hact, q_w2, W("mlp.2.bias"), mod, 8 * D, X2, L)
-        else:
-            hpre, hact = ops.linear_fwd_gelu(xn3, W("mlp.0.weight"), W("mlp.0.bias"))
-            y_mlp, X3 = ops.linear_fwd_gate_res(hact, W("mlp.2.weight"), W("mlp.2.bias"), mod, 8 * D, X2, L)
-        bs = None
-        if save:
-            bs = _Saved()
-            bs.mod, bs.X, bs.X1, bs.X2 = mod, X, X1, X2
-            bs.xn1, bs.rstd1, bs.qkv, bs.q, bs.k, bs.v, bs.attn, bs.lse1, bs.y_sa = xn1, rstd1, qkv, q, k, v, attn, lse1, y_sa
-            bs.mix, bs.has_cross = mix, has_cross
-            if has_cross:
-                bs.xn2, bs.rstd2, bs.qc, bs.ckv, bs.catt, bs.lse2, bs.y_ca = xn2, rstd2, qc, ckv, catt, lse2, y_ca
-            bs.xn3, bs.rstd3, bs.hpre, bs.hact, bs.y_mlp = xn3, rstd3, hpre, hact, y_mlp
-            bs.f8 = f8
-            if f8:  # the backward contracts the fp8 copies: the bf16 GEMM inputs need not be kept
-                bs.q_xn1, bs.q_wqkv, bs.q_xn3, bs.q_w1, bs.q_hact, bs.q_w2 = q_xn1, q_wqkv, q_xn3, q_w1, q_hact, q_w2
-                bs.xn1 = bs.xn3 = bs.hact = None
-        return X3, v, bs
 
     # ----------------------------------------------------------------------- backward ----
     def _backward_impl(self, sv: _Saved, dout: torch.Tensor):
@@ -486,7 +730,8 @@ class DiT(nn.Module):
         for i in reversed(range(self.depth)):
             if fs is not None:
                 fs.pre_backward_block(i)
-            dX = self._block_bwd(i, sv.blocks[i], dX, sv, dc, dv0, B, L, Lc)
+            dX = self.blocks[i]._bwd(self.block_group(i), f"blocks.{i}.", sv.blocks[i], dX, sv, dc, dv0, B, L, Lc,
+                                     i == 0, (self._fp8_hist, i) if self.fp8 else None)
             sv.blocks[i] = None
             if fs is not None:
                 fs.post_backward_block(i)
@@ -513,100 +758,6 @@ class DiT(nn.Module):
                     g.gshard.add_(h)
         if self.fp8 and getattr(self, "_fp8_hist", None) is not None:
             self._fp8_hist.backward_done()
-
-    def _block_bwd(self, i, bs, dX, sv, dc, dv0, B, L, Lc):
-        D, H, hd = self.hidden_size, self.num_heads, self.head_dim
-        hdp = {64: 64, 72: 96, 128: 128}[hd]
-        G = self.block_group(i)
-        pre = f"blocks.{i}."
-        W = lambda n: G.w(pre + n)
-        Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
-        Gr = lambda n: G.g(pre + n)
-        Go = lambda n: G.g(pre + n) if G.has(pre + n) else None
-        dev = dX.device
-        mod = bs.mod
-        dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
-        # --- MLP
-        dy = ops.gate_bwd(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L)
-        if bs.f8:
-            hist = self._fp8_hist
-            q_dy = F8.Q(dy, F8.E5M2, True, True, hist, 6 * i + 4)
-            F8.wgrad(q_dy, bs.q_hact, Gr("mlp.2.weight"))
-            if hist.ready and not _NO_EMIT:  # the fc2 input gradient leaves the GEMM as e5m2 (+ transposed, + bias gradient)
-                dh = None
-                q_dh = F8.dgrad_gelu_emit(q_dy, bs.q_w2, bs.hpre, hist.prev(6 * i + 1), hist.cur(6 * i + 1),
-                                          Gr("mlp.0.bias"))
-            else:
-                dh = F8.dgrad(q_dy, bs.q_w2, pre=bs.hpre)
-                q_dh = F8.Q(dh, F8.E5M2, True, True, hist, 6 * i + 1)
-                ops.colsum(dh, Gr("mlp.0.bias"))
-            F8.wgrad(q_dh, bs.q_xn3, Gr("mlp.0.weight"))
-            dxn = F8.dgrad(q_dh, bs.q_w1)
-            del q_dy, q_dh
-        else:
-            ops.linear_wgrad(dy, bs.hact, Gr("mlp.2.weight"))
-            dh = ops.linear_dgrad(dy, W("mlp.2.weight"), pre=bs.hpre)
-            ops.linear_wgrad(dh, bs.xn3, Gr("mlp.0.weight"))
-            ops.colsum(dh, Gr("mlp.0.bias"))
-            dxn = ops.linear_dgrad(dh, W("mlp.0.weight"))
-        del dh
-        dX2 = ops.rmsnorm_mod_bwd(dxn, bs.X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, bs.rstd3, dX, dmod,
-                                  Go("norm3.weight"), B, L)
-        # --- cross attention
-        if bs.has_cross:
-            dy = ops.gate_bwd(dX2, bs.y_ca, mod, 5 * D, dmod, None, B, L)
-            ops.linear_wgrad(dy, bs.catt, Gr("cross_proj.weight"))
-            dcatt = ops.linear_dgrad(dy, W("cross_proj.weight"))
-            dqc = torch.empty(B * L, D, dtype=bf16, device=dev)
-            dckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
-            delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
-            ops.attn_bwd(ops.heads_view(bs.qc, B, L, H, hd), ops.heads_view(bs.ckv, B, Lc, H, hd, 0),
-                         ops.heads_view(bs.ckv, B, Lc, H, hd, D), ops.heads_view(bs.catt, B, L, H, hd), bs.lse2,
-                         ops.heads_view(dcatt, B, L, H, hd), ops.heads_view(dqc, B, L, H, hd),
-                         ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), delta)
-            ops.linear_wgrad(dckv, sv.ctx2d, Gr("context_kv.weight"))
-            if G.has(pre + "context_kv.bias"):
-                ops.colsum(dckv, Gr("context_kv.bias"))
-            ops.linear_wgrad(dqc, bs.xn2, Gr("q_cross.weight"))
-            if G.has(pre + "q_cross.bias"):
-                ops.colsum(dqc, Gr("q_cross.bias"))
-            dxn = ops.linear_dgrad(dqc, W("q_cross.weight"))
-            dX1 = ops.rmsnorm_mod_bwd(dxn, bs.X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, bs.rstd2, dX2, dmod,
-                                      Go("norm2.weight"), B, L)
-        else:
-            dX1 = dX2
-        # --- self attention
-        dy = ops.gate_bwd(dX1, bs.y_sa, mod, 2 * D, dmod, None, B, L)
-        ops.linear_wgrad(dy, bs.attn, Gr("attn_proj.weight"))
-        dattn = ops.linear_dgrad(dy, W("attn_proj.weight"))
-        dq = torch.empty(B, H, L, hdp, dtype=bf16, device=dev)
-        dk = torch.empty_like(dq)
-        dv = torch.empty_like(dq)
-        delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
-        ops.attn_bwd(bs.q[..., :hd], bs.k[..., :hd], bs.v[..., :hd], ops.heads_view(bs.attn, B, L, H, hd), bs.lse1,
-                     ops.heads_view(dattn, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta,
-                     kv_pad_ones=(hdp - hd) >= 8)
-        first = (i == 0)
-        dqkv = ops.qkv_rope_bwd(dq, dk, dv, sv.cos, sv.sin, bs.qkv if bs.mix else None, sv.v0 if bs.mix else None,
-                                W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),
-                                Gr("lambda_param") if bs.mix else None, bs.mix,
-                                first and dv0 is not None, B, L, H, hd, hdp)
-        if G.has(pre + "qkv.bias"):
-            ops.colsum(dqkv, Gr("qkv.bias"))
-        if bs.f8:
-            q_dqkv = F8.Q(dqkv, F8.E5M2, True, True, self._fp8_hist, 6 * i + 5)
-            F8.wgrad(q_dqkv, bs.q_xn1, Gr("qkv.weight"))
-            dxn = F8.dgrad(q_dqkv, bs.q_wqkv)
-            del q_dqkv
-        else:
-            ops.linear_wgrad(dqkv, bs.xn1, Gr("qkv.weight"))
-            dxn = ops.linear_dgrad(dqkv, W("qkv.weight"))
-        dX0 = ops.rmsnorm_mod_bwd(dxn, bs.X, Wo("norm1.weight"), mod, 0, D, bs.rstd1, dX1, dmod, Go("norm1.weight"),
-                                  B, L)
-        # --- adaLN modulation (model.py:89-94,107)
-        ops.small_linear_bwd(dmod, sv.cvec, W("adaLN_modulation.1.weight"), Gr("adaLN_modulation.1.weight"),
-                             Gr("adaLN_modulation.1.bias"), dc, 1)
-        return dX0
 
     # ------------------------------------------------------------------- muP table ----
     def get_mup_setup(self, learning_rate, weight_decay, constant_param_classes):
@@ -659,6 +810,80 @@ class DiT(nn.Module):
         for g in self._groups:
             out.update(g.full_tensors())
         return out
+
+
+class _BlockFunction(torch.autograd.Function):
+    """DiTBlock.forward as one autograd node (see DiTBlock.forward for the contract)."""
+
+    @staticmethod
+    def forward(ctx, block, need, x, context, c, v_0, cos, sin, *params):
+        B, L, D = x.shape
+        H, hd = block.num_heads, block.head_dim
+        hdp = {64: 64, 72: 96, 128: 128}[hd]
+        dev = x.device
+        if (context is None) != (block.q_cross is None):
+            raise ValueError("DiTBlock: `context` must be given exactly when the block has cross-attention")
+        G, pre = block._group_and_prefix(dev)
+        G.gather(ops.cast_f32_bf16, None)
+        X = x.reshape(B * L, D).to(bf16).contiguous()
+        if context is not None:
+            Lc = context.shape[1]
+            ctx2d = context.to(bf16).contiguous().view(B * Lc, context.shape[2])
+        else:
+            Lc, ctx2d = 0, None
+        cvec = c.to(f32).contiguous()
+        if cos is None:  # rope=None: no rotation (model.py:132-134) = the identity rotation
+            cos2 = torch.ones(L, hd // 2, dtype=f32, device=dev)
+            sin2 = torch.zeros(L, hd // 2, dtype=f32, device=dev)
+        else:
+            cos2 = cos.reshape(L, hd // 2).to(f32).contiguous()
+            sin2 = sin.reshape(L, hd // 2).to(f32).contiguous()
+        v0p = None
+        if v_0 is not None and block.residual_v:
+            if tuple(v_0.shape) != (B, H, L, hd):
+                raise ValueError(f"DiTBlock: v_0 must be [B,H,L,hd] = {(B, H, L, hd)}, got {tuple(v_0.shape)}")
+            if v_0.dtype == bf16 and v_0.stride() == (H * L * hdp, L * hdp, hdp, 1):
+                v0p = v_0.as_strided((B, H, L, hdp), (H * L * hdp, L * hdp, hdp, 1))  # a `v` this class returned
+            else:
+                v0p = torch.zeros(B, H, L, hdp, dtype=bf16, device=dev)
+                v0p[..., :hd].copy_(v_0)
+        Xo, v, bs = block._fwd(G, pre, X, ctx2d, cvec, v0p, cos2, sin2, B, L, Lc, need)
+        if need:
+            sv = _Saved()
+            sv.cos, sv.sin, sv.v0, sv.ctx2d, sv.cvec = cos2, sin2, v0p, ctx2d, cvec
+            ctx.state = (block, G, pre, bs, sv, (B, L, Lc, D, H, hd, hdp), x.dtype, c.dtype,
+                         v_0.dtype if v_0 is not None else None)
+        ctx.set_materialize_grads(False)
+        return Xo.view(B, L, D), v[..., :hd]
+
+    @staticmethod
+    def backward(ctx, dx, dv_out):
+        block, G, pre, bs, sv, (B, L, Lc, D, H, hd, hdp), xdt, cdt, v0dt = ctx.state
+        ctx.state = None
+        dev = sv.cvec.device
+        held = None
+        if any(p.grad is not None for p in G.params.values()):  # accumulate like autograd (see DiT._backward_impl)
+            held = G.gshard.clone()
+        G.gfull.zero_()
+        dX = (dx.reshape(B * L, D).to(bf16).contiguous() if dx is not None
+              else torch.zeros(B * L, D, dtype=bf16, device=dev))
+        dc = torch.zeros(B, D, dtype=f32, device=dev)
+        dv0 = None
+        if bs.mix:
+            if dv_out is not None:
+                raise NotImplementedError("DiTBlock: a gradient through the returned (lambda-mixed) v of a block "
+                                          "that was given v_0 is not implemented; the model only consumes block 0's v")
+            dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev)
+        elif dv_out is not None:
+            dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev)
+            dv0[..., :hd].copy_(dv_out)
+        dX0 = block._bwd(G, pre, bs, dX, sv, dc, dv0, B, L, Lc, first=(not bs.mix and dv0 is not None))
+        G.publish_grads()
+        if held is not None:
+            G.gshard.add_(held)
+        gv0 = dv0[..., :hd].to(v0dt) if (bs.mix and v0dt is not None) else None
+        n_params = len(list(block.parameters()))
+        return (None, None, dX0.view(B, L, D).to(xdt), None, dc.to(cdt), gv0, None, None) + (None,) * n_params
 
 
 class _DiTFunction(torch.autograd.Function):

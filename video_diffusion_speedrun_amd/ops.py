@@ -187,14 +187,17 @@ def attn_fwd(q, k, v, o, lse, kv_pad_ones: bool = False):
     check(_lib.load().vds_attn_fwd(C.byref(a), _stream()), f"vds_attn_fwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta, kv_pad_ones: bool = False):
-    """delta: f32 workspace of 2*B*H*Lq elements (rowsum(dO*O), then lse*log2 e)."""
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta=None, kv_pad_ones: bool = False):
+    """delta: f32 workspace of 2*B*H*Lq elements (rowsum(dO*O), then lse*log2 e); allocated here when None
+    (size from vds_attn_bwd_workspace_bytes)."""
     B, H, Lq, hd = q.shape
-    assert delta.numel() >= 2 * B * H * Lq and delta.is_contiguous(), "attn_bwd: delta workspace is [2,B,H,Lq] f32"
     assert lse.is_contiguous()
     Lk = k.shape[2]
     a = AttnArgs()
     a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, hd
+    if delta is None:
+        delta = torch.empty(_lib.load().vds_attn_bwd_workspace_bytes(C.byref(a)) // 4, dtype=f32, device=q.device)
+    assert delta.numel() >= 2 * B * H * Lq and delta.is_contiguous(), "attn_bwd: delta workspace is [2,B,H,Lq] f32"
     a.q, (a.q_sb, a.q_sh, a.q_sl) = _p(q), _st(q)
     a.k, (a.k_sb, a.k_sh, a.k_sl) = _p(k), _st(k)
     a.v, (a.v_sb, a.v_sh, a.v_sl) = _p(v), _st(v)
@@ -264,6 +267,18 @@ def qkv_rope_bwd(dq, dk, dv, cos, sin, qkv_raw, v0, lam, dv0_acc, dlam, mix, add
                                        _p(dv0_acc), _p(dlam), _p(dqkv), int(mix), int(add_dv0), B, L, H, hd, hdp,
                                        _stream()), "vds_qkv_rope_bwd")
     return dqkv
+
+
+def rope_apply(x, cos, sin, inverse: bool = False):
+    """apply_rotary_emb (model.py:266-275): x [B,H,L,hd] bf16 (last dim contiguous), cos / sin f32 [L, hd/2]"""
+    B, H, L, hd = x.shape
+    assert x.dtype == bf16 and x.stride(3) == 1 and cos.dtype == f32 and cos.shape == (L, hd // 2) == sin.shape
+    assert cos.is_contiguous() and sin.is_contiguous()
+    y = torch.empty(B, H, L, hd, dtype=bf16, device=x.device)
+    check(_lib.load().vds_rope_apply(_p(x), x.stride(0), x.stride(1), x.stride(2), _p(cos), _p(sin), _p(y),
+                                     y.stride(0), y.stride(1), y.stride(2), B, H, L, hd, int(inverse), _stream()),
+          "vds_rope_apply")
+    return y
 
 
 def rope_rows(tabs, thw, start, n_reg, device):

@@ -207,9 +207,15 @@ class FlatGroup:
         return out
 
 
-# ---- collectives (RCCL via torch.distributed "nccl"; gloo emulation for the CPU tests) -------
+# ---- collectives -------------------------------------------------------------------------------
+# GPU tensors: the library's own RCCL communicator (comm.py -> vds_all_gather_bf16 / vds_reduce_scatter_f32_avg,
+# asynchronous on the current HIP stream).  CPU tensors (gloo; the tests of the host logic) and VDS_COMM=torch:
+# torch.distributed.
 def all_gather_flat(out: torch.Tensor, inp: torch.Tensor, group=None):
-    if dist.get_backend(group) == "gloo":
+    from . import comm
+    if out.is_cuda and comm.active_for(group):
+        comm.all_gather(out, inp)
+    elif dist.get_backend(group) == "gloo":
         parts = list(out.view(dist.get_world_size(group), -1).unbind(0))
         if inp.dtype == torch.bfloat16:  # gloo has no bf16: move the raw bits
             dist.all_gather([p.view(torch.uint8) for p in parts], inp.view(torch.uint8), group=group)
@@ -220,7 +226,10 @@ def all_gather_flat(out: torch.Tensor, inp: torch.Tensor, group=None):
 
 
 def reduce_scatter_avg(out: torch.Tensor, inp: torch.Tensor, group=None):
-    if dist.get_backend(group) == "gloo":
+    from . import comm
+    if out.is_cuda and comm.active_for(group):
+        comm.reduce_scatter_avg(out, inp)
+    elif dist.get_backend(group) == "gloo":
         tmp = inp.clone()
         dist.all_reduce(tmp, group=group)
         w, r = dist.get_world_size(group), dist.get_rank(group)
