@@ -69,6 +69,11 @@ typedef struct vds_gemm_args {
 } vds_gemm_args;
 
 int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);
+/* Tests / experiments: pin the tiling vds_gemm_bf16 picks (0 = by its cost model (default), 128 = 128x128 tiles,
+ * 256 = 256x256, 2 = 256x128 with two workgroups per CU); returns the previous setting, VDS_ERR_ARG for other
+ * values.  The environment variable VDS_GEMM_TILE sets the initial value.  Results are identical across tilings up
+ * to fp32 summation order. */
+int vds_gemm_force_tile(int32_t tile);
 
 /* The same GEMM with OCP fp8 operands (BASELINE config 5; no reference counterpart -- the reference trains in
  * bf16): layout VDS_NT only, A[M,K] and B[N,K] one byte per element (a_fmt / b_fmt: 0 = e4m3fn, 1 = e5m2; B must

@@ -53,9 +53,18 @@ def test_lane_maps(ops):
 
 
 # ------------------------------------------------------------------------------- GEMM ----
+@pytest.fixture(params=[0, 128, 256, 2], ids=["auto", "t128", "t256", "t256x128"])
+def tile(request, ops):
+    """every GEMM test runs under the dispatcher's own choice and with each of the three tilings pinned
+    (vds_gemm_force_tile): 128x128, 256x256 and 256x128 (two workgroups per CU)"""
+    ops.gemm_force_tile(request.param)
+    yield request.param
+    ops.gemm_force_tile(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 384, 192), (1000, 1152, 1152), (4112, 128, 768),
                                    (131, 64, 64), (212, 432, 144), (77, 144, 72)])
-def test_gemm_nt_store_bias(ops, M, N, K):
+def test_gemm_nt_store_bias(ops, tile, M, N, K):
     x, w, b = gen(M, K, seed=1), gen(N, K, seed=2, scale=0.05), gen(N, seed=3)
     y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
     ref = x.float() @ w.float().t() + b.float()
@@ -65,7 +74,7 @@ def test_gemm_nt_store_bias(ops, M, N, K):
 
 
 @pytest.mark.parametrize("N", [1152, 3456, 1096, 1280])
-def test_gemm_large_m_ragged_last_column_tile(ops, N):
+def test_gemm_large_m_ragged_last_column_tile(ops, tile, N):
     """problems big enough for the 256^2 kernel whose N does not fill the last column of tiles (1152 = 4.5 tiles,
     3456 = 13.5, 1096 = 4 tiles + 72 columns; 1280 = 5 full tiles as the control): forward (bias), gate + residual
     epilogue and input gradient, ragged M (49248 = 192.4 tiles)"""
@@ -86,7 +95,7 @@ def test_gemm_large_m_ragged_last_column_tile(ops, N):
     close("stripe.nn", dx, dy.float() @ w2.float(), 4e-3)
 
 
-def test_gemm_nt_asymmetric_identity(ops):
+def test_gemm_nt_asymmetric_identity(ops, tile):
     """A = I against an asymmetric B catches transposed / permuted fragment maps."""
     K = 128
     a = torch.eye(K).to(bf16)
@@ -95,7 +104,7 @@ def test_gemm_nt_asymmetric_identity(ops):
     assert torch.equal(y.cpu().float(), w.float().t().contiguous())
 
 
-def test_gemm_nt_gelu(ops):
+def test_gemm_nt_gelu(ops, tile):
     M, N, K = 520, 512, 256
     x, w, b = gen(M, K, seed=4), gen(N, K, seed=5, scale=0.08), gen(N, seed=6, scale=0.5)
     pre, act = ops.linear_fwd_gelu(x.cuda(), w.cuda(), b.cuda())
@@ -104,7 +113,7 @@ def test_gemm_nt_gelu(ops):
     close("gelu.act", act, O.gelu_erf(ref), 5e-3)
 
 
-def test_gemm_nt_gate_residual(ops):
+def test_gemm_nt_gate_residual(ops, tile):
     B, L, N, K = 3, 173, 384, 256
     M = B * L
     x, w, res = gen(M, K, seed=7), gen(N, K, seed=8, scale=0.06), gen(M, N, seed=9)
@@ -121,14 +130,14 @@ def test_gemm_nt_gate_residual(ops):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (777, 1152, 384), (4112, 768, 3072), (200, 128, 64),
                                    (212, 432, 144), (90, 200, 72)])
-def test_gemm_nn_dgrad(ops, M, N, K):
+def test_gemm_nn_dgrad(ops, tile, M, N, K):
     """dx[M,K] = dy[M,N] W[N,K]"""
     dy, w = gen(M, N, seed=12), gen(N, K, seed=13, scale=0.05)
     dx = ops.linear_dgrad(dy.cuda(), w.cuda())
     close("nn", dx, dy.float() @ w.float(), 4e-3)
 
 
-def test_gemm_nn_asymmetric_identity(ops):
+def test_gemm_nn_asymmetric_identity(ops, tile):
     N = 128
     dy = torch.eye(N).to(bf16)
     w = (torch.arange(N * 384).reshape(N, 384) % 241 - 120).float().to(bf16)
@@ -136,7 +145,7 @@ def test_gemm_nn_asymmetric_identity(ops):
     assert torch.equal(dx.cpu().float(), w.float())
 
 
-def test_gemm_nn_dgelu(ops):
+def test_gemm_nn_dgelu(ops, tile):
     M, N, K = 333, 256, 512
     dy, w, pre = gen(M, N, seed=14), gen(N, K, seed=15, scale=0.05), gen(M, K, seed=16)
     dx = ops.linear_dgrad(dy.cuda(), w.cuda(), pre.cuda())
@@ -147,7 +156,7 @@ def test_gemm_nn_dgelu(ops):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 384, 1152), (4112, 1152, 384), (8208, 128, 768),
                                    (77, 64, 128)])
-def test_gemm_tn_wgrad(ops, M, N, K):
+def test_gemm_tn_wgrad(ops, tile, M, N, K):
     """dW[N,K] = dy[M,N]^T x[M,K], ragged token count M, fp32 out, split-K atomics"""
     dy, x = gen(M, N, seed=17), gen(M, K, seed=18)
     dW = torch.zeros(N, K, dtype=f32, device="cuda")
@@ -155,7 +164,7 @@ def test_gemm_tn_wgrad(ops, M, N, K):
     close("tn", dW, dy.float().t() @ x.float(), 2e-3)
 
 
-def test_gemm_tn_asymmetric(ops):
+def test_gemm_tn_asymmetric(ops, tile):
     M = 192
     dy = torch.zeros(M, 128)
     dy[torch.arange(128), torch.arange(128)] = 1  # dy^T x = x[:128]

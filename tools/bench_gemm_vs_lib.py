@@ -28,7 +28,9 @@ def rnd(*shape, scale=1.0, dtype=bf16):
 
 B, L, D = int(os.environ.get("B", 6)), 8208, 1152
 M = B * L
-print(f"{'shape':40s} {'ours ms':>9s} {'TF/s':>8s} {'lib ms':>9s} {'TF/s':>8s}")
+TILES = [int(t) for t in os.environ.get("TILES", "0").split(",")]  # 0 auto, 128, 256, 2 (= 256x128, 2 WG / CU)
+NOLIB = os.environ.get("NOLIB") == "1"
+print(f"{'shape':40s} " + " ".join(f"{'t' + str(t) + ' ms':>9s} {'TF/s':>7s}" for t in TILES) + f" {'lib ms':>9s} {'TF/s':>8s}")
 for name, N, K in (("qkv", 3 * D, D), ("proj", D, D), ("fc1", 4 * D, D), ("fc2", D, 4 * D), ("ctxkv", 2 * D, 4096)):
     Mx = B * 512 if name == "ctxkv" else M
     x, w = rnd(Mx, K), rnd(N, K, scale=0.03)
@@ -41,5 +43,11 @@ for name, N, K in (("qkv", 3 * D, D), ("proj", D, D), ("fc1", 4 * D, D), ("fc2",
         ("NN dgrad", lambda: ops.linear_dgrad(dy, w), lambda: torch.matmul(dy, w)),
         ("TN wgrad", lambda: ops.linear_wgrad(dy, x, dW), lambda: torch.matmul(dy.t(), x)),
     ):
-        to, tl = timeit(ours), timeit(lib)
-        print(f"{tag:9s} {name:6s} M{Mx} N{N} K{K:5d}     {to*1e3:9.3f} {fl/to/1e12:8.1f} {tl*1e3:9.3f} {fl/tl/1e12:8.1f}")
+        cols = []
+        for t in TILES:
+            ops.gemm_force_tile(t)
+            to = timeit(ours)
+            cols.append(f"{to*1e3:9.3f} {fl/to/1e12:7.1f}")
+        ops.gemm_force_tile(0)
+        tl = float("nan") if NOLIB else timeit(lib)
+        print(f"{tag:9s} {name:6s} M{Mx} N{N} K{K:5d}     " + " ".join(cols) + f" {tl*1e3:9.3f} {fl/tl/1e12:8.1f}", flush=True)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "vds_version": [],
     "vds_last_error": [],
     "vds_gemm_bf16": [C.POINTER(GemmArgs), c_vp],
+    "vds_gemm_force_tile": [c_i32],
     "vds_attn_fwd": [C.POINTER(AttnArgs), c_vp],
     "vds_attn_bwd": [C.POINTER(AttnArgs), c_vp],
     "vds_attn_bwd_workspace_bytes": [C.POINTER(AttnArgs)],

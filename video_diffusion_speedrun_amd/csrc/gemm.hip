@@ -705,6 +705,202 @@ int launch(const GemmP& p, hipStream_t s) {
 }
 }  // namespace big
 
+// =====================================================================================
+// 256 x 128 x 32 tile, 4 waves (2 x 2), TWO workgroups per CU: the kernel for N = 1152-class problems.
+//
+// Why a third tiling: at the DiT-XL shapes the 256^2 kernel (one workgroup per CU) leaves two things on the table
+// when N = 1152 and / or K = 1152 -- 1152 = 4.5 tiles of 256 (10 % of the MFMA work is padding) and the per-tile
+// prologue + epilogue (~4.5 K-tile times, 16-19 % of a K = 1152 launch) is exposed because nothing else runs on the
+// CU meanwhile.  Here 1152 = 9 x 128 exactly, and the two co-resident workgroups are not synchronised with each
+// other, so one's epilogue / pipeline fill runs under the other's main loop.
+//   * each wave owns 128 x 64 outputs (8 x 4 v_mfma_f32_16x16x32_bf16 tiles, 128 accumulator VGPRs) -- the same
+//     wave tile, hence the same LDS reads per MFMA, as the 256^2 kernel;
+//   * BK = 32: a stage is A[256][32] + B[128][32] = 24 KiB; three stages (72 KiB, so that two workgroups fit in the
+//     160 KiB of a CU) give a prefetch distance of two K steps with ONE counted wait (vmcnt(6) = "all but the
+//     youngest stage have landed") and one barrier per K step;
+//   * k-contiguous stages have 64-byte rows: the bank swizzle is chunk ^ T[(row >> 2) & 3], T = {0, 2, 3, 1}, which
+//     makes every ds_read_b128 lane group of a 16-row x 32-k fragment read hit 16 different quad-banks (applied to
+//     the per-lane SOURCE address of the LDS-DMA and again on the fragment read, like the 128-byte-row swizzle);
+//     k-major stages ([32 k][128] halves) use the 128^2 kernel's format and ds_read_b64_tr_b16.
+namespace mid {
+constexpr int BM = 256, BN = 128, BK = 32;
+constexpr int A_BYTES = 16384, B_BYTES = 8192, STAGE = A_BYTES + B_BYTES;
+constexpr int LDS_BYTES = 3 * STAGE;  // 73728 >= the epilogue's 4 x 64 x EPI_LD floats (69632)
+static_assert(LDS_BYTES >= 4 * 64 * EPI_LD * 4, "epilogue staging must fit in the stage ring");
+
+__device__ __forceinline__ int swz32(int row) {
+  const int h = (row >> 2) & 3;
+  return (((h >> 1) ^ h) & 1) << 1 | (h >> 1);
+}
+
+// per-lane source byte offsets of the NP 1-KiB pieces this wave stages of one operand stage
+//   k-contiguous [ROWS][32 k]: piece q = 16 rows; k-major [32 k][ROWS cols] as ROWS/128 tiles of [32][128]: piece = 4 k rows
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void offsets(unsigned (&voff)[ROWS / 64], int (&kchunk)[ROWS / 64], int wave, int lane,
+                                        long ld, int origin) {
+  constexpr int NP = ROWS / 64;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int q = wave * NP + j;
+    if constexpr (!KMAJOR) {
+      const int row = q * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ swz32(row);
+      kchunk[j] = chunk * 8;
+      voff[j] = (unsigned)(((long)(origin + row) * ld + chunk * 8) * 2);
+    } else {
+      const int t = q >> 3, krow = (q & 7) * 4 + (lane >> 4);  // tile t = columns t*128..
+      const int pc = lane & 15;
+      const int chunk = (((pc >> 1) ^ swz_km(krow)) << 1) | (pc & 1);
+      kchunk[j] = krow;
+      voff[j] = (unsigned)(((long)krow * ld + origin + t * 128 + chunk * 8) * 2);
+    }
+  }
+}
+
+template <bool KMAJOR, int NP>
+__device__ __forceinline__ void issue(srd_t rsrc, char* slot, const unsigned (&voff)[NP], const int (&kchunk)[NP],
+                                      unsigned koff, int krem, int wave) {
+  const unsigned base = lds_addr_of(slot) + wave * NP * 1024;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    unsigned off = voff[j] + koff;
+    if (kchunk[j] >= krem) off = 0xfffffff0u;  // K tail / steps past the range: zeros (keeps the wait counts uniform)
+    lds_dma16(rsrc, base + j * 1024, off);
+  }
+}
+
+__device__ __forceinline__ bf16x8 frag_kc32(const char* tile, int row0, int lane) {
+  const int row = row0 + (lane & 15);
+  const int pc = (lane >> 4) ^ swz32(row);
+  return *reinterpret_cast<const bf16x8*>(tile + row * 64 + pc * 16);
+}
+
+template <int LAYOUT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool A_KM = (LAYOUT == VDS_TN);
+  constexpr bool B_KM = (LAYOUT != VDS_NT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int group = p.group_m * p.tiles_n;
+  const int first_m = (pid / group) * p.group_m;
+  const int gsz = min(p.tiles_m - first_m, p.group_m);
+  const int tile_m = first_m + (pid % group) % gsz;
+  const int tile_n = (pid % group) / gsz;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int kt_total = (p.K + BK - 1) / BK;
+  int kt_begin = 0, kt_end = kt_total;
+  if (p.split_k > 1) {
+    int per = (kt_total + p.split_k - 1) / p.split_k;
+    kt_begin = blockIdx.y * per;
+    kt_end = min(kt_total, kt_begin + per);
+    if (kt_begin >= kt_end) return;
+  }
+
+  const srd_t ra = make_srd(p.A, p.a_bytes);
+  const srd_t rb = make_srd(p.B, p.b_bytes);
+  unsigned va[4], vb[2];
+  int ca[4], cb[2];
+  offsets<A_KM, 256>(va, ca, wave, lane, p.lda, m0);
+  offsets<B_KM, 128>(vb, cb, wave, lane, p.ldb, n0);
+  const unsigned a_step = A_KM ? (unsigned)(BK * p.lda * 2) : BK * 2;
+  const unsigned b_step = B_KM ? (unsigned)(BK * p.ldb * 2) : BK * 2;
+
+  auto stage_in = [&](int T, int slot) {
+    const int krem = (T < kt_end) ? p.K - T * BK : 0;
+    char* st = smem + slot * STAGE;
+    issue<A_KM, 4>(ra, st, va, ca, (unsigned)T * a_step, krem, wave);
+    issue<B_KM, 2>(rb, st + A_BYTES, vb, cb, (unsigned)T * b_step, krem, wave);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage_in(kt_begin, 0);
+  stage_in(kt_begin + 1, 1);
+  VDS_WAIT_VM(6);  // the first stage has landed (the 6 youngest pieces are the second)
+  __builtin_amdgcn_s_barrier();
+
+  auto k_step = [&](int T, auto SLOT) {
+    constexpr int slot = decltype(SLOT)::value;
+    stage_in(T + 2, (slot + 2) % 3);  // the slot every wave finished reading before the last barrier
+    const char* ta = smem + slot * STAGE;
+    const char* tb = ta + A_BYTES;
+    bf16x8 fa[8], fb[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (A_KM) fa[i] = frag_km(ta + wm * B_BYTES, i * 16, 0, lane);  // [32][128] half wm of the 256 rows
+      else fa[i] = frag_kc32(ta, wm * 128 + i * 16, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (B_KM) fb[j] = frag_km(tb, wn * 64 + j * 16, 0, lane);
+      else fb[j] = frag_kc32(tb, wn * 64 + j * 16, lane);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    VDS_WAIT_VM(6);  // stage T+1 landed (this wave's pieces; the barrier publishes everyone's)
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int T = kt_begin; T < kt_end; T += 3) {
+    k_step(T, std::integral_constant<int, 0>{});
+    if (T + 1 < kt_end) k_step(T + 1, std::integral_constant<int, 1>{});
+    if (T + 2 < kt_end) k_step(T + 2, std::integral_constant<int, 2>{});
+  }
+  VDS_WAIT_VM(0);  // the zero-fill tail DMAs target LDS the epilogue reuses
+  __builtin_amdgcn_s_barrier();
+
+  float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
+  float cs_unused[8];
+  u32x2 ew_unused[8];
+#pragma unroll
+  for (int qa = 0; qa < 2; ++qa) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stg[(i * 16 + 4 * (lane >> 4) + r) * EPI_LD + j * 16 + (lane & 15)] = acc[qa * 4 + i][j][r];
+    VDS_WAIT_LGKM0();
+    __builtin_amdgcn_wave_barrier();
+    epilogue_64x64<EPI>(p, stg, m0 + wm * 128 + qa * 64, n0 + wn * 64, lane, cs_unused, ew_unused);
+    __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
+  }
+}
+
+template <int LAYOUT, int EPI>
+int launch(const GemmP& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, p.split_k > 1 ? p.split_k : 1, 1);
+  vdsprof::Scope ps(LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : LAYOUT == VDS_NN ? VDS_PROF_GEMM_NN : VDS_PROF_GEMM_TN, s,
+                    2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI>), grid, dim3(256), LDS_BYTES, s, p);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+}  // namespace mid
+
 thread_local char g_err[256] = "";
 
 template <int LAYOUT, int EPI>
@@ -723,6 +919,15 @@ int launch(const GemmP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+static int g_force_tile = -1;  // -1: read VDS_GEMM_TILE on first use; 0 auto; 128 | 256 | 2 (= 256 x 128) forced
+
+extern "C" int vds_gemm_force_tile(int32_t tile) {
+  const int prev = g_force_tile < 0 ? 0 : g_force_tile;
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 2) return VDS_ERR_ARG;
+  g_force_tile = tile;
+  return prev;
+}
 
 extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   if (!a || !a->A || !a->B || a->M <= 0 || a->N <= 0 || a->K <= 0) return VDS_ERR_ARG;
@@ -773,11 +978,11 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   if (!a->C && a->epilogue != VDS_EPI_GATE_RES) return VDS_ERR_ARG;
   // tile choice: 256^2 (one workgroup per CU, deep LDS-DMA pipeline) for problems that fill the chip
   // with such tiles; 128^2 otherwise.  VDS_GEMM_TILE=128|256 forces one (experiments).
-  static int force_tile = -1;
-  if (force_tile < 0) {
+  if (g_force_tile < 0) {
     const char* e = getenv("VDS_GEMM_TILE");
-    force_tile = e ? atoi(e) : 0;
+    g_force_tile = e ? atoi(e) : 0;
   }
+  const int force_tile = g_force_tile;
   // model: a 256^2 workgroup (alone on its CU) sustains ~1.24x the rate of two co-resident 128^2
   // workgroups; compare the number of rounds each tiling needs (wave quantisation dominates at
   // these sizes).  Weight gradients (TN, split-K + atomics) stay on the 128^2 kernel.
@@ -790,9 +995,39 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   static int group_m = -1;
   if (group_m < 0) {
     const char* e = getenv("VDS_GEMM_GROUP_M");
-    group_m = e ? atoi(e) : 4;  // 256^2 kernel: groups of 4 row tiles (1024 rows) measured best at the DiT shapes
+    group_m = e ? atoi(e) : 4;  // groups of 4 row tiles (1024 rows) measured best at the DiT shapes
   }
   p.group_m = group_m;
+  // 256 x 128 tiles, two workgroups per CU: no padded half tile when N is a multiple of 128 but not of 256, and the
+  // epilogue of one workgroup runs under the main loop of the other.  Model (same units as above): a round of 512
+  // such tiles costs what a round of 256 tiles of 256^2 costs, times ~1.0.  VDS_GEMM_TILE=2 forces it.
+  {
+    const int tmm = cdiv(a->M, 256), tnm = cdiv(a->N, 128);
+    const double rounds_mid = (double)((long)tmm * tnm + 511) / 512;  // not rounded up: the tail round is half-price per tile
+    static double mid_factor = -1.0;
+    if (mid_factor < 0) {
+      const char* e = getenv("VDS_GEMM_MID_FACTOR");
+      mid_factor = e ? atof(e) : 1.0;
+    }
+    const double cost_mid = (double)(((long)tmm * tnm + 511) / 512) * mid_factor;
+    const double cost_big = (double)rounds_big, cost_small = (double)rounds_small * (1.24 / 2.0);
+    bool use_mid = a->K >= 128 && cost_mid < (use_big ? cost_big : cost_small) && a->layout != VDS_TN;
+    (void)rounds_mid;
+    if (force_tile == 2) use_mid = true;
+    if (force_tile == 128 || force_tile == 256) use_mid = false;
+    if (use_mid) {
+      p.tiles_m = tmm;
+      p.tiles_n = tnm;
+#define GOM(L, E) if (a->layout == L && a->epilogue == E) return mid::launch<L, E>(p, s);
+      GOM(VDS_NT, VDS_EPI_STORE)
+      GOM(VDS_NT, VDS_EPI_BIAS_GELU)
+      GOM(VDS_NT, VDS_EPI_GATE_RES)
+      GOM(VDS_NN, VDS_EPI_STORE)
+      GOM(VDS_NN, VDS_EPI_DGELU)
+      GOM(VDS_TN, VDS_EPI_F32)
+#undef GOM
+    }
+  }
   if (use_big) {
     p.tiles_m = tm;
     p.tiles_n = tn;

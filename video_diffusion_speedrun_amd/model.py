@@ -693,13 +693,13 @@ class DiT(nn.Module):
         # gradients already held in p.grad (a second backward before zero_grad: micro-batch accumulation, like
         # autograd's accumulate-into-.grad in the reference loop) are set aside and added back at the end
         held = None
-        if any(p.grad is not None for g in self._groups for p in g.params.values()):
+        if any(q.grad is not None for g in self._groups for q in g.params.values()):
             for g in self._groups:
-                for p in g.params.values():
-                    if p.grad is not None and p.grad.data_ptr() != p._vds_grad_view.data_ptr():
+                for q in g.params.values():
+                    if q.grad is not None and q.grad.data_ptr() != q._vds_grad_view.data_ptr():
                         raise RuntimeError("DiT backward: a parameter's .grad was replaced by a foreign tensor; "
                                            "call zero_grad(set_to_none=True) before backward")
-            held = [g.gshard.clone() if any(p.grad is not None for p in g.params.values()) else None
+            held = [g.gshard.clone() if any(q.grad is not None for q in g.params.values()) else None
                     for g in self._groups]
         for g in self._groups:
             g.gfull.zero_()

@@ -44,6 +44,14 @@ def gemm(layout: int, epi: int, M: int, N: int, K: int, A, lda, B, ldb, Cp=None,
     check(_lib.load().vds_gemm_bf16(C.byref(a), _stream()), f"vds_gemm_bf16(layout={layout},epi={epi},M={M},N={N},K={K})")
 
 
+def gemm_force_tile(tile: int) -> int:
+    """tests / experiments: pin the GEMM tiling (0 auto, 128, 256, 2 = 256x128); returns the previous setting"""
+    prev = _lib.load().vds_gemm_force_tile(int(tile))
+    if prev < 0:
+        raise ValueError(f"vds_gemm_force_tile({tile}): not a tiling")
+    return prev
+
+
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = x W^T + b.  x [M,K] bf16, W [N,K] bf16 -> y [M,N] bf16."""
