@@ -46,9 +46,8 @@ const char* vds_last_error(void);
  *   VDS_EPI_GATE_RES   C = bf16(y), C2 = bf16(aux[m,n] + y*gate[m/rows_per_batch, n]),
  *                      y = acc + bias[n]                         (model.py:138-139,159-160,165)
  *   VDS_EPI_DGELU      C = bf16(acc * gelu'(aux[m,n]))           (backward of model.py:85)
- *   VDS_EPI_F32        C(f32) = acc; with split_k > 1 the K range is split over blockIdx.y and C (pre-zeroed)
- *                      is accumulated atomically; split_k < 0 means |split_k| splits with atomic
- *                      accumulation even for one split (several calls summing into one C)
+ *   VDS_EPI_F32        C(f32) = acc; a K split (vds_gemm_args.split_k) runs over blockIdx.y and accumulates
+ *                      atomically into the pre-zeroed C; the accumulate forms let several calls sum into one C
  * Requirements: K % 8 == 0 for NT / NN (any K for TN); N % 8 == 0 (TN: M % 8 == 0 too);
  * ld* % 8 == 0; every tensor < 4 GiB. */
 enum { VDS_NT = 0, VDS_NN = 1, VDS_TN = 2 };
@@ -65,7 +64,9 @@ typedef struct vds_gemm_args {
   const void* aux; int64_t ldaux; /* bf16 [M,N]: residual (GATE_RES) or pre-activation (DGELU) */
   const float* gate; int64_t ldgate; /* f32 [batch, ldgate], column n */
   int32_t rows_per_batch;
-  int32_t split_k;             /* TN only; 0/1 = none, >1 split + atomics, <0 accumulate */
+  int32_t split_k;             /* TN + F32 only: 0 = the library picks tiling and K split (atomics iff it splits; C
+                                  pre-zeroed), -1 = the same but always accumulating atomically into C, 1 = no
+                                  split, > 1 = that many splits + atomics, <= -2 = |split_k| splits, accumulate */
 } vds_gemm_args;
 
 int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);
@@ -207,9 +208,10 @@ int vds_rope_rows_dev(const float* tab_t_cos, const float* tab_t_sin, const floa
                       const int32_t* start_dev, int32_t n_reg, float* cosb, float* sinb, vds_stream_t stream);
 
 /* ------------------------------------------------------------- small-M linears (B rows) --
- * y[b, n] = act_out( sum_k act_in(x[b,k]) * W[n,k] + bias[n] ), M = B <= 16 rows:
- * time_embed / adaLN_modulation / final_modulation (model.py:90,318-322,339-341).
- * x f32 [M,K]; W bf16 [N,K]; bias bf16 [N]; y f32 [M,N].  act: 0 none, 1 SiLU. */
+ * y[b, n] = act_out( sum_k act_in(x[b,k]) * W[n,k] + bias[n] ), M = B rows (the per-GPU batch; any M >= 1, run
+ * in chunks of <= 16 rows that stay in registers): time_embed / adaLN_modulation / final_modulation
+ * (model.py:90,318-322,339-341).  x f32 [M,K]; W bf16 [N,K]; bias bf16 [N]; y f32 [M,N].  act: 0 none, 1 SiLU.
+ * K % 8 == 0. */
 int vds_small_linear_fwd(const float* x, const void* W, const void* bias, float* y, int32_t M,
                          int32_t N, int32_t K, int32_t act_in, vds_stream_t stream);
 /* dW[n,k] (f32) = sum_b dy[b,n]*act_in(x[b,k]);  dbias[n] (f32) = sum_b dy[b,n]  (overwritten);

@@ -392,7 +392,8 @@ def test_qkv_rope_fwd_bwd(ops, hd, hdp):
 
 
 # -------------------------------------------------------------------- small linears ----
-@pytest.mark.parametrize("M,N,K", [(4, 1152, 384), (6, 3456, 1152), (13, 203, 72), (16, 70, 1160), (1, 33, 8)])
+@pytest.mark.parametrize("M,N,K", [(4, 1152, 384), (6, 3456, 1152), (13, 203, 72), (16, 70, 1160), (1, 33, 8),
+                                   (37, 1152, 384), (64, 144, 72)])  # > 16 rows: per-rank batches up to train.py:150's 64
 def test_small_linear_and_timestep(ops, M, N, K):
     x = gen(M, K, seed=80, dtype=f32)
     W, b = gen(N, K, seed=81, scale=0.05), gen(N, seed=82, scale=0.1)

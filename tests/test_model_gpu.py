@@ -255,6 +255,7 @@ def test_full_size_properties_dit_xl_block(vds):
     l1, _ = vds["train"].flow_loss(o1, v1)
     l1.backward()
     g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()  # a second backward without it accumulates into .grad, like autograd
     o2 = m(x1.repeat(2, 1, 1, 1, 1), c1.repeat(2, 1, 1), t1.repeat(2), rope_start=start)
     assert torch.equal(o2[0], o2[1]) and torch.equal(o2[0], o1[0])
     l2, _ = vds["train"].flow_loss(o2, v1.repeat(2, 1, 1, 1, 1))
@@ -779,3 +780,28 @@ def test_upstream_gradient_and_accumulation_like_autograd(vds):
     for k in full:
         if float(full[k].abs().max()) > 0 and not k.endswith("lambda_param"):
             assert rel(acc[k], full[k]) <= 1e-2, (k, rel(acc[k], full[k]))
+
+
+def test_per_gpu_batch_above_16(vds):
+    """the reference's default is 64 samples per rank (train.py:150): B = 18 through the whole step vs the oracle"""
+    cfg = O.DiTConfig(in_channels=16, hidden_size=128, depth=2, num_heads=2, cross_attn_input_size=64,
+                      residual_v=True, train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=27, randomize_zero_init=True, init_std_factor=1.0)
+    g = torch.Generator().manual_seed(28)
+    B = 18
+    x = torch.randn(B, 16, 2, 8, 8, generator=g).to(bf16)
+    ctx = torch.randn(B, 8, 64, generator=g).to(bf16)
+    t = torch.rand(B, generator=g).to(bf16)
+    v = torch.randn(B, 16, 2, 8, 8, generator=g).to(bf16)
+    Pg = {k: w.clone().requires_grad_(True) for k, w in P.items()}
+    o_ref = O.dit_forward(Pg, cfg, x.float(), ctx.float(), t.float(), (1, 2, 3))
+    l_ref, _ = O.flow_loss(v, o_ref)
+    l_ref.backward()
+    m = build(vds, cfg, P)
+    out = m(x.cuda(), ctx.cuda(), t.cuda(), rope_start=(1, 2, 3))
+    assert rel(out, o_ref) <= 2.5e-2
+    loss, _ = vds["train"].flow_loss(out, v.cuda())
+    loss.backward()
+    for k, p in m.named_parameters():
+        if Pg[k].grad is not None and not k.endswith("lambda_param") and float(Pg[k].grad.abs().max()) > 0:
+            assert cosine(p.grad, Pg[k].grad) >= 0.99 and rel(p.grad, Pg[k].grad) <= 6e-2, k

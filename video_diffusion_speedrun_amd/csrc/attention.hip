@@ -984,7 +984,9 @@ int run_bwd(AttnP p, hipStream_t s) {
     once = true;
   }
   const long rows = (long)p.B * p.H * p.Lq;
-  // algorithmic backward = 5 products of 2*Lq*Lk*hd (S, dP, dV, dK, dQ): dkv carries 3 of them, dq 2
+  // ALGORITHMIC backward = 2 x forward = 4 products of 2*Lq*Lk*hd (train step = 3 x forward FLOPs, no
+  // credit for the recomputed S, nor for the dP the split backward computes twice): dK/dV kernel 2 (dV, dK), dQ
+  // kernel 2 (dP, dQ).  The kernels EXECUTE 4 + 3 = 7 products (and head-dim padding on top).
   const double prod = 2.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
   const double qb = 2.0 * p.B * p.H * p.hd * (double)p.Lq, kb = 2.0 * p.B * p.H * p.hd * (double)p.Lk;
   {
@@ -1003,7 +1005,7 @@ int run_bwd(AttnP p, hipStream_t s) {
   {
     bool ones_kv = false;
     if constexpr (HDP == 96) ones_kv = p.kv_pad_ones && p.hd == 72;
-    vdsprof::Scope ps(ones_kv ? VDS_PROF_ATTN_BWD_DKV : VDS_PROF_ATTN_BWD_DKV_PLAIN, s, 3.0 * prod, 2.0 * qb + 4.0 * kb);
+    vdsprof::Scope ps(ones_kv ? VDS_PROF_ATTN_BWD_DKV : VDS_PROF_ATTN_BWD_DKV_PLAIN, s, 2.0 * prod, 2.0 * qb + 4.0 * kb);
     if constexpr (HDP == 96) {
       if (ones_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DKV, s, p);
     }

@@ -935,23 +935,29 @@ extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, 
 
 extern "C" int vds_small_linear_fwd(const float* x, const void* W, const void* bias, float* y, int32_t M,
                                     int32_t N, int32_t K, int32_t act_in, vds_stream_t stream) {
-  if (!x || !W || !y || M < 1 || M > 16 || (K & 7)) return VDS_ERR_ARG;
+  if (!x || !W || !y || M < 1 || (K & 7)) return VDS_ERR_ARG;
   const dim3 grid((N + 15) / 16);
-  if (M <= 4)
-    hipLaunchKernelGGL(small_linear_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)W,
-                       (const bf16_t*)bias, y, M, N, K, act_in);
-  else if (M <= 8)
-    hipLaunchKernelGGL(small_linear_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)W,
-                       (const bf16_t*)bias, y, M, N, K, act_in);
-  else
-    hipLaunchKernelGGL(small_linear_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)W,
-                       (const bf16_t*)bias, y, M, N, K, act_in);
+  // the kernels keep <= 16 rows in registers: larger batches (the reference trains with up to 64 samples per rank,
+  // train.py:150) run as row chunks -- rows are independent
+  for (int r0 = 0; r0 < M; r0 += 16) {
+    const int m = min(16, M - r0);
+    const float* xs = x + (long)r0 * K;
+    float* ys = y + (long)r0 * N;
+    if (m <= 4)
+      hipLaunchKernelGGL(small_linear_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, xs, (const bf16_t*)W,
+                         (const bf16_t*)bias, ys, m, N, K, act_in);
+    else if (m <= 8)
+      hipLaunchKernelGGL(small_linear_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, xs, (const bf16_t*)W,
+                         (const bf16_t*)bias, ys, m, N, K, act_in);
+    else
+      hipLaunchKernelGGL(small_linear_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, xs, (const bf16_t*)W,
+                         (const bf16_t*)bias, ys, m, N, K, act_in);
+  }
   return ok();
 }
-
 extern "C" int vds_small_linear_bwd(const float* dy, const float* x, const void* W, float* dW, float* dbias,
                                     float* dx, int32_t M, int32_t N, int32_t K, int32_t act_in, vds_stream_t stream) {
-  if (!dy || !x || M < 1 || M > 16 || (K & 7)) return VDS_ERR_ARG;
+  if (!dy || !x || M < 1 || (K & 7)) return VDS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (dW) {
     const long n = (long)((N + 3) / 4) * (K >> 3);
@@ -964,12 +970,18 @@ extern "C" int vds_small_linear_bwd(const float* dy, const float* x, const void*
     const int rows = ((N + ny - 1) / ny + 31) / 32 * 32;
     ny = (N + rows - 1) / rows;
     const dim3 grid(gx, ny);
-    if (M <= 4)
-      hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)W, dx, M, N, K, act_in, rows);
-    else if (M <= 8)
-      hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)W, dx, M, N, K, act_in, rows);
-    else
-      hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)W, dx, M, N, K, act_in, rows);
+    for (int r0 = 0; r0 < M; r0 += 16) {  // <= 16 rows per launch (rows are independent; dx accumulates)
+      const int m = min(16, M - r0);
+      const float* dys = dy + (long)r0 * N;
+      const float* xs = x + (long)r0 * K;
+      float* dxs = dx + (long)r0 * K;
+      if (m <= 4)
+        hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows);
+      else if (m <= 8)
+        hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows);
+      else
+        hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows);
+    }
   }
   return ok();
 }

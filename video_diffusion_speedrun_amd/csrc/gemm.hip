@@ -941,7 +941,10 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   p.aux = (const bf16_t*)a->aux; p.ldaux = a->ldaux;
   p.gate = a->gate; p.ldgate = a->ldgate;
   p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
-  // split_k < 0: |split_k| splits and atomic accumulation into C even for a single split
+  // split_k: > 1 that many K splits (atomic accumulation into a pre-zeroed C); 1 none; <= -2: |split_k| splits and
+  // atomic accumulation; 0 / -1 (TN + F32 only): the library picks tiling and split count itself (-1: and always
+  // accumulates atomically, so that several calls can sum into one C)
+  const bool auto_split = (a->split_k == 0 || a->split_k == -1) && a->layout == VDS_TN && a->epilogue == VDS_EPI_F32;
   p.split_k = a->split_k > 1 ? a->split_k : (a->split_k < -1 ? -a->split_k : 1);
   p.atomic = (a->split_k > 1 || a->split_k < 0) ? 1 : 0;
   p.sa = p.sb = nullptr;
@@ -998,6 +1001,42 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     group_m = e ? atoi(e) : 4;  // groups of 4 row tiles (1024 rows) measured best at the DiT shapes
   }
   p.group_m = group_m;
+  if (auto_split) {
+    // weight gradient dW[M = out features, N = in features] = dy^T x over K = tokens: few output tiles, long K.
+    // Candidates: 128^2 tiles (two workgroups per CU) and 256 x 128 tiles (two per CU, ~g_mid_tn x the per-CU rate:
+    // half the transposing LDS reads per MFMA).  Cost of (tiling, s splits) in units of one 128^2 tile x 64-token
+    // step: rounds of 512 co-resident workgroups x K steps per split x tile size, plus the fp32-atomic traffic of
+    // the partial tiles (64 KB per 128^2 tile at the chip-wide ~1.3 TB/s, ~0.034 units each).
+    static double mid_tn = -1.0;
+    if (mid_tn < 0) {
+      const char* e = getenv("VDS_GEMM_MID_TN");
+      mid_tn = e ? atof(e) : 0.85;  // relative time per unit of work of the 256 x 128 kernel on TN problems
+    }
+    const long kt = cdiv(a->K, 64);
+    double best = 1e300;
+    int best_tile = 128, best_s = 1;
+    for (int cand = 0; cand < 2; ++cand) {
+      if ((cand == 0 && force_tile == 2) || (cand == 1 && (force_tile == 128 || force_tile == 256))) continue;
+      const long tiles = cand == 0 ? (long)cdiv(a->M, 128) * cdiv(a->N, 128) : (long)cdiv(a->M, 256) * cdiv(a->N, 128);
+      const double unit = cand == 0 ? 1.0 : 2.0 * mid_tn, atom = cand == 0 ? 0.034 : 0.068;
+      for (int sp = 1; sp <= 32; ++sp) {
+        if (sp > 1 && kt / sp < 8) break;
+        const long rounds = (tiles * sp + 511) / 512;
+        const double cost = (double)rounds * (double)((kt + sp - 1) / sp) * unit + (sp > 1 ? tiles * sp * atom : 0.0);
+        if (cost < best - 1e-9) { best = cost; best_tile = cand == 0 ? 128 : 2; best_s = sp; }
+      }
+    }
+    p.split_k = best_s;
+    p.atomic = (best_s > 1 || a->split_k == -1) ? 1 : 0;
+    if (force_tile != 256) {
+      if (best_tile == 2) {
+        p.tiles_m = cdiv(a->M, 256);
+        p.tiles_n = cdiv(a->N, 128);
+        return mid::launch<VDS_TN, VDS_EPI_F32>(p, s);
+      }
+      return launch<VDS_TN, VDS_EPI_F32>(p, s);
+    }
+  }
   // 256 x 128 tiles, two workgroups per CU: no padded half tile when N is a multiple of 128 but not of 256, and the
   // epilogue of one workgroup runs under the main loop of the other.  Model (same units as above): a round of 512
   // such tiles costs what a round of 256 tiles of 256^2 costs, times ~1.0.  VDS_GEMM_TILE=2 forces it.

@@ -158,18 +158,17 @@ def _wgrad_split(tiles: int, kt: int, slots: int) -> int:
     return best
 
 
-def linear_wgrad(dy, x, dW: torch.Tensor, accumulate: bool = False, n_cu: int = 256):
-    """dW[N,K] (f32) = dy^T x   (dy [M,N], x [M,K]); split-K over the tokens adds atomically into
-    dW, which must then be pre-zeroed (the model zeroes its flat gradient buffers once per step);
-    accumulate=True forces the atomic path so several calls sum into dW."""
+def linear_wgrad(dy, x, dW: torch.Tensor, accumulate: bool = False, split_k: Optional[int] = None):
+    """dW[N,K] (f32) = dy^T x   (dy [M,N], x [M,K]).  The library picks tiling and split-K itself (split_k=None):
+    a split over the tokens adds atomically into dW, which must then be pre-zeroed (the model zeroes its flat gradient
+    buffers once per step); accumulate=True forces the atomic path so several calls sum into dW."""
     M, N = dy.shape
     K = x.shape[1]
     assert dW.dtype == f32 and dW.numel() == N * K and dW.is_contiguous()
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    kt = (M + 63) // 64
-    split = _wgrad_split(tiles, kt, 2 * n_cu)
-    if accumulate:
-        split = -split
+    if split_k is None:
+        split = -1 if accumulate else 0
+    else:
+        split = -max(2, split_k) if accumulate else split_k
     gemm(VDS_TN, EPI_F32, N, K, M, dy, dy.stride(0), x, x.stride(0), dW, K, split_k=split)
 
 
