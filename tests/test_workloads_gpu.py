@@ -144,7 +144,7 @@ def test_c2_dit_b_two_blocks_residual_v(vds, parity_log):
 
 # blocks.{i>0}.lambda_param gradient: |got - ref| <= LAMBDA_ERR * sum_j |dv_j (v_raw_j - v_0_j)| -- every one of the
 # B*L*D bf16 products carries ~2^-9 relative error; checked per block (the HIP kernel accumulates them in fp32)
-LAMBDA_ERR = 1e-3
+LAMBDA_ERR = 1e-4  # measured worst 4.1e-5 (gpurun_out/parity_report.jsonl, DiT-XL depth 6)
 
 
 # ---------------------------------------------------------------------------- C3b / C5 ----
@@ -226,7 +226,8 @@ def test_c4_attention_kernels_vs_chunked_oracle(vds, parity_log):
     ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ov, lse, kv_pad_ones=True)
     dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
     delta = torch.zeros(2, B, H, L, dtype=f32, device="cuda")
-    ops.attn_bwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ov, lse, ops.heads_view(do.cuda(), B, L, H, hd),
+    ops.attn_bwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ov, lse,
+                 ops.heads_view(do.reshape(B * L, H * hd).cuda(), B, L, H, hd),
                  dq[..., :hd], dk[..., :hd], dv[..., :hd], delta, kv_pad_ones=True)
     fig = dict(o=rel(o.view(B, L, H, hd).permute(0, 2, 1, 3), o_ref), lse=rel(lse, lse_ref),
                dq=rel(dq[..., :hd], dq_ref), dk=rel(dk[..., :hd], dk_ref), dv=rel(dv[..., :hd], dv_ref))

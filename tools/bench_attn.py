@@ -24,12 +24,17 @@ def timeit(fn, iters=8, warm=3):
 
 B = int(os.environ.get("B", 2))
 tag = f"variant={os.environ.get('VDS_ATTN_VARIANT', 'default')}"
-for hd, H, hdp in ((72, 16, 96), (64, 12, 64), (128, 16, 128)):
+SHAPES = ((72, 16, 96), (64, 12, 64), (128, 16, 128))
+if os.environ.get("ONLY72") == "1":
+    SHAPES = SHAPES[:1]
+for hd, H, hdp in SHAPES:
     Lq = 8208
     g = torch.Generator(device=dev).manual_seed(0)
     q, k, v = (torch.zeros(B, H, Lq, hdp, dtype=bf16, device=dev) for _ in range(3))
+    ZERO = os.environ.get("ZERO") == "1"  # all-zero operands: same cycles, less switching power -> shows the DVFS share
     for t_ in (q, k, v):
-        t_[..., :hd] = torch.randn(B, H, Lq, hd, device=dev, generator=g).to(bf16)
+        if not ZERO:
+            t_[..., :hd] = torch.randn(B, H, Lq, hd, device=dev, generator=g).to(bf16)
     ones = os.environ.get("ONES", "1") == "1" and hdp - hd >= 8
     if ones:  # the pad layout vds_qkv_rope_fwd produces
         k[..., hd] = 1
@@ -43,6 +48,8 @@ for hd, H, hdp in ((72, 16, 96), (64, 12, 64), (128, 16, 128)):
     t = timeit(lambda: ops.attn_fwd(q[..., :hd], k[..., :hd], v[..., :hd], ov, lse, kv_pad_ones=ones))
     print(f"{tag} fwd hd{hd}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TF/s")
     do = torch.randn(B * Lq, H * hd, device=dev, generator=g).to(bf16)
+    if ZERO:
+        do.zero_()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty(2, B, H, Lq, dtype=f32, device=dev)
     dov = ops.heads_view(do, B, Lq, H, hd)

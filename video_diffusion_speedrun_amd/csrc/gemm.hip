@@ -1010,7 +1010,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     static double mid_tn = -1.0;
     if (mid_tn < 0) {
       const char* e = getenv("VDS_GEMM_MID_TN");
-      mid_tn = e ? atof(e) : 0.85;  // relative time per unit of work of the 256 x 128 kernel on TN problems
+      mid_tn = e ? atof(e) : 0.75;  // relative time per unit of work of the 256 x 128 kernel on TN problems
     }
     const long kt = cdiv(a->K, 64);
     double best = 1e300;
@@ -1038,15 +1038,18 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     }
   }
   // 256 x 128 tiles, two workgroups per CU: no padded half tile when N is a multiple of 128 but not of 256, and the
-  // epilogue of one workgroup runs under the main loop of the other.  Model (same units as above): a round of 512
-  // such tiles costs what a round of 256 tiles of 256^2 costs, times ~1.0.  VDS_GEMM_TILE=2 forces it.
+  // epilogue of one workgroup runs under the main loop of the other.  Measured (tools/bench_gemm_tiles.py, DiT-XL
+  // shapes, B = 12): its LDS-DMA issue rate (1.5x the bytes per FLOP of a 256^2 tile, from half as many waves) caps
+  // it at ~0.8x the 256^2 kernel on NT / NN problems, so a round of 512 such tiles is priced at 1.3 rounds of 256^2
+  // tiles and it only wins where tile quantisation is severe; on weight gradients (TN) it beats the 128^2 kernel
+  // by 7-24 % (see auto_split above).  VDS_GEMM_TILE=2 forces it.
   {
     const int tmm = cdiv(a->M, 256), tnm = cdiv(a->N, 128);
     const double rounds_mid = (double)((long)tmm * tnm + 511) / 512;  // not rounded up: the tail round is half-price per tile
     static double mid_factor = -1.0;
     if (mid_factor < 0) {
       const char* e = getenv("VDS_GEMM_MID_FACTOR");
-      mid_factor = e ? atof(e) : 1.0;
+      mid_factor = e ? atof(e) : 1.3;
     }
     const double cost_mid = (double)(((long)tmm * tnm + 511) / 512) * mid_factor;
     const double cost_big = (double)rounds_big, cost_small = (double)rounds_small * (1.24 / 2.0);
