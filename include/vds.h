@@ -140,6 +140,10 @@ typedef struct vds_attn_args {
 
 int vds_attn_fwd(const vds_attn_args* args, vds_stream_t stream);
 int vds_attn_bwd(const vds_attn_args* args, vds_stream_t stream);
+/* Tests / experiments: which of the head_dim-72 (ones-column) kernels run on v_mfma_f32_16x16x32_bf16 instead of
+ * v_mfma_f32_32x32x16_bf16 -- bit 0: dK/dV, bit 1: dQ, bit 2: forward; -1 = back to the default / VDS_ATTN_MFMA16.
+ * Returns the previous mask.  Results agree up to fp32 summation order. */
+int vds_attn_set_variant(int32_t mask);
 /* bytes of the caller-allocated `delta` workspace vds_attn_bwd needs for these B, H, Lq (2*B*H*Lq floats) */
 size_t vds_attn_bwd_workspace_bytes(const vds_attn_args* args);
 

