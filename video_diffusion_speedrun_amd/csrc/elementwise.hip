@@ -3,6 +3,7 @@
 // residual-V (fwd/bwd), the B-row "small" linears (time embed / adaLN), sinusoid,
 // patchify / unpatchify, register tokens, noising, flow-matching loss, casts.
 // Reference call sites are cited per kernel (file:line of the reference repo).
+#include <cstdlib>
 #include "common.h"
 #include "prof.h"
 #include "../../include/vds.h"
@@ -110,22 +111,34 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
       if constexpr (HAS_W) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv[i]);
     }
   }
-  for (int l = l0 + wave; l < l1; l += 4) {
+  // the next row's dy / x (and dres) are requested before the current row is processed: a wave walks its rows
+  // one after the other and would otherwise expose a full HBM round trip per row (the kernel is HBM-bound)
+  u32x4 ndy[NC], nx[NC], nres[NC];
+  auto fetch = [&](int l) {
     const long row = (long)b * L + l;
-    const float r = rstd[row];
-    u32x4 pdy[NC], px[NC];
-    float dot = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
-      if (c < nch) {
-        pdy[i] = *reinterpret_cast<const u32x4*>(dy + row * lddy + c * 8);
-        px[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
+      if (c < nch && l < l1) {
+        ndy[i] = *reinterpret_cast<const u32x4*>(dy + row * lddy + c * 8);
+        nx[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
+        if (dres) nres[i] = *reinterpret_cast<const u32x4*>(dres + row * lddres + c * 8);
       } else {
-        pdy[i] = u32x4{0u, 0u, 0u, 0u};
-        px[i] = u32x4{0u, 0u, 0u, 0u};
+        ndy[i] = u32x4{0u, 0u, 0u, 0u};
+        nx[i] = u32x4{0u, 0u, 0u, 0u};
       }
+      if (!dres || !(c < nch && l < l1)) nres[i] = u32x4{0u, 0u, 0u, 0u};
     }
+  };
+  fetch(l0 + wave);
+  for (int l = l0 + wave; l < l1; l += 4) {
+    const long row = (long)b * L + l;
+    const float r = rstd[row];
+    u32x4 pdy[NC], px[NC], pres[NC];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { pdy[i] = ndy[i]; px[i] = nx[i]; pres[i] = nres[i]; }
+    fetch(l + 4);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       float dyv[8], xv[8];
@@ -152,11 +165,7 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
       const int c = lane + 64 * i;
       if (c < nch) {
         float o[8], dyv[8], xv[8];
-        if (dres) unpack8(*reinterpret_cast<const u32x4*>(dres + row * lddres + c * 8), o);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = 0.f;
-        }
+        unpack8(pres[i], o);  // zeros without a residual gradient
         unpack8(pdy[i], dyv);
         unpack8(px[i], xv);
 #pragma unroll
@@ -217,15 +226,35 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
     for (int e = 0; e < 8; ++e) { a_g[i][e] = 0.f; a_b[i][e] = 0.f; gt[i][e] = 0.f; }
     if (c < nch) load8f(mod + (long)b * ldmod + gate_col + c * 8, gt[i]);
   }
+  u32x4 nd[NC], ny[NC];  // next row, requested one row ahead (see rmsnorm_mod_bwd_kernel)
+  auto fetch = [&](int l) {
+    const long row = (long)b * L + l;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch && l < l1) {
+        nd[i] = *reinterpret_cast<const u32x4*>(dxn + row * lddxn + c * 8);
+        ny[i] = *reinterpret_cast<const u32x4*>(y + row * ldy + c * 8);
+      } else {
+        nd[i] = u32x4{0u, 0u, 0u, 0u};
+        ny[i] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  fetch(l0 + wave);
   for (int l = l0 + wave; l < l1; l += 4) {
     const long row = (long)b * L + l;
+    u32x4 pd[NC], py[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { pd[i] = nd[i]; py[i] = ny[i]; }
+    fetch(l + 4);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         float d[8], yv[8], o[8];
-        unpack8(*reinterpret_cast<const u32x4*>(dxn + row * lddxn + c * 8), d);
-        unpack8(*reinterpret_cast<const u32x4*>(y + row * ldy + c * 8), yv);
+        unpack8(pd[i], d);
+        unpack8(py[i], yv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           a_g[i][e] += d[e] * yv[e];
@@ -467,6 +496,221 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* dq, con
   if (mix) {
     dl = wave_sum(dl);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dl;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dlam, red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+// ---------------------------------- qkv split + RoPE + residual-V, wave-per-token form -------
+// The kernels above move 8 bytes per lane and access (the rotation partner of element d is d + hd/2, and
+// hd/2 = 36 is not a multiple of 8 for head_dim 72); 8-byte global accesses run at 0.54-0.70x the rate of
+// 16-byte ones (MI355X_MICROARCH.md) and these passes were the slowest HBM-bound kernels of the step
+// (3.3-4.1 TB/s).  Here one wave owns one token: every global access is 16 bytes per lane -- the token's
+// [3D] row as 3D/8 consecutive chunks, the head-major rows as (head, chunk) items -- and the rotation
+// partners meet in a wave-private LDS copy of the token's q and k sections (5 KB per wave).  Item = chunk
+// c = h * hd/8 + j of a section; lane l handles items l, l + 64, ... (NI of them, D <= 512 * NI).
+template <int NI>
+__global__ __launch_bounds__(256) void qkv_rope_fwd_tok_kernel(const bf16_t* qkv, const float* cosb,
+                                                               const float* sinb, const bf16_t* v0,
+                                                               const bf16_t* lamp, bf16_t* q, bf16_t* k, bf16_t* v,
+                                                               int B, int L, int H, int hd, int hdp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long tok = (long)blockIdx.x * 4 + wave;
+  if (tok >= (long)B * L) return;
+  const int b = (int)(tok / L), l = (int)(tok % L);
+  const int D = H * hd, nch = D >> 3, cph = hd >> 3, half = hd >> 1;
+  const int wstride = 2 * D * 2 + 2 * half * 4;  // q | k sections (bf16) | cos | sin rows (f32)
+  char* wq = smem + wave * wstride;
+  char* wk = wq + D * 2;
+  float* wc = reinterpret_cast<float*>(wk + D * 2);
+  float* wsn = wc + half;
+  const bf16_t* src = qkv + tok * 3 * D;
+  u32x4 rq[NI], rk[NI], rv[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      rq[i] = *reinterpret_cast<const u32x4*>(src + c * 8);
+      rk[i] = *reinterpret_cast<const u32x4*>(src + D + c * 8);
+      rv[i] = *reinterpret_cast<const u32x4*>(src + 2 * D + c * 8);
+      *reinterpret_cast<u32x4*>(wq + c * 16) = rq[i];
+      *reinterpret_cast<u32x4*>(wk + c * 16) = rk[i];
+    }
+  }
+  if (lane < half / 4) {  // this token's cos / sin rows: half floats each
+    *reinterpret_cast<f32x4*>(wc + 4 * lane) = *reinterpret_cast<const f32x4*>(cosb + (long)l * half + 4 * lane);
+    *reinterpret_cast<f32x4*>(wsn + 4 * lane) = *reinterpret_cast<const f32x4*>(sinb + (long)l * half + 4 * lane);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes
+  __builtin_amdgcn_wave_barrier();
+  float lam = 0.f, oml = 0.f;
+  if (v0) {
+    lam = bf2f(*lamp);
+    oml = bf2f(f2bf(1.0f - lam));
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane + 64 * i;
+    if (c >= nch) continue;
+    const int hh = c / cph, j = c % cph;
+    const long dst = (((long)b * H + hh) * L + l) * hdp + 8 * j;
+    float xq[8], xk[8], yq[8], yk[8];
+    unpack8(rq[i], xq);
+    unpack8(rk[i], xk);
+#pragma unroll
+    for (int g4 = 0; g4 < 2; ++g4) {  // a group of 4 elements lies in one half (hd/2 is a multiple of 4)
+      const int d0 = 8 * j + 4 * g4;
+      const bool first = d0 < half;
+      const int pd = first ? d0 + half : d0 - half, ci = first ? d0 : d0 - half;
+      const u32x2 pq = *reinterpret_cast<const u32x2*>(wq + (hh * hd + pd) * 2);
+      const u32x2 pk = *reinterpret_cast<const u32x2*>(wk + (hh * hd + pd) * 2);
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(wc + ci);
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(wsn + ci);
+      const float pqf[4] = {bflo(pq[0]), bfhi(pq[0]), bflo(pq[1]), bfhi(pq[1])};
+      const float pkf[4] = {bflo(pk[0]), bfhi(pk[0]), bflo(pk[1]), bfhi(pk[1])};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // first half: y1 = x1 c + x2 s ; second half: y2 = x2 c - x1 s  (model.py:266-275)
+        const float sg = first ? s4[e] : -s4[e];
+        yq[4 * g4 + e] = xq[4 * g4 + e] * c4[e] + pqf[e] * sg;
+        yk[4 * g4 + e] = xk[4 * g4 + e] * c4[e] + pkf[e] * sg;
+      }
+    }
+    *reinterpret_cast<u32x4*>(q + dst) = pack8(yq);
+    *reinterpret_cast<u32x4*>(k + dst) = pack8(yk);
+    u32x4 w = rv[i];
+    if (v0) {
+      const u32x4 z = *reinterpret_cast<const u32x4*>(v0 + dst);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // reference (bf16 tensors): lam*v rounds, (1-lam) rounds, (1-lam)*v0 rounds, sum rounds
+        const float a0 = bf2f(f2bf(lam * bflo(w[e]))) + bf2f(f2bf(oml * bflo(z[e])));
+        const float a1 = bf2f(f2bf(lam * bfhi(w[e]))) + bf2f(f2bf(oml * bfhi(z[e])));
+        w[e] = pack_bf2(a0, a1);
+      }
+    }
+    *reinterpret_cast<u32x4*>(v + dst) = w;
+  }
+  // pad columns hd..hdp of every (token, head): zeros, except the ones columns K[hd] = K[hd+1] = V[hd] = V[hd+4] = 1
+  // (see qkv_rope_fwd_kernel); 8-column chunks, one item per (head, pad chunk)
+  const int npc = (hdp - hd) >> 3;
+  const bool ones = (hdp - hd) >= 8;
+  for (int it = lane; it < H * npc; it += 64) {
+    const int hh = it / npc, pc = it % npc;
+    const long pd = (((long)b * H + hh) * L + l) * hdp + hd + 8 * pc;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4 kk = z, vv = z;
+    if (ones && pc == 0) {
+      kk[0] = 0x3f803f80u;                 // columns hd, hd+1
+      vv[0] = 0x3f80u;                     // column hd
+      vv[2] = 0x3f80u;                     // column hd+4
+    }
+    *reinterpret_cast<u32x4*>(q + pd) = z;
+    *reinterpret_cast<u32x4*>(k + pd) = kk;
+    *reinterpret_cast<u32x4*>(v + pd) = vv;
+  }
+}
+
+template <int NI>
+__global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq, const bf16_t* dk, const bf16_t* dv,
+                                                               const float* cosb, const float* sinb,
+                                                               const bf16_t* qkv_raw, const bf16_t* v0,
+                                                               const bf16_t* lamp, float* dv0_acc, float* dlam,
+                                                               bf16_t* dqkv, int mix, int add_dv0, int B, int L,
+                                                               int H, int hd, int hdp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long tok = (long)blockIdx.x * 4 + wave;
+  const bool live = tok < (long)B * L;
+  float dl = 0.f;
+  if (live) {
+    const int b = (int)(tok / L), l = (int)(tok % L);
+    const int D = H * hd, nch = D >> 3, cph = hd >> 3, half = hd >> 1;
+    const int wstride = 2 * D * 2 + 2 * half * 4;
+    char* wq = smem + wave * wstride;
+    char* wk = wq + D * 2;
+    float* wc = reinterpret_cast<float*>(wk + D * 2);
+    float* wsn = wc + half;
+    bf16_t* dst = dqkv + tok * 3 * D;
+    u32x4 rq[NI], rk[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const int hh = c / cph, j = c % cph;
+        const long so = (((long)b * H + hh) * L + l) * hdp + 8 * j;
+        rq[i] = *reinterpret_cast<const u32x4*>(dq + so);
+        rk[i] = *reinterpret_cast<const u32x4*>(dk + so);
+        *reinterpret_cast<u32x4*>(wq + c * 16) = rq[i];
+        *reinterpret_cast<u32x4*>(wk + c * 16) = rk[i];
+      }
+    }
+    if (lane < half / 4) {
+      *reinterpret_cast<f32x4*>(wc + 4 * lane) = *reinterpret_cast<const f32x4*>(cosb + (long)l * half + 4 * lane);
+      *reinterpret_cast<f32x4*>(wsn + 4 * lane) = *reinterpret_cast<const f32x4*>(sinb + (long)l * half + 4 * lane);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const float lam = mix ? bf2f(*lamp) : 0.f, oml = 1.0f - lam;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane + 64 * i;
+      if (c >= nch) continue;
+      const int hh = c / cph, j = c % cph;
+      const long so = (((long)b * H + hh) * L + l) * hdp + 8 * j;
+      float gq[8], gk[8], oq[8], ok_[8];
+      unpack8(rq[i], gq);
+      unpack8(rk[i], gk);
+#pragma unroll
+      for (int g4 = 0; g4 < 2; ++g4) {
+        const int d0 = 8 * j + 4 * g4;
+        const bool first = d0 < half;
+        const int pd = first ? d0 + half : d0 - half, ci = first ? d0 : d0 - half;
+        const u32x2 pq = *reinterpret_cast<const u32x2*>(wq + (hh * hd + pd) * 2);
+        const u32x2 pk = *reinterpret_cast<const u32x2*>(wk + (hh * hd + pd) * 2);
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(wc + ci);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(wsn + ci);
+        const float pqf[4] = {bflo(pq[0]), bfhi(pq[0]), bflo(pq[1]), bfhi(pq[1])};
+        const float pkf[4] = {bflo(pk[0]), bfhi(pk[0]), bflo(pk[1]), bfhi(pk[1])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // transposed rotation: d1 = g1 c - g2 s ; d2 = g1 s + g2 c
+          const float sg = first ? -s4[e] : s4[e];
+          oq[4 * g4 + e] = gq[4 * g4 + e] * c4[e] + pqf[e] * sg;
+          ok_[4 * g4 + e] = gk[4 * g4 + e] * c4[e] + pkf[e] * sg;
+        }
+      }
+      *reinterpret_cast<u32x4*>(dst + c * 8) = pack8(oq);
+      *reinterpret_cast<u32x4*>(dst + D + c * 8) = pack8(ok_);
+      float g[8];
+      unpack8(*reinterpret_cast<const u32x4*>(dv + so), g);
+      if (mix) {
+        float vr[8], vz[8], a[8];
+        unpack8(*reinterpret_cast<const u32x4*>(qkv_raw + tok * 3 * D + 2 * D + c * 8), vr);
+        unpack8(*reinterpret_cast<const u32x4*>(v0 + so), vz);
+        load8f(dv0_acc + so, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dl += g[e] * (vr[e] - vz[e]);
+          a[e] += oml * g[e];
+          g[e] *= lam;
+        }
+        *reinterpret_cast<f32x4*>(dv0_acc + so) = f32x4{a[0], a[1], a[2], a[3]};
+        *reinterpret_cast<f32x4*>(dv0_acc + so + 4) = f32x4{a[4], a[5], a[6], a[7]};
+      } else if (add_dv0) {
+        float a[8];
+        load8f(dv0_acc + so, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += a[e];
+      }
+      *reinterpret_cast<u32x4*>(dst + 2 * D + c * 8) = pack8(g);
+    }
+  }
+  if (mix) {
+    dl = wave_sum(dl);
+    if (lane == 0) red[wave] = dl;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(dlam, red[0] + red[1] + red[2] + red[3]);
   }
@@ -904,6 +1148,17 @@ extern "C" int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M
   return ok();
 }
 
+// the wave-per-token kernels need 16-byte aligned head rows (hdp % 8 == 0), hd/2 a multiple of 4 and D <= 2048;
+// VDS_ROPE_TOK=0 keeps the 8-byte-access kernels (A/B)
+static bool rope_tok_form(int H, int hd, int hdp) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VDS_ROPE_TOK");
+    on = e ? atoi(e) : 1;
+  }
+  return on && (hdp & 7) == 0 && (hd & 7) == 0 && H * hd <= 2048;
+}
+
 extern "C" int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float* sinb, const void* v0,
                                 const void* lam, void* q, void* k, void* v, int32_t B, int32_t L, int32_t H,
                                 int32_t hd, int32_t hdp, vds_stream_t stream) {
@@ -912,6 +1167,19 @@ extern "C" int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float*
   if (((hdp - hd) >> 2) > (hd >> 3)) return VDS_ERR_UNSUPPORTED;
   const long n = (long)B * L * H * (hd >> 3);
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, (hipStream_t)stream, 0.0, (v0 ? 14.0 : 12.0) * B * L * H * hd);
+  if (rope_tok_form(H, hd, hdp)) {  // wave-per-token form: 16-byte global accesses
+    const int D = H * hd, lds = 4 * (4 * D + 4 * hd);
+    const dim3 grid((unsigned)(((long)B * L + 3) / 4));
+#define ROPE_FWD(NI)                                                                                              \
+  hipLaunchKernelGGL(qkv_rope_fwd_tok_kernel<NI>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, \
+                     cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, B, L, H, hd, hdp)
+    if (D <= 512) ROPE_FWD(1);
+    else if (D <= 1024) ROPE_FWD(2);
+    else if (D <= 1536) ROPE_FWD(3);
+    else ROPE_FWD(4);
+#undef ROPE_FWD
+    return ok();
+  }
   hipLaunchKernelGGL(qkv_rope_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (bf16_t*)q, (bf16_t*)k,
                      (bf16_t*)v, B, L, H, hd, hdp);
@@ -927,6 +1195,20 @@ extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, 
   if (add_dv0 && !dv0_acc) return VDS_ERR_ARG;
   const long n = (long)B * L * H * (hd >> 3);
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_BWD, (hipStream_t)stream, 0.0, (mix ? 24.0 : 12.0) * B * L * H * hd);
+  if (rope_tok_form(H, hd, hdp)) {
+    const int D = H * hd, lds = 4 * (4 * D + 4 * hd);
+    const dim3 grid((unsigned)(((long)B * L + 3) / 4));
+#define ROPE_BWD(NI)                                                                                                \
+  hipLaunchKernelGGL(qkv_rope_bwd_tok_kernel<NI>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dq,    \
+                     (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw, (const bf16_t*)v0,  \
+                     (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp)
+    if (D <= 512) ROPE_BWD(1);
+    else if (D <= 1024) ROPE_BWD(2);
+    else if (D <= 1536) ROPE_BWD(3);
+    else ROPE_BWD(4);
+#undef ROPE_BWD
+    return ok();
+  }
   hipLaunchKernelGGL(qkv_rope_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw,
                      (const bf16_t*)v0, (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp);
