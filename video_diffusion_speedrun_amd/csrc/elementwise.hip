@@ -74,6 +74,9 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
   }
 }
 
+// (Measured negative, round 2: requesting the next row's dy / x / dres one row ahead in registers -- 36 more VGPRs --
+// dropped the kernel below its 3 waves per SIMD and tripled its time; occupancy, not an explicit prefetch, is what
+// keeps the loads in flight here.)
 // Backward.  grid = (row-groups, B); each wave walks rows of ONE sample so that the
 // d(shift), d(scale) sums over L stay in registers; one atomicAdd per column per block.
 // dy and x stay PACKED (bf16) between the two passes over a row and the norm-weight terms are
@@ -111,34 +114,22 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
       if constexpr (HAS_W) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv[i]);
     }
   }
-  // the next row's dy / x (and dres) are requested before the current row is processed: a wave walks its rows
-  // one after the other and would otherwise expose a full HBM round trip per row (the kernel is HBM-bound)
-  u32x4 ndy[NC], nx[NC], nres[NC];
-  auto fetch = [&](int l) {
-    const long row = (long)b * L + l;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nch && l < l1) {
-        ndy[i] = *reinterpret_cast<const u32x4*>(dy + row * lddy + c * 8);
-        nx[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
-        if (dres) nres[i] = *reinterpret_cast<const u32x4*>(dres + row * lddres + c * 8);
-      } else {
-        ndy[i] = u32x4{0u, 0u, 0u, 0u};
-        nx[i] = u32x4{0u, 0u, 0u, 0u};
-      }
-      if (!dres || !(c < nch && l < l1)) nres[i] = u32x4{0u, 0u, 0u, 0u};
-    }
-  };
-  fetch(l0 + wave);
   for (int l = l0 + wave; l < l1; l += 4) {
     const long row = (long)b * L + l;
     const float r = rstd[row];
-    u32x4 pdy[NC], px[NC], pres[NC];
+    u32x4 pdy[NC], px[NC];
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < NC; ++i) { pdy[i] = ndy[i]; px[i] = nx[i]; pres[i] = nres[i]; }
-    fetch(l + 4);
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        pdy[i] = *reinterpret_cast<const u32x4*>(dy + row * lddy + c * 8);
+        px[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
+      } else {
+        pdy[i] = u32x4{0u, 0u, 0u, 0u};
+        px[i] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       float dyv[8], xv[8];
@@ -165,7 +156,11 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
       const int c = lane + 64 * i;
       if (c < nch) {
         float o[8], dyv[8], xv[8];
-        unpack8(pres[i], o);  // zeros without a residual gradient
+        if (dres) unpack8(*reinterpret_cast<const u32x4*>(dres + row * lddres + c * 8), o);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        }
         unpack8(pdy[i], dyv);
         unpack8(px[i], xv);
 #pragma unroll
@@ -226,35 +221,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
     for (int e = 0; e < 8; ++e) { a_g[i][e] = 0.f; a_b[i][e] = 0.f; gt[i][e] = 0.f; }
     if (c < nch) load8f(mod + (long)b * ldmod + gate_col + c * 8, gt[i]);
   }
-  u32x4 nd[NC], ny[NC];  // next row, requested one row ahead (see rmsnorm_mod_bwd_kernel)
-  auto fetch = [&](int l) {
-    const long row = (long)b * L + l;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nch && l < l1) {
-        nd[i] = *reinterpret_cast<const u32x4*>(dxn + row * lddxn + c * 8);
-        ny[i] = *reinterpret_cast<const u32x4*>(y + row * ldy + c * 8);
-      } else {
-        nd[i] = u32x4{0u, 0u, 0u, 0u};
-        ny[i] = u32x4{0u, 0u, 0u, 0u};
-      }
-    }
-  };
-  fetch(l0 + wave);
   for (int l = l0 + wave; l < l1; l += 4) {
     const long row = (long)b * L + l;
-    u32x4 pd[NC], py[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) { pd[i] = nd[i]; py[i] = ny[i]; }
-    fetch(l + 4);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         float d[8], yv[8], o[8];
-        unpack8(pd[i], d);
-        unpack8(py[i], yv);
+        unpack8(*reinterpret_cast<const u32x4*>(dxn + row * lddxn + c * 8), d);
+        unpack8(*reinterpret_cast<const u32x4*>(y + row * ldy + c * 8), yv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           a_g[i][e] += d[e] * yv[e];
@@ -501,117 +476,16 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* dq, con
   }
 }
 
-// ---------------------------------- qkv split + RoPE + residual-V, wave-per-token form -------
-// The kernels above move 8 bytes per lane and access (the rotation partner of element d is d + hd/2, and
+// ------------------------------ backward of qkv split + RoPE + residual-V, wave-per-token form -------
+// The kernel above moves 8 bytes per lane and access (the rotation partner of element d is d + hd/2, and
 // hd/2 = 36 is not a multiple of 8 for head_dim 72); 8-byte global accesses run at 0.54-0.70x the rate of
-// 16-byte ones (MI355X_MICROARCH.md) and these passes were the slowest HBM-bound kernels of the step
-// (3.3-4.1 TB/s).  Here one wave owns one token: every global access is 16 bytes per lane -- the token's
-// [3D] row as 3D/8 consecutive chunks, the head-major rows as (head, chunk) items -- and the rotation
-// partners meet in a wave-private LDS copy of the token's q and k sections (5 KB per wave).  Item = chunk
-// c = h * hd/8 + j of a section; lane l handles items l, l + 64, ... (NI of them, D <= 512 * NI).
-template <int NI>
-__global__ __launch_bounds__(256) void qkv_rope_fwd_tok_kernel(const bf16_t* qkv, const float* cosb,
-                                                               const float* sinb, const bf16_t* v0,
-                                                               const bf16_t* lamp, bf16_t* q, bf16_t* k, bf16_t* v,
-                                                               int B, int L, int H, int hd, int hdp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long tok = (long)blockIdx.x * 4 + wave;
-  if (tok >= (long)B * L) return;
-  const int b = (int)(tok / L), l = (int)(tok % L);
-  const int D = H * hd, nch = D >> 3, cph = hd >> 3, half = hd >> 1;
-  const int wstride = 2 * D * 2 + 2 * half * 4;  // q | k sections (bf16) | cos | sin rows (f32)
-  char* wq = smem + wave * wstride;
-  char* wk = wq + D * 2;
-  float* wc = reinterpret_cast<float*>(wk + D * 2);
-  float* wsn = wc + half;
-  const bf16_t* src = qkv + tok * 3 * D;
-  u32x4 rq[NI], rk[NI], rv[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nch) {
-      rq[i] = *reinterpret_cast<const u32x4*>(src + c * 8);
-      rk[i] = *reinterpret_cast<const u32x4*>(src + D + c * 8);
-      rv[i] = *reinterpret_cast<const u32x4*>(src + 2 * D + c * 8);
-      *reinterpret_cast<u32x4*>(wq + c * 16) = rq[i];
-      *reinterpret_cast<u32x4*>(wk + c * 16) = rk[i];
-    }
-  }
-  if (lane < half / 4) {  // this token's cos / sin rows: half floats each
-    *reinterpret_cast<f32x4*>(wc + 4 * lane) = *reinterpret_cast<const f32x4*>(cosb + (long)l * half + 4 * lane);
-    *reinterpret_cast<f32x4*>(wsn + 4 * lane) = *reinterpret_cast<const f32x4*>(sinb + (long)l * half + 4 * lane);
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes
-  __builtin_amdgcn_wave_barrier();
-  float lam = 0.f, oml = 0.f;
-  if (v0) {
-    lam = bf2f(*lamp);
-    oml = bf2f(f2bf(1.0f - lam));
-  }
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int c = lane + 64 * i;
-    if (c >= nch) continue;
-    const int hh = c / cph, j = c % cph;
-    const long dst = (((long)b * H + hh) * L + l) * hdp + 8 * j;
-    float xq[8], xk[8], yq[8], yk[8];
-    unpack8(rq[i], xq);
-    unpack8(rk[i], xk);
-#pragma unroll
-    for (int g4 = 0; g4 < 2; ++g4) {  // a group of 4 elements lies in one half (hd/2 is a multiple of 4)
-      const int d0 = 8 * j + 4 * g4;
-      const bool first = d0 < half;
-      const int pd = first ? d0 + half : d0 - half, ci = first ? d0 : d0 - half;
-      const u32x2 pq = *reinterpret_cast<const u32x2*>(wq + (hh * hd + pd) * 2);
-      const u32x2 pk = *reinterpret_cast<const u32x2*>(wk + (hh * hd + pd) * 2);
-      const f32x4 c4 = *reinterpret_cast<const f32x4*>(wc + ci);
-      const f32x4 s4 = *reinterpret_cast<const f32x4*>(wsn + ci);
-      const float pqf[4] = {bflo(pq[0]), bfhi(pq[0]), bflo(pq[1]), bfhi(pq[1])};
-      const float pkf[4] = {bflo(pk[0]), bfhi(pk[0]), bflo(pk[1]), bfhi(pk[1])};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // first half: y1 = x1 c + x2 s ; second half: y2 = x2 c - x1 s  (model.py:266-275)
-        const float sg = first ? s4[e] : -s4[e];
-        yq[4 * g4 + e] = xq[4 * g4 + e] * c4[e] + pqf[e] * sg;
-        yk[4 * g4 + e] = xk[4 * g4 + e] * c4[e] + pkf[e] * sg;
-      }
-    }
-    *reinterpret_cast<u32x4*>(q + dst) = pack8(yq);
-    *reinterpret_cast<u32x4*>(k + dst) = pack8(yk);
-    u32x4 w = rv[i];
-    if (v0) {
-      const u32x4 z = *reinterpret_cast<const u32x4*>(v0 + dst);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // reference (bf16 tensors): lam*v rounds, (1-lam) rounds, (1-lam)*v0 rounds, sum rounds
-        const float a0 = bf2f(f2bf(lam * bflo(w[e]))) + bf2f(f2bf(oml * bflo(z[e])));
-        const float a1 = bf2f(f2bf(lam * bfhi(w[e]))) + bf2f(f2bf(oml * bfhi(z[e])));
-        w[e] = pack_bf2(a0, a1);
-      }
-    }
-    *reinterpret_cast<u32x4*>(v + dst) = w;
-  }
-  // pad columns hd..hdp of every (token, head): zeros, except the ones columns K[hd] = K[hd+1] = V[hd] = V[hd+4] = 1
-  // (see qkv_rope_fwd_kernel); 8-column chunks, one item per (head, pad chunk)
-  const int npc = (hdp - hd) >> 3;
-  const bool ones = (hdp - hd) >= 8;
-  for (int it = lane; it < H * npc; it += 64) {
-    const int hh = it / npc, pc = it % npc;
-    const long pd = (((long)b * H + hh) * L + l) * hdp + hd + 8 * pc;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    u32x4 kk = z, vv = z;
-    if (ones && pc == 0) {
-      kk[0] = 0x3f803f80u;                 // columns hd, hd+1
-      vv[0] = 0x3f80u;                     // column hd
-      vv[2] = 0x3f80u;                     // column hd+4
-    }
-    *reinterpret_cast<u32x4*>(q + pd) = z;
-    *reinterpret_cast<u32x4*>(k + pd) = kk;
-    *reinterpret_cast<u32x4*>(v + pd) = vv;
-  }
-}
-
+// 16-byte ones (MI355X_MICROARCH.md).  Here one wave owns one token: every global access is 16 bytes per lane --
+// the token's [3D] output row as 3D/8 consecutive chunks, the head-major gradient rows as (head, chunk) items --
+// and the rotation partners meet in a wave-private LDS copy of the token's dq and dk rows (5 KB per wave).
+// Item = chunk c = h * hd/8 + j of a section; lane l handles items l, l + 64, ... (NI of them, D <= 512 * NI).
+// Measured on the DiT-XL step (B = 12, same box): 18.8 ms per step against 22.2 ms.  The same restructuring of
+// the FORWARD kernel was slower (14.3 against 13.4 ms: its scattered 144-byte head-row stores gain nothing from
+// 16-byte lanes and it pays the LDS exchange) and is not in the tree.
 template <int NI>
 __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq, const bf16_t* dk, const bf16_t* dv,
                                                                const float* cosb, const float* sinb,
@@ -1149,7 +1023,7 @@ extern "C" int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M
 }
 
 // the wave-per-token kernels need 16-byte aligned head rows (hdp % 8 == 0), hd/2 a multiple of 4 and D <= 2048;
-// VDS_ROPE_TOK=0 keeps the 8-byte-access kernels (A/B)
+// VDS_ROPE_TOK=0 keeps the 8-byte-access backward kernel (A/B)
 static bool rope_tok_form(int H, int hd, int hdp) {
   static int on = -1;
   if (on < 0) {
@@ -1167,19 +1041,6 @@ extern "C" int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float*
   if (((hdp - hd) >> 2) > (hd >> 3)) return VDS_ERR_UNSUPPORTED;
   const long n = (long)B * L * H * (hd >> 3);
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, (hipStream_t)stream, 0.0, (v0 ? 14.0 : 12.0) * B * L * H * hd);
-  if (rope_tok_form(H, hd, hdp)) {  // wave-per-token form: 16-byte global accesses
-    const int D = H * hd, lds = 4 * (4 * D + 4 * hd);
-    const dim3 grid((unsigned)(((long)B * L + 3) / 4));
-#define ROPE_FWD(NI)                                                                                              \
-  hipLaunchKernelGGL(qkv_rope_fwd_tok_kernel<NI>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, \
-                     cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, B, L, H, hd, hdp)
-    if (D <= 512) ROPE_FWD(1);
-    else if (D <= 1024) ROPE_FWD(2);
-    else if (D <= 1536) ROPE_FWD(3);
-    else ROPE_FWD(4);
-#undef ROPE_FWD
-    return ok();
-  }
   hipLaunchKernelGGL(qkv_rope_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (bf16_t*)q, (bf16_t*)k,
                      (bf16_t*)v, B, L, H, hd, hdp);
