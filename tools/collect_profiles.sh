@@ -1,0 +1,30 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence behind DESIGN.md / bench.py's roofline object.  Run on the GPU box from the repo root:
+#     bash tools/collect_profiles.sh r02        (writes gpurun_out/prof_r02/..., summaries are then copied into profiles/)
+# Counter passes are separate runs (--pmc with --kernel-trace only), as MI355X_MICROARCH.md prescribes.
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+PY=python3
+# 1. per-kernel time of the bench command itself
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o c3b --output-format csv -- $PY bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+# 2. HBM-side bytes of the attention kernels at the bench shape (B = 12): FETCH_SIZE and WRITE_SIZE cannot share a pass
+for c in FETCH_SIZE WRITE_SIZE; do
+  B=12 REPS=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o x --output-format csv -- $PY tools/prof_attn.py > "$OUT/pmc_$c.log" 2>&1
+done
+# 3. SQ counters of the attention kernels (B = 6) and of the GEMMs (B = 12), 4 counters per pass
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"; do
+  i=$((i + 1))
+  B=6 REPS=2 rocprofv3 --kernel-trace --pmc $set -d "$OUT/sq_attn_$i" -o x --output-format csv -- $PY tools/prof_attn.py > "$OUT/sq_attn_$i.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d "$OUT/sq_gemm_$i" -o x --output-format csv -- $PY tools/prof_gemm.py > "$OUT/sq_gemm_$i.log" 2>&1
+done
+$PY tools/pmc_summary.py $(find "$OUT" -path "*pmc_*" -name "*counter_collection.csv") > "$OUT/attn_hbm_traffic_pmc.txt" 2>&1
+$PY tools/pmc_summary.py $(find "$OUT" -path "*sq_attn_*" -name "*counter_collection.csv") > "$OUT/attn_sq_counters.txt" 2>&1
+$PY tools/pmc_summary.py $(find "$OUT" -path "*sq_gemm_*" -name "*counter_collection.csv") > "$OUT/gemm_sq_counters.txt" 2>&1
+find "$OUT" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c3b_kernel_stats.csv"
+tail -c 600 "$OUT/bench_under_rocprof.log"; echo; cat "$OUT/attn_hbm_traffic_pmc.txt" | head -20
