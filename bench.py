@@ -324,17 +324,21 @@ def main():
             else:
                 ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
                 peak, unit = PEAK_HBM_GBS, "GB/s"
-            traffic = None  # HBM bytes per launch: from the committed PMC pass of this kernel / workload, if any
+            # HBM bytes per launch: PMC counters cannot be read from inside this process (rocprofv3 wraps the command in
+            # separate --pmc passes), so the figure is the committed pass of this kernel at this workload and batch,
+            # stamped with the commit and kernel symbol it was taken on; null when there is none
+            traffic, traffic_src = None, None
             try:
-                tj = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
+                tj = json.load(open(os.path.join(REPO, "profiles", "r02_traffic.json")))
                 if tj["workload"] == args.workload and tj["per_gpu_batch"] == B and dominant in tj["kernels"]:
                     k = tj["kernels"][dominant]
                     traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
+                    traffic_src = f"profiles/r02_traffic.json: rocprofv3 PMC pass of {k['symbol']} at commit {tj['commit']}"
             except (OSError, KeyError, ValueError):
                 pass
             out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": ach, "peak": peak, "unit": unit,
-                               "frac": ach / peak, "traffic": traffic, "kernel": dominant,
-                               "launches": dom["launches"], "avg_ms": dom["ms"] / dom["launches"]}
+                               "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                               "kernel": dominant, "launches": dom["launches"], "avg_ms": dom["ms"] / dom["launches"]}
         if breakdown:
             tot = sum(v["ms"] for v in breakdown.values())
             out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in
