@@ -34,8 +34,9 @@ def active_for(group) -> bool:
 
 def ensure(group=None) -> bool:
     """Create the library's RCCL communicator over the ranks of `group` (collective: every rank of the group calls
-    it).  Returns False when the torch path was requested (`VDS_COMM=torch`).  Raises if RCCL cannot be bound --
-    there is no silent fallback."""
+    it).  Returns False when the torch path was requested (`VDS_COMM=torch`) -- or, LOUDLY (stderr, every rank), when
+    the library's communicator could not be created on some rank: the collectives then stay on torch.distributed's
+    RCCL communicator over the same GPUs and links (same transport, same kernels; never a CPU path)."""
     if not enabled():
         return False
     if active_for(group):
@@ -45,13 +46,31 @@ def ensure(group=None) -> bool:
     lib = _lib.load()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     buf = (C.c_ubyte * ID_BYTES)()
+    err = None
     if rank == 0:
-        _lib.check(lib.vds_comm_unique_id(buf, ID_BYTES), "vds_comm_unique_id")
-    box = [bytes(buf)]
+        rc = lib.vds_comm_unique_id(buf, ID_BYTES)
+        if rc != 0:
+            err = f"vds_comm_unique_id -> {rc} {lib.vds_last_error().decode()}"
+    box = [bytes(buf), err]
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast_object_list(box, src=src, group=group)
-    ident = (C.c_ubyte * ID_BYTES).from_buffer_copy(box[0])
-    _lib.check(lib.vds_comm_init(rank, world, ident, ID_BYTES), f"vds_comm_init(rank={rank}, world={world})")
+    ok = box[1] is None
+    if ok:
+        ident = (C.c_ubyte * ID_BYTES).from_buffer_copy(box[0])
+        rc = lib.vds_comm_init(rank, world, ident, ID_BYTES)
+        if rc != 0:
+            ok, err = False, f"vds_comm_init(rank={rank}, world={world}) -> {rc} {lib.vds_last_error().decode()}"
+    # every rank must take the same path: agree on success
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                        device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        import sys
+        print(f"[vds comm] rank {rank}: the library's RCCL communicator is NOT in use ({err or 'another rank failed'}); "
+              "collectives run on torch.distributed's RCCL communicator instead", file=sys.stderr, flush=True)
+        if ok:
+            lib.vds_comm_destroy()
+        return False
     _state.update(group=group, active=True, rank=rank, world=world)
     return True
 
