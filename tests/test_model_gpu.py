@@ -5,7 +5,8 @@ Tolerances (bf16 compute, fp32 accumulation; the reference's own bf16 run differ
 run by `e_ref` = a few 1e-3..1e-2 at these sizes):
     outputs  : rel L2 error vs the fp32 reference <= max(2.5 * e_ref, 1.5e-2)
     loss     : relative error <= 1e-2
-    grads    : cosine >= 0.99 and rel L2 error <= 6e-2 per parameter tensor
+    grads    : cosine >= GRAD_COS and rel L2 error <= GRAD_REL per parameter tensor -- about 2x the worst values
+               measured on the MI355X (recorded per run in gpurun_out/parity_report.jsonl by `_worst_grad_report`)
 """
 import os
 
@@ -16,6 +17,21 @@ from oracle import dit_oracle as O
 
 pytestmark = pytest.mark.gpu
 bf16, f32 = torch.bfloat16, torch.float32
+GRAD_COS, GRAD_REL = 0.999, 3e-2
+_WORST = {"cos": (1.0, None), "rel": (0.0, None)}
+
+
+def _track(name, c, e):
+    if c < _WORST["cos"][0]:
+        _WORST["cos"] = (c, name)
+    if e > _WORST["rel"][0]:
+        _WORST["rel"] = (e, name)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _worst_grad_report(parity_log):
+    yield
+    parity_log("test_model_gpu.worst_gradient", worst_cos=_WORST["cos"], worst_rel=_WORST["rel"])
 
 
 @pytest.fixture(scope="module")
@@ -77,7 +93,8 @@ def check_grad(name, got, ref, report):
         g, r = got, ref
     c, e = cosine(g, r), rel(g, r)
     report.append((name, c, e))
-    return c >= 0.99 and e <= 6e-2
+    _track(name, c, e)
+    return c >= GRAD_COS and e <= GRAD_REL
 
 
 @pytest.mark.parametrize("name", ["g1_tiny_hd64.pt", "g1_tiny_hd72.pt"])
@@ -187,7 +204,8 @@ def test_oracle_parity_random(vds, hd, H, train_bias):
         if Pg[k].grad is None or k.endswith("lambda_param"):
             continue
         c, e = cosine(p.grad, Pg[k].grad), rel(p.grad, Pg[k].grad)
-        if not (c >= 0.99 and e <= 6e-2):
+        _track(k, c, e)
+        if not (c >= GRAD_COS and e <= GRAD_REL):
             bad.append((k, c, e))
     assert not bad, bad
     check_lambda_vector(dict(m.named_parameters()), {k: v.grad for k, v in Pg.items() if v.grad is not None})
@@ -445,7 +463,8 @@ def test_oracle_parity_long_sequence_hd72(vds):
         if Pg[k].grad is None or k.endswith("lambda_param"):
             continue
         c, e = cosine(p.grad, Pg[k].grad), rel(p.grad, Pg[k].grad)
-        if not (c >= 0.99 and e <= 6e-2):
+        _track(k, c, e)
+        if not (c >= GRAD_COS and e <= GRAD_REL):
             bad.append((k, c, e))
     assert not bad, bad
     groups, _ = m.get_mup_setup(3e-3, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
@@ -804,4 +823,4 @@ def test_per_gpu_batch_above_16(vds):
     loss.backward()
     for k, p in m.named_parameters():
         if Pg[k].grad is not None and not k.endswith("lambda_param") and float(Pg[k].grad.abs().max()) > 0:
-            assert cosine(p.grad, Pg[k].grad) >= 0.99 and rel(p.grad, Pg[k].grad) <= 6e-2, k
+            assert cosine(p.grad, Pg[k].grad) >= GRAD_COS and rel(p.grad, Pg[k].grad) <= GRAD_REL, k
