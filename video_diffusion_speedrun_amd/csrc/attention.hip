@@ -1108,6 +1108,171 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
   }
 }
 
+// ===================================== forward on v_mfma_f32_16x16x32_bf16 ====================
+// attn_fwd_wide_kernel<96, 80, true> (head_dim 72, ones columns, 64 queries per wave) on the 16x16x32 shape, for the
+// reason given at attn_bwd_dkv16_kernel (higher held clock at equal MFMA cycles).  S^T = K Q'^T with 16 key rows from
+// LDS as A and 16 queries in registers as B (k in 3 steps of 32); O^T += V^T P^T with V^T read by two transposing
+// 4 x 16 reads and the two stacked S accumulators of a 32-key sub-block used in place as B.  A wave owns 4 query
+// blocks of 16; lane (c = l & 15, g = l >> 4) holds key rows 4g..4g+3 of each 16-key block of query c.  The ones-column
+// softmax is unchanged: -m rides in column head_dim of Q', the denominator comes out of the PV MFMA as rows head_dim
+// (lanes g = 2) and head_dim + 4 (g = 3) of O^T, the running maximum is raised lazily (wave-uniform branch).
+__device__ __forceinline__ float max_over_lane_groups(float x) {  // max over the 4 lanes l & 15 + 16 g
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+template <int HDP>
+__global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
+  static_assert(HDP == 96, "head_dim 72 layout (ones columns at 72, 73 / 72, 76)");
+  constexpr int KS = HDP / 32, NDB = 5, TILE = 64 * HDP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qrow0 = qt * 256 + wave * 64 + (lane & 15);  // query of block 0; block cb = + 16 cb
+  const int hd_kv = p.hd + 8;
+
+  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const srd_t rk = slice_srd(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, hd_kv);
+  const srd_t rv = slice_srd(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, hd_kv);
+  DmaStage<64, HDP, 1> dk, dv;
+  dk.init(p.k_sl, hd_kv, wave, lane);
+  dv.init(p.v_sl, hd_kv, wave, lane);
+  const unsigned k_step = (unsigned)(64 * p.k_sl * 2), v_step = (unsigned)(64 * p.v_sl * 2);
+  dk.issue(rk, smem, 0, wave);
+  dv.issue(rv, smem + TILE, 0, wave);
+
+  const float c = p.scale * LOG2E;
+  bf16x8 qf[4][KS];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int e = ks * 32 + 8 * g;
+      unsigned off = (unsigned)(((long)(qrow0 + 16 * cb) * p.q_sl + e) * 2);
+      if (e >= p.hd) off = 0xfffffff0u;
+      qf[cb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+    }
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[cb][ks] = scale_frag(qf[cb][ks], c);  // also retires the loads
+
+  f32x4 o[NDB][4];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) o[db][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nkt = (p.Lk + 63) / 64;
+  VDS_WAIT_VM(0);
+  __syncthreads();
+
+  auto kv_tile = [&](int j, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    if (j + 1 < nkt) {
+      char* nk = smem + (par ^ 1) * 2 * TILE;
+      dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
+      dv.issue(rv, nk + TILE, (unsigned)(j + 1) * v_step, wave);
+    }
+    const char* kt = smem + par * 2 * TILE;
+    const char* vt = kt + TILE;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 s[2][4];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      PRIO_HI();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const bf16x8 ak = frag16_row<HDP>(kt, kb * 32 + rb * 16, ks, lane);
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) s[rb][cb] = mfma16(ak, qf[cb][ks], s[rb][cb]);
+        }
+      PRIO_LO();
+      // keys past Lk need no mask: their zero-filled V rows (ones columns included) add nothing to the numerators or
+      // to the denominator, whatever exp2 makes of their scores
+      const bool first = (j == 0) && (kb == 0);
+      float mx[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        mx[cb] = fmaxf(fmaxf(fmaxf(s[0][cb][0], s[0][cb][1]), fmaxf(s[0][cb][2], s[0][cb][3])),
+                       fmaxf(fmaxf(s[1][cb][0], s[1][cb][1]), fmaxf(s[1][cb][2], s[1][cb][3])));
+      }
+      const float mxa = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+      if (first || __builtin_amdgcn_ballot_w64(mxa > LAZY_THR) != 0) {  // wave-uniform, rare after the first tile
+        asm volatile("; rescale" ::: "memory");  // keeps this a real branch (no if-conversion of the O multiplies)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          const float mxf = max_over_lane_groups(mx[cb]);  // all four lanes of a query agree
+          const float m_new = bf2f(f2bf(m[cb] + (first ? mxf : fmaxf(mxf, 0.f))));
+          const float delta = m_new - m[cb];
+          const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+          m[cb] = m_new;
+#pragma unroll
+          for (int db = 0; db < NDB; ++db) o[db][cb] *= alpha;  // includes the denominator rows
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[rb][cb][r] -= delta;
+          if (g == 1) qf[cb][KS - 1][0] = (__bf16)(-m_new);  // column head_dim of Q' (exact: m is a bf16 value)
+        }
+      }
+      bf16x8 pf[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[rb][cb][r] = __builtin_amdgcn_exp2f(s[rb][cb][r]);
+        pf[cb] = pack2(s[0][cb], s[1][cb]);
+      }
+      PRIO_HI();
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const bf16x8 av = frag16_tr<HDP>(vt, kb * 32, db * 16, lane);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) o[db][cb] = mfma16(av, pf[cb], o[db][cb]);
+      }
+      PRIO_LO();
+    }
+    VDS_WAIT_VM(0);
+    __syncthreads();
+  };
+  for (int j = 0; j < nkt; j += 2) {
+    kv_tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
+  }
+
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int qrow = qrow0 + 16 * cb;
+    // the denominator is row head_dim (= 64 + 4*2 + 0: lanes g = 2, register 0 of block 4) of O^T
+    const float lt = __shfl(o[NDB - 1][cb][0], (lane & 15) | 32, 64);
+    if (qrow < p.Lq) {
+      const float inv = 1.0f / lt;
+      bf16_t* orow = p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const int d = db * 16 + 4 * g;
+        if (d < p.hd) {
+          const u32x2 w = {pack_bf2(o[db][cb][0] * inv, o[db][cb][1] * inv), pack_bf2(o[db][cb][2] * inv, o[db][cb][3] * inv)};
+          *reinterpret_cast<u32x2*>(orow + d) = w;
+        }
+      }
+      if (g == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m[cb] + __builtin_amdgcn_logf(lt)) * LN2;
+    }
+  }
+}
+
 AttnP to_p(const vds_attn_args* a) {
   AttnP p;
   p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.hd = a->head_dim;
@@ -1163,6 +1328,7 @@ int run_fwd(AttnP p, hipStream_t s) {
     set_lds(attn_fwd_kernel<HDP, HDQ, 2, true>, LDS);
     if constexpr (HDP <= 96) set_lds(attn_fwd_wide_kernel<HDP, HDQ, false>, LDS);
     if constexpr (HDP == 96) set_lds(attn_fwd_wide_kernel<HDP, HDQ, true>, LDS);
+    if constexpr (HDP == 96) set_lds(attn_fwd16_kernel<HDP>, LDS);
     once = true;
   }
   static int wide = -1;  // VDS_ATTN_FWD_WIDE=0/1 forces (experiments); default: head_dim 64 / 72, long query sequences
@@ -1187,7 +1353,9 @@ int run_fwd(AttnP p, hipStream_t s) {
   }
   if constexpr (HDP == 96) {
     if (use_wide) {
-      if (p.kv_pad_ones && p.hd == 72)
+      if (p.kv_pad_ones && p.hd == 72 && (attn_variant() & 4))
+        hipLaunchKernelGGL((attn_fwd16_kernel<HDP>), dim3(grid), dim3(256), LDS, s, p);
+      else if (p.kv_pad_ones && p.hd == 72)
         hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS, s, p);
       else
         hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS, s, p);
