@@ -1273,6 +1273,143 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
   }
 }
 
+// ===================================== dQ on v_mfma_f32_16x16x32_bf16 =========================
+// attn_bwd_dq_kernel<96, 80, true> on the 16x16x32 shape (see attn_bwd_dkv16_kernel).  S'^T = K Q'^T and
+// dP^T = V dO'^T with 16 key rows from LDS as A and 16 queries in registers as B; dQ^T += K^T dS^T with K^T read by
+// transposing reads and the stacked dS^T accumulators used in place as B.  Per 32 x 32 block: 34 MFMAs of 16 cycles
+// (544) against 16 of 32 (512) -- the contraction pads 72 -> 96 instead of 80 -- in exchange for the higher clock.
+template <int HDP>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
+  static_assert(HDP == 96, "head_dim 72 layout");
+  constexpr int KS = HDP / 32, NDB = 5, TILE = 64 * HDP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qrow0 = qt * 128 + wave * 32 + (lane & 15);  // query of column block 0; block 1 = + 16
+  const int hd_kv = p.hd + 8;
+
+  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
+  const __amdgpu_buffer_rsrc_t rdo = slice_rsrc(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
+  const srd_t rk = slice_srd(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, hd_kv);
+  const srd_t rv = slice_srd(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, hd_kv);
+  DmaStage<64, HDP, 1> dk, dv;
+  dk.init(p.k_sl, hd_kv, wave, lane);
+  dv.init(p.v_sl, hd_kv, wave, lane);
+  const unsigned k_step = (unsigned)(64 * p.k_sl * 2), v_step = (unsigned)(64 * p.v_sl * 2);
+  dk.issue(rk, smem, 0, wave);
+  dv.issue(rv, smem + TILE, 0, wave);
+
+  const long nrows = (long)p.B * p.H * p.Lq;
+  const float c = p.scale * LOG2E;
+  bf16x8 qf[2][KS], dof[2][KS];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int qrow = qrow0 + 16 * cb;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int e = ks * 32 + 8 * g;
+      unsigned off = (unsigned)(((long)qrow * p.q_sl + e) * 2);
+      unsigned off2 = (unsigned)(((long)qrow * p.do_sl + e) * 2);
+      if (e >= p.hd) { off = 0xfffffff0u; off2 = 0xfffffff0u; }
+      qf[cb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+      dof[cb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdo, off2, 0, 0));
+    }
+    const long srow = ((long)b * p.H + hh) * p.Lq + min(qrow, p.Lq - 1);
+    const float ndl = p.delta[srow];           // -delta of this lane's query
+    const float lse2 = p.delta[nrows + srow];  // lse * log2(e)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { qf[cb][ks] = scale_frag(qf[cb][ks], c); retire(dof[cb][ks]); }
+    if (g == 1) {  // ks = 2, g = 1: columns 72 .. 79 (K holds 1.0 at 72, 73; V at 72, 76)
+      __bf16 hi, lo;
+      split_bf16(-lse2, hi, lo);
+      qf[cb][KS - 1][0] = hi;
+      qf[cb][KS - 1][1] = lo;
+      split_bf16(ndl, hi, lo);
+      dof[cb][KS - 1][0] = hi;
+      dof[cb][KS - 1][4] = lo;
+    }
+  }
+
+  f32x4 dq[NDB][2];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) dq[db][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nkt = (p.Lk + 63) / 64;
+  VDS_WAIT_VM(0);
+  __syncthreads();  // tile 0 landed
+
+  auto kv_tile = [&](int j, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    if (j + 1 < nkt) {
+      char* nk = smem + (par ^ 1) * 2 * TILE;
+      dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
+      dv.issue(rv, nk + TILE, (unsigned)(j + 1) * v_step, wave);
+    }
+    const char* kt = smem + par * 2 * TILE;
+    const char* vt = kt + TILE;
+    // keys past Lk need no mask: their K rows are zero-filled, so whatever dS they get multiplies a zero row of K
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 s[2][2], dp[2][2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) { s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const bf16x8 ak = frag16_row<HDP>(kt, kb * 32 + rb * 16, ks, lane);
+          const bf16x8 av = frag16_row<HDP>(vt, kb * 32 + rb * 16, ks, lane);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            s[rb][cb] = mfma16(ak, qf[cb][ks], s[rb][cb]);
+            dp[rb][cb] = mfma16(av, dof[cb][ks], dp[rb][cb]);
+          }
+        }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[rb][cb][r] = __builtin_amdgcn_exp2f(s[rb][cb][r]) * dp[rb][cb][r];  // dS^T (unscaled)
+      bf16x8 df[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) df[cb] = pack2(s[0][cb], s[1][cb]);
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const bf16x8 akt = frag16_tr<HDP>(kt, kb * 32, db * 16, lane);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) dq[db][cb] = mfma16(akt, df[cb], dq[db][cb]);
+      }
+    }
+    VDS_WAIT_VM(0);
+    __syncthreads();
+  };
+  for (int j = 0; j < nkt; j += 2) {
+    kv_tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int qrow = qrow0 + 16 * cb;
+    if (qrow >= p.Lq) continue;
+    bf16_t* dqp = p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      const int d = db * 16 + 4 * g;
+      if (d >= p.hd) continue;
+      const u32x2 w = {pack_bf2(dq[db][cb][0] * p.scale, dq[db][cb][1] * p.scale),
+                       pack_bf2(dq[db][cb][2] * p.scale, dq[db][cb][3] * p.scale)};
+      *reinterpret_cast<u32x2*>(dqp + d) = w;
+    }
+  }
+}
+
 AttnP to_p(const vds_attn_args* a) {
   AttnP p;
   p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.hd = a->head_dim;
@@ -1377,6 +1514,7 @@ int run_bwd(AttnP p, hipStream_t s) {
     set_lds(attn_bwd_dkv_kernel<HDP, HDQ, false>, LDS_DKV);
     if constexpr (HDP == 96) set_lds(attn_bwd_dkv_kernel<HDP, HDQ, true>, LDS_DKV);
     if constexpr (HDP == 96) set_lds(attn_bwd_dkv16_kernel<HDP>, LDS_DKV);
+    if constexpr (HDP == 96) set_lds(attn_bwd_dq16_kernel<HDP>, LDS_DQ);
     once = true;
   }
   const long rows = (long)p.B * p.H * p.Lq;
@@ -1417,7 +1555,10 @@ int run_bwd(AttnP p, hipStream_t s) {
     if constexpr (HDP == 96) ones = p.kv_pad_ones && p.hd == 72;
     vdsprof::Scope ps(ones ? VDS_PROF_ATTN_BWD_DQ : VDS_PROF_ATTN_BWD_DQ_PLAIN, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
     if constexpr (HDP == 96) {
-      if (ones) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DQ, s, p);
+      if (ones && (attn_variant() & 2))
+        hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP>), dim3(grid), dim3(256), LDS_DQ, s, p);
+      else if (ones)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DQ, s, p);
     }
     if (!ones) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS_DQ, s, p);
   }
