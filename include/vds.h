@@ -170,6 +170,10 @@ int vds_gate_bwd(const void* dxn, int64_t lddxn, const void* y, int64_t ldy, con
 
 /* column sums: out[n] (f32, atomically +=) += sum_m x[m,n]  (bias gradients). */
 int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M, int32_t N, vds_stream_t stream);
+/* the same over the token rows only of a [B * rows_per_sample] buffer: rows r with r % rows_per_sample < row_offset
+ * (the register rows) are skipped; rows_per_sample = 0: every row */
+int vds_colsum_bf16_rows(const void* x, int64_t ldx, float* out, int32_t M, int32_t N, int32_t rows_per_sample,
+                         int32_t row_offset, vds_stream_t stream);
 
 /* ----------------------------------------------------- qkv split / RoPE / residual-V --
  * forward of model.py:126-134: qkv [B,L,3D] token-major (k h d) ->
@@ -239,6 +243,16 @@ int vds_unpatchify(const void* y, void* out, int32_t B, int32_t C, int32_t T, in
 /* gradient wrt tokens: dy[B*N, P] bf16 from dout [B,C,T,H,W] bf16 (inverse permutation) */
 int vds_unpatchify_bwd(const void* dout, void* dy, int32_t B, int32_t C, int32_t T, int32_t H,
                        int32_t W, int32_t pt, int32_t p, vds_stream_t stream);
+/* The same three with the tokens addressed as rows of the model's [B * (R + N)] token buffer: token n of sample b
+ * is row b * rows_per_sample + row_offset + n (rows_per_sample = R + N, row_offset = R = 16 register tokens,
+ * model.py:362,386), so that patch embedding and final layer run as ONE GEMM over all B * L rows instead of one
+ * per sample; the R rows in front of every sample are not touched.  rows_per_sample = 0 means N (dense).
+ * vds_unpatchify_rows: bwd = 0 tokens -> image, bwd != 0 image gradient -> token-row gradient. */
+int vds_patchify_rows(const void* latent, void* patches, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                      int32_t pt, int32_t p, int32_t rows_per_sample, int32_t row_offset, vds_stream_t stream);
+int vds_unpatchify_rows(const void* y, void* out, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                        int32_t pt, int32_t p, int32_t rows_per_sample, int32_t row_offset, int32_t bwd,
+                        vds_stream_t stream);
 /* x[b, 0:R] = reg[0:R] ; used to prepend the 16 register tokens (model.py:362) */
 int vds_fill_registers(const void* reg, void* x, int64_t batch_stride, int32_t B, int32_t R,
                        int32_t D, vds_stream_t stream);

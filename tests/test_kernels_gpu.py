@@ -336,6 +336,9 @@ def test_gate_bwd_and_colsum(ops):
     cs = torch.zeros(D, dtype=f32, device="cuda")
     ops.colsum(y.cuda(), cs)
     close("colsum", cs, y.float().sum(0), 1e-4)
+    cs2 = torch.zeros(D, dtype=f32, device="cuda")
+    ops.colsum(y.cuda(), cs2, rows_per_sample=L, row_offset=16)  # token rows only (skip 16 register rows per sample)
+    close("colsum.rows", cs2, y.float().reshape(B, L, D)[:, 16:].sum((0, 1)), 1e-4)
 
 
 # ----------------------------------------------------------------- qkv / rope / res-V ----
@@ -433,6 +436,18 @@ def test_patchify_unpatchify(ops, pt):
     assert torch.equal(img.cpu(), ref_img)
     back = ops.unpatchify_bwd(img, pt, p)
     assert torch.equal(back.cpu(), y)
+    # the same with the tokens addressed as rows of the model's [B * (16 + N)] token buffer (16 untouched register
+    # rows in front of every sample): what lets patch embedding / final layer run as one GEMM over all rows
+    R = 16
+    pat_r = ops.patchify(x.cuda(), pt, p, lead_rows=R).cpu().reshape(B, R + n, -1)
+    assert torch.equal(pat_r[:, R:], ref) and pat_r[:, :R].abs().max().item() == 0
+    y_r = torch.zeros(B, R + n, p * p * pt * C, dtype=bf16)
+    y_r[:, R:] = y.reshape(B, n, -1)
+    y_r[:, :R] = 7.0  # register rows must be ignored
+    img_r = ops.unpatchify(y_r.reshape(B * (R + n), -1).cuda(), B, C, T, H, W, pt, p, lead_rows=R)
+    assert torch.equal(img_r.cpu(), ref_img)
+    back_r = ops.unpatchify_bwd(img, pt, p, lead_rows=R).cpu().reshape(B, R + n, -1)
+    assert torch.equal(back_r[:, R:], y.reshape(B, n, -1)) and back_r[:, :R].abs().max().item() == 0
 
 
 def test_registers_noise_loss_cast(ops):

@@ -73,6 +73,7 @@ SIGNATURES = {
     "vds_gate_bwd": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32,
                      c_vp],
     "vds_colsum_bf16": [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp],
+    "vds_colsum_bf16_rows": [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_qkv_rope_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_qkv_rope_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                          c_i32, c_i32, c_i32, c_i32, c_vp],
@@ -87,6 +88,8 @@ SIGNATURES = {
     "vds_patchify": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_unpatchify": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_unpatchify_bwd": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_patchify_rows": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_unpatchify_rows": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_fill_registers": [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp],
     "vds_registers_bwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp],
     "vds_noise_latents": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],

@@ -261,8 +261,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
 }
 
 // column sums of a bf16 matrix (bias gradients): block = 64 column-chunks x 4 row lanes
+// rps > 0: only rows r with (r % rps) >= roff are summed (token rows of the [B*L] buffer, register rows skipped)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, long ldx, float* out, int M, int N,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, int rps, int roff) {
   __shared__ float red[4][64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, long ldx, 
   for (int e = 0; e < 8; ++e) a[e] = 0.f;
   if (c * 8 < N)
     for (int r = r0 + wave; r < r1; r += 4) {
+      if (rps > 0 && (r % rps) < roff) continue;
       float v[8];
       unpack8(*reinterpret_cast<const u32x4*>(x + (long)r * ldx + c * 8), v);
 #pragma unroll
@@ -746,7 +748,10 @@ __global__ void timestep_embedding_kernel(const float* t, float* out, int B, int
 
 // --------------------------------------------------------------- patchify / unpatchify ---
 // model.py:182-186: token (h w t), feature (c dt dh dw). thread = one (token, c, dt, dh) -> p elements
-__global__ void patchify_kernel(const bf16_t* x, bf16_t* out, int B, int C, int T, int H, int W, int pt, int p) {
+// token n of sample b is row b * rps + roff + n of `out` (rps = n tokens, roff = 0: the dense [B*N, P] matrix;
+// rps = 16 + N, roff = 16: rows of the [B*L] token buffer, register rows left to the caller)
+__global__ void patchify_kernel(const bf16_t* x, bf16_t* out, int B, int C, int T, int H, int W, int pt, int p,
+                                int rps, int roff) {
   const int t = T / pt, h = H / p, w = W / p;
   const int fpt = C * pt * p;  // feature groups of p elements per token
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -763,13 +768,15 @@ __global__ void patchify_kernel(const bf16_t* x, bf16_t* out, int B, int C, int 
   const int hi = (int)(r % h); r /= h;
   const int b = (int)r;
   const bf16_t* src = x + ((((long)b * C + c) * T + ti * pt + dt) * H + hi * p + dh) * W + wi * p;
-  bf16_t* dst = out + tok * (fpt * p) + ((c * pt + dt) * p + dh) * p;
+  const long orow = (long)b * rps + roff + (tok - (long)b * h * w * t);
+  bf16_t* dst = out + orow * (fpt * p) + ((c * pt + dt) * p + dh) * p;
   for (int dw = 0; dw < p; ++dw) dst[dw] = src[dw];
 }
 
 // model.py:392-401: y[b,(h w t),(p1 p2 p3 c)] <-> out[b,c,(t p3),(h p1),(w p2)]; thread = one out element
 template <bool BWD>
-__global__ void unpatchify_kernel(const bf16_t* in, bf16_t* outp, int B, int C, int T, int H, int W, int pt, int p) {
+__global__ void unpatchify_kernel(const bf16_t* in, bf16_t* outp, int B, int C, int T, int H, int W, int pt, int p,
+                                  int rps, int roff) {
   const int t = T / pt, h = H / p, w = W / p;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long total = (long)B * C * (t * pt) * (h * p) * (w * p);
@@ -781,7 +788,7 @@ __global__ void unpatchify_kernel(const bf16_t* in, bf16_t* outp, int B, int C, 
   const int c = (int)(r % C); r /= C;
   const int b = (int)r;
   const int wi = x / p, p2 = x % p, hi = yy / p, p1 = yy % p, ti = tt / pt, p3 = tt % pt;
-  const long tok = (((long)b * h + hi) * w + wi) * t + ti;
+  const long tok = (long)b * rps + roff + ((long)hi * w + wi) * t + ti;  // row of the token matrix (see patchify_kernel)
   const long tokidx = tok * ((long)p * p * pt * C) + (((p1 * p + p2) * pt + p3) * C + c);
   // image index over the full [B,C,T,H,W] tensor (T,H,W may exceed t*pt.. when not divisible)
   const long img = ((((long)b * C + c) * T + tt) * H + yy) * W + x;
@@ -1014,12 +1021,17 @@ extern "C" int vds_gate_bwd(const void* dxn, int64_t lddxn, const void* y, int64
   return ok();
 }
 
-extern "C" int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M, int32_t N, vds_stream_t stream) {
-  if (!x || !out || (N & 7) || (ldx & 7)) return VDS_ERR_ARG;
+extern "C" int vds_colsum_bf16_rows(const void* x, int64_t ldx, float* out, int32_t M, int32_t N,
+                                    int32_t rows_per_sample, int32_t row_offset, vds_stream_t stream) {
+  if (!x || !out || (N & 7) || (ldx & 7) || rows_per_sample < 0 || row_offset < 0) return VDS_ERR_ARG;
   const int rpb = M > 8192 ? (M + 127) / 128 : 64;
   dim3 grid((N / 8 + 63) / 64, (M + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, out, M, N, rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, out, M, N, rpb,
+                     rows_per_sample, row_offset);
   return ok();
+}
+extern "C" int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M, int32_t N, vds_stream_t stream) {
+  return vds_colsum_bf16_rows(x, ldx, out, M, N, 0, 0, stream);
 }
 
 // the wave-per-token kernels need 16-byte aligned head rows (hdp % 8 == 0), hd/2 a multiple of 4 and D <= 2048;
@@ -1135,31 +1147,48 @@ extern "C" int vds_timestep_embedding(const float* t, float* out, int32_t B, int
   return ok();
 }
 
-extern "C" int vds_patchify(const void* latent, void* patches, int32_t B, int32_t C, int32_t T, int32_t H,
-                            int32_t W, int32_t pt, int32_t p, vds_stream_t stream) {
+extern "C" int vds_patchify_rows(const void* latent, void* patches, int32_t B, int32_t C, int32_t T, int32_t H,
+                                 int32_t W, int32_t pt, int32_t p, int32_t rows_per_sample, int32_t row_offset,
+                                 vds_stream_t stream) {
   if (!latent || !patches || pt < 1 || p < 1) return VDS_ERR_ARG;
-  const long n = (long)B * (H / p) * (W / p) * (T / pt) * C * pt * p;
+  const int ntok = (H / p) * (W / p) * (T / pt);
+  if (rows_per_sample == 0) rows_per_sample = ntok;
+  if (row_offset < 0 || rows_per_sample < row_offset + ntok) return VDS_ERR_ARG;
+  const long n = (long)B * ntok * C * pt * p;
   hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)latent, (bf16_t*)patches, B, C, T, H, W, pt, p);
+                     (const bf16_t*)latent, (bf16_t*)patches, B, C, T, H, W, pt, p, rows_per_sample, row_offset);
   return ok();
 }
+extern "C" int vds_patchify(const void* latent, void* patches, int32_t B, int32_t C, int32_t T, int32_t H,
+                            int32_t W, int32_t pt, int32_t p, vds_stream_t stream) {
+  return vds_patchify_rows(latent, patches, B, C, T, H, W, pt, p, 0, 0, stream);
+}
 
+extern "C" int vds_unpatchify_rows(const void* y, void* out, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                                   int32_t pt, int32_t p, int32_t rows_per_sample, int32_t row_offset, int32_t bwd,
+                                   vds_stream_t stream) {
+  if (!y || !out || (T % pt) || (H % p) || (W % p)) return VDS_ERR_ARG;
+  const int ntok = (H / p) * (W / p) * (T / pt);
+  if (rows_per_sample == 0) rows_per_sample = ntok;
+  if (row_offset < 0 || rows_per_sample < row_offset + ntok) return VDS_ERR_ARG;
+  const long n = (long)B * C * T * H * W;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (bwd)  // y = d(out) [B,C,T,H,W] in, out = d(token rows) written
+    hipLaunchKernelGGL((unpatchify_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+                       (bf16_t*)out, B, C, T, H, W, pt, p, rows_per_sample, row_offset);
+  else
+    hipLaunchKernelGGL((unpatchify_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+                       (bf16_t*)out, B, C, T, H, W, pt, p, rows_per_sample, row_offset);
+  return ok();
+}
 extern "C" int vds_unpatchify(const void* y, void* out, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
                               int32_t pt, int32_t p, vds_stream_t stream) {
-  if (!y || !out || (T % pt) || (H % p) || (W % p)) return VDS_ERR_ARG;
-  const long n = (long)B * C * T * H * W;
-  hipLaunchKernelGGL((unpatchify_kernel<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)y, (bf16_t*)out, B, C, T, H, W, pt, p);
-  return ok();
+  return vds_unpatchify_rows(y, out, B, C, T, H, W, pt, p, 0, 0, 0, stream);
 }
 
 extern "C" int vds_unpatchify_bwd(const void* dout, void* dy, int32_t B, int32_t C, int32_t T, int32_t H,
                                   int32_t W, int32_t pt, int32_t p, vds_stream_t stream) {
-  if (!dout || !dy || (T % pt) || (H % p) || (W % p)) return VDS_ERR_ARG;
-  const long n = (long)B * C * T * H * W;
-  hipLaunchKernelGGL((unpatchify_kernel<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dout, (bf16_t*)dy, B, C, T, H, W, pt, p);
-  return ok();
+  return vds_unpatchify_rows(dout, dy, B, C, T, H, W, pt, p, 0, 0, 1, stream);
 }
 
 extern "C" int vds_fill_registers(const void* reg, void* x, int64_t batch_stride, int32_t B, int32_t R, int32_t D,

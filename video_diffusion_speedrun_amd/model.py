@@ -624,14 +624,13 @@ class DiT(nn.Module):
             if save:
                 self._fp8_hist.roll()
 
-        # patch embed + register tokens -> token buffer X [B*L, D]   (model.py:360-362)
-        patches = ops.patchify(x, pt, p)
+        # patch embed + register tokens -> token buffer X [B*L, D]   (model.py:360-362).  ONE GEMM over all B*L rows:
+        # the patches are laid out as rows of the token buffer (16 zero rows in front of every sample, whose outputs --
+        # the bias -- are then overwritten by the register tokens)
+        patches = ops.patchify(x, pt, p, lead_rows=N_REG)
         P = patches.shape[1]
-        X = torch.empty(B * L, D, dtype=bf16, device=dev)
         Wpe = R.w("patch_embed.patch_proj.weight").view(D, P)
-        bpe = R.w("patch_embed.patch_proj.bias")
-        for bi in range(B):
-            ops.linear_fwd(patches[bi * N:(bi + 1) * N], Wpe, bpe, out=X[bi * L + N_REG:(bi + 1) * L])
+        X = ops.linear_fwd(patches, Wpe, R.w("patch_embed.patch_proj.bias"))
         ops.fill_registers(R.w("register_tokens").view(N_REG, D), X, L * D, B, N_REG, D)
         cos, sin = self.rope.rows((t, h, w), rope_start, N_REG)
 
@@ -664,15 +663,11 @@ class DiT(nn.Module):
         # final layer (model.py:386-401)
         fmod = ops.small_linear_fwd(cvec, R.w("final_modulation.1.weight"), R.w("final_modulation.1.bias"), 1)
         wfn = R.w("final_norm.weight") if R.has("final_norm.weight") else None
-        xnf = torch.empty(B * N, D, dtype=bf16, device=dev)
-        rstdf = torch.empty(B * N, dtype=f32, device=dev)
-        for bi in range(B):
-            ops._lib.check(ops._lib.load().vds_rmsnorm_mod_fwd(
-                X[bi * L + N_REG:].data_ptr(), D, ops._p(wfn), fmod[bi:].data_ptr(), 2 * D, 0, D,
-                xnf[bi * N:].data_ptr(), D, rstdf[bi * N:].data_ptr(), 1, N, D, 1e-6, ops._stream()),
-                "vds_rmsnorm_mod_fwd(final)")
+        # norm, modulation and projection run over all B*L rows (the 16 register rows of a sample are 0.2 % of them and
+        # are simply not read back: the reference slices them off first, model.py:386); unpatchify picks the token rows
+        xnf, rstdf = ops.rmsnorm_mod_fwd(X, wfn, fmod, 0, D, B, L)
         yf = ops.linear_fwd(xnf, R.w("final_proj.weight"), R.w("final_proj.bias"))
-        out = ops.unpatchify(yf, B, C, T, Hh, Ww, pt, p)
+        out = ops.unpatchify(yf, B, C, T, Hh, Ww, pt, p, lead_rows=N_REG)
         if save:
             sv.fmod, sv.xnf, sv.rstdf = fmod, xnf, rstdf
         if fs is not None:
@@ -705,20 +700,15 @@ class DiT(nn.Module):
         Pd = p * p * pt * C
         dout = dout.to(bf16).contiguous()
         # final layer
-        dyf = ops.unpatchify_bwd(dout, pt, p)
+        dyf = ops.unpatchify_bwd(dout, pt, p, lead_rows=N_REG)  # [B*L, P], register rows zero
         ops.linear_wgrad(dyf, sv.xnf, R.g("final_proj.weight"))
         ops.colsum(dyf, R.g("final_proj.bias"))
         dxnf = ops.linear_dgrad(dyf, R.w("final_proj.weight"))
-        dX = torch.zeros(B * L, D, dtype=bf16, device=dev)
         dfmod = torch.zeros(B, 2 * D, dtype=f32, device=dev)
         wfn = R.w("final_norm.weight") if R.has("final_norm.weight") else None
         dwfn = R.g("final_norm.weight") if wfn is not None else None
-        for bi in range(B):
-            ops._lib.check(ops._lib.load().vds_rmsnorm_mod_bwd(
-                dxnf[bi * N:].data_ptr(), D, sv.x_last[bi * L + N_REG:].data_ptr(), D, ops._p(wfn),
-                sv.fmod[bi:].data_ptr(), 2 * D, 0, D, sv.rstdf[bi * N:].data_ptr(), None, 0,
-                dX[bi * L + N_REG:].data_ptr(), D, dfmod[bi:].data_ptr(), ops._p(dwfn), 1, N, D, ops._stream()),
-                "vds_rmsnorm_mod_bwd(final)")
+        # register rows: dxnf = 0 there, so they get a zero gradient from the final layer (they were sliced off)
+        dX = ops.rmsnorm_mod_bwd(dxnf, sv.x_last, wfn, sv.fmod, 0, D, sv.rstdf, None, dfmod, dwfn, B, L)
         dc = torch.zeros(B, D, dtype=f32, device=dev)
         ops.small_linear_bwd(dfmod, sv.cvec, R.w("final_modulation.1.weight"), R.g("final_modulation.1.weight"),
                              R.g("final_modulation.1.bias"), dc, 1)
@@ -734,11 +724,10 @@ class DiT(nn.Module):
                 fs.post_backward_block(i)
         # registers + patch embed (model.py:360-362)
         ops.registers_bwd(dX, L * D, R.g("register_tokens").view(N_REG, D), B, N_REG, D)
-        gWpe = R.g("patch_embed.patch_proj.weight").view(D, Pd)
-        for bi in range(B):
-            dtok = dX[bi * L + N_REG:(bi + 1) * L]
-            ops.linear_wgrad(dtok, sv.patches[bi * N:(bi + 1) * N], gWpe, accumulate=True)
-            ops.colsum(dtok, R.g("patch_embed.patch_proj.bias"))
+        # patch embedding: weight gradient over all B*L rows (the register rows of `patches` are zero), bias gradient
+        # over the token rows only
+        ops.linear_wgrad(dX, sv.patches, R.g("patch_embed.patch_proj.weight").view(D, Pd))
+        ops.colsum(dX, R.g("patch_embed.patch_proj.bias"), rows_per_sample=L, row_offset=N_REG)
         # time embed MLP
         dh1 = torch.zeros(B, 4 * D, dtype=f32, device=dev)
         ops.small_linear_bwd(dc, sv.h1, R.w("time_embed.2.weight"), R.g("time_embed.2.weight"),

@@ -259,9 +259,11 @@ def gate_bwd(dxn, y, mod, gate_col, dmod, dbias, B, L):
     return dy
 
 
-def colsum(x, out):
+def colsum(x, out, rows_per_sample: int = 0, row_offset: int = 0):
+    """out[n] += sum_m x[m, n]; with rows_per_sample: only rows m with m % rows_per_sample >= row_offset (token rows)"""
     M, N = x.shape
-    check(_lib.load().vds_colsum_bf16(_p(x), x.stride(0), _p(out), M, N, _stream()), "vds_colsum_bf16")
+    check(_lib.load().vds_colsum_bf16_rows(_p(x), x.stride(0), _p(out), M, N, rows_per_sample, row_offset, _stream()),
+          "vds_colsum_bf16_rows")
 
 
 # ----------------------------------------------------------------- qkv / rope / res-V ----
@@ -338,25 +340,32 @@ def timestep_embedding(t, D):
 
 
 # ------------------------------------------------------------- patches / registers ----
-def patchify(x, pt, p):
+def patchify(x, pt, p, lead_rows: int = 0):
+    """[B,C,T,H,W] -> patch rows; lead_rows = R: rows of a [B * (R + N)] token buffer (R zero rows per sample first)"""
     B, Cc, T, H, W = x.shape
     n = (T // pt) * (H // p) * (W // p)
-    out = torch.empty(B * n, Cc * pt * p * p, dtype=bf16, device=x.device)
-    check(_lib.load().vds_patchify(_p(x), _p(out), B, Cc, T, H, W, pt, p, _stream()), "vds_patchify")
+    alloc = torch.zeros if lead_rows else torch.empty
+    out = alloc(B * (lead_rows + n), Cc * pt * p * p, dtype=bf16, device=x.device)
+    check(_lib.load().vds_patchify_rows(_p(x), _p(out), B, Cc, T, H, W, pt, p, lead_rows + n, lead_rows, _stream()),
+          "vds_patchify_rows")
     return out
 
 
-def unpatchify(y, B, Cc, T, H, W, pt, p):
+def unpatchify(y, B, Cc, T, H, W, pt, p, lead_rows: int = 0):
+    n = (T // pt) * (H // p) * (W // p)
     out = torch.empty(B, Cc, T, H, W, dtype=bf16, device=y.device)
-    check(_lib.load().vds_unpatchify(_p(y), _p(out), B, Cc, T, H, W, pt, p, _stream()), "vds_unpatchify")
+    check(_lib.load().vds_unpatchify_rows(_p(y), _p(out), B, Cc, T, H, W, pt, p, lead_rows + n, lead_rows, 0, _stream()),
+          "vds_unpatchify_rows")
     return out
 
 
-def unpatchify_bwd(dout, pt, p):
+def unpatchify_bwd(dout, pt, p, lead_rows: int = 0):
     B, Cc, T, H, W = dout.shape
     n = (T // pt) * (H // p) * (W // p)
-    dy = torch.empty(B * n, Cc * pt * p * p, dtype=bf16, device=dout.device)
-    check(_lib.load().vds_unpatchify_bwd(_p(dout), _p(dy), B, Cc, T, H, W, pt, p, _stream()), "vds_unpatchify_bwd")
+    alloc = torch.zeros if lead_rows else torch.empty
+    dy = alloc(B * (lead_rows + n), Cc * pt * p * p, dtype=bf16, device=dout.device)
+    check(_lib.load().vds_unpatchify_rows(_p(dout), _p(dy), B, Cc, T, H, W, pt, p, lead_rows + n, lead_rows, 1, _stream()),
+          "vds_unpatchify_rows(bwd)")
     return dy
 
 
