@@ -500,23 +500,38 @@ class WgradOverlap:
     def __init__(self, device):
         self.side = torch.cuda.Stream(device=device, priority=0)
         self.pending = False
+        self.held = []    # operands of the weight gradients queued since the last end_block (kept alive by hand:
+        self.queue = []   # record_stream() would make the caching allocator stall on multi-GB buffers)
 
     def wgrad(self, dy, x, dW):
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)                 # dy, x (and the zeroed dW) are complete at this point of the main stream
         self.side.wait_event(ev)
-        dy.record_stream(self.side)     # the caching allocator must not hand these out again before the GEMM ran
-        x.record_stream(self.side)
+        self.held.append((dy, x))
         with torch.cuda.stream(self.side):
             ops.linear_wgrad(dy, x, dW)
         self.pending = True
+
+    def end_block(self):
+        """after a block's backward: its weight gradients may still run; the main stream waits for those of the block
+        BEFORE it (one block of lag) and only then are their operands released to the allocator"""
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        self.queue.append((ev, self.held))
+        self.held = []
+        if len(self.queue) > 1:
+            ev0, held0 = self.queue.pop(0)
+            torch.cuda.current_stream().wait_event(ev0)
+            del held0
 
     def join(self):
         """the main stream waits for every weight gradient queued so far"""
         if self.pending:
             torch.cuda.current_stream().wait_stream(self.side)
             self.pending = False
+        self.queue.clear()
+        self.held = []
 
 
 class DiT(nn.Module):
@@ -761,9 +776,12 @@ class DiT(nn.Module):
             dX = self.blocks[i]._bwd(self.block_group(i), f"blocks.{i}.", sv.blocks[i], dX, sv, dc, dv0, B, L, Lc,
                                      i == 0, (self._fp8_hist, i) if self.fp8 else None, wgrad)
             sv.blocks[i] = None
-            if fs is not None:
-                if wo is not None:
+            if wo is not None:
+                if fs is not None:
                     wo.join()  # the block's reduce-scatter needs its weight gradients
+                else:
+                    wo.end_block()
+            if fs is not None:
                 fs.post_backward_block(i)
         # registers + patch embed (model.py:360-362)
         ops.registers_bwd(dX, L * D, R.g("register_tokens").view(N_REG, D), B, N_REG, D)
