@@ -167,8 +167,6 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel-class table (stderr)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one captured HIP graph (1 GPU; launch-bound workloads)")
-    ap.add_argument("--wgrad-stream", action="store_true",
-                    help="experiment: weight-gradient GEMMs on a second (low-priority) stream, the step on a high-priority one")
     ap.add_argument("--force-shard-runtime", action="store_true",
                     help="1 GPU only: run the sharding runtime (streams, events, RCCL collectives on a 1-rank group)")
     args = ap.parse_args()
@@ -218,16 +216,7 @@ def main():
              "context": torch.randn(B, LC, CC, device=device, generator=gen).to(torch.bfloat16),
              "prompt": [""] * B}
 
-    hi = None
-    if args.wgrad_stream:
-        model.enable_wgrad_overlap()
-        hi = torch.cuda.Stream(device=device, priority=-1)
-        hi.wait_stream(torch.cuda.current_stream())
-
     def one_step():
-        if hi is not None:
-            with torch.cuda.stream(hi):
-                return train_step(model, opt, sched, batch, device, generator=gen)
         return train_step(model, opt, sched, batch, device, generator=gen)
 
     graphed = None

@@ -387,14 +387,13 @@ class DiTBlock(nn.Module):
         return X3, v, bs
 
 
-    def _bwd(self, G, pre, bs, dX, sv, dc, dv0, B, L, Lc, first, fp8=None, wgrad=None):
+    def _bwd(self, G, pre, bs, dX, sv, dc, dv0, B, L, Lc, first, fp8=None):
         """backward of `_fwd`: dX [B*L, D] bf16 -> d(input tokens); parameter gradients go to G's fp32 gradient
         buffer; dc (f32 [B, D]) and dv0 (f32 [B,H,L,hdp]) accumulate the conditioning / residual-V gradients.
         sv carries cos, sin, v0, ctx2d, cvec.  first: this is the block whose v was handed out as v_0."""
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
         hdp = {64: 64, 72: 96, 128: 128}[hd]
         fp8_hist, i = fp8 if fp8 is not None else (None, 0)
-        wg = wgrad if wgrad is not None else ops.linear_wgrad
         W = lambda n: G.w(pre + n)
         Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
         Gr = lambda n: G.g(pre + n)
@@ -420,9 +419,9 @@ class DiTBlock(nn.Module):
             dxn = F8.dgrad(q_dh, bs.q_w1)
             del q_dy, q_dh
         else:
-            wg(dy, bs.hact, Gr("mlp.2.weight"))
+            ops.linear_wgrad(dy, bs.hact, Gr("mlp.2.weight"))
             dh = ops.linear_dgrad(dy, W("mlp.2.weight"), pre=bs.hpre)
-            wg(dh, bs.xn3, Gr("mlp.0.weight"))
+            ops.linear_wgrad(dh, bs.xn3, Gr("mlp.0.weight"))
             ops.colsum(dh, Gr("mlp.0.bias"))
             dxn = ops.linear_dgrad(dh, W("mlp.0.weight"))
         del dh
@@ -431,7 +430,7 @@ class DiTBlock(nn.Module):
         # --- cross attention
         if bs.has_cross:
             dy = ops.gate_bwd(dX2, bs.y_ca, mod, 5 * D, dmod, None, B, L)
-            wg(dy, bs.catt, Gr("cross_proj.weight"))
+            ops.linear_wgrad(dy, bs.catt, Gr("cross_proj.weight"))
             dcatt = ops.linear_dgrad(dy, W("cross_proj.weight"))
             dqc = torch.empty(B * L, D, dtype=bf16, device=dev)
             dckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
@@ -440,10 +439,10 @@ class DiTBlock(nn.Module):
                          ops.heads_view(bs.ckv, B, Lc, H, hd, D), ops.heads_view(bs.catt, B, L, H, hd), bs.lse2,
                          ops.heads_view(dcatt, B, L, H, hd), ops.heads_view(dqc, B, L, H, hd),
                          ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), delta)
-            wg(dckv, sv.ctx2d, Gr("context_kv.weight"))
+            ops.linear_wgrad(dckv, sv.ctx2d, Gr("context_kv.weight"))
             if G.has(pre + "context_kv.bias"):
                 ops.colsum(dckv, Gr("context_kv.bias"))
-            wg(dqc, bs.xn2, Gr("q_cross.weight"))
+            ops.linear_wgrad(dqc, bs.xn2, Gr("q_cross.weight"))
             if G.has(pre + "q_cross.bias"):
                 ops.colsum(dqc, Gr("q_cross.bias"))
             dxn = ops.linear_dgrad(dqc, W("q_cross.weight"))
@@ -453,7 +452,7 @@ class DiTBlock(nn.Module):
             dX1 = dX2
         # --- self attention
         dy = ops.gate_bwd(dX1, bs.y_sa, mod, 2 * D, dmod, None, B, L)
-        wg(dy, bs.attn, Gr("attn_proj.weight"))
+        ops.linear_wgrad(dy, bs.attn, Gr("attn_proj.weight"))
         dattn = ops.linear_dgrad(dy, W("attn_proj.weight"))
         dq = torch.empty(B, H, L, hdp, dtype=bf16, device=dev)
         dk = torch.empty_like(dq)
@@ -474,7 +473,7 @@ class DiTBlock(nn.Module):
             dxn = F8.dgrad(q_dqkv, bs.q_wqkv)
             del q_dqkv
         else:
-            wg(dqkv, bs.xn1, Gr("qkv.weight"))
+            ops.linear_wgrad(dqkv, bs.xn1, Gr("qkv.weight"))
             dxn = ops.linear_dgrad(dqkv, W("qkv.weight"))
         dX0 = ops.rmsnorm_mod_bwd(dxn, bs.X, Wo("norm1.weight"), mod, 0, D, bs.rstd1, dX1, dmod, Go("norm1.weight"),
                                   B, L)
@@ -487,51 +486,6 @@ class DiTBlock(nn.Module):
 class _Saved:
     """activations kept for the backward pass"""
     pass
-
-
-class WgradOverlap:
-    """Weight-gradient GEMMs on a second HIP stream (experiment, `DiT.enable_wgrad_overlap()` / VDS_WGRAD_STREAM=1).
-    dW = dy^T x is off the backward's critical path (only the optimizer / the reduce-scatter consumes it), and its
-    256x128-tile kernel (72 KiB of LDS per workgroup) cannot share a CU with the attention kernels or the 256^2 GEMM
-    (LDS is full) but can with the HBM-bound glue kernels, which leave the matrix pipes idle.  Run the model itself on
-    a HIGH-priority stream (`torch.cuda.Stream(priority=-1)`): the side stream has the default (low) priority, so
-    its workgroups only take what the critical path leaves free."""
-
-    def __init__(self, device):
-        self.side = torch.cuda.Stream(device=device, priority=0)
-        self.pending = False
-        self.held = []    # operands of the weight gradients queued since the last end_block (kept alive by hand:
-        self.queue = []   # record_stream() would make the caching allocator stall on multi-GB buffers)
-
-    def wgrad(self, dy, x, dW):
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)                 # dy, x (and the zeroed dW) are complete at this point of the main stream
-        self.side.wait_event(ev)
-        self.held.append((dy, x))
-        with torch.cuda.stream(self.side):
-            ops.linear_wgrad(dy, x, dW)
-        self.pending = True
-
-    def end_block(self):
-        """after a block's backward: its weight gradients may still run; the main stream waits for those of the block
-        BEFORE it (one block of lag) and only then are their operands released to the allocator"""
-        ev = torch.cuda.Event()
-        ev.record(self.side)
-        self.queue.append((ev, self.held))
-        self.held = []
-        if len(self.queue) > 1:
-            ev0, held0 = self.queue.pop(0)
-            torch.cuda.current_stream().wait_event(ev0)
-            del held0
-
-    def join(self):
-        """the main stream waits for every weight gradient queued so far"""
-        if self.pending:
-            torch.cuda.current_stream().wait_stream(self.side)
-            self.pending = False
-        self.queue.clear()
-        self.held = []
 
 
 class DiT(nn.Module):
@@ -572,18 +526,12 @@ class DiT(nn.Module):
         self._world, self._rank, self._pg = 1, 0, None
         self._fsdp = None  # set by fsdp.apply_fsdp
         self.fp8 = False   # enable_fp8(): qkv / mlp GEMMs on the fp8 MFMA path (fp8.py; BASELINE config 5)
-        self._wgrad_overlap: Optional[WgradOverlap] = None
 
     def enable_fp8(self, on: bool = True):
         """Run the qkv and MLP linears of every block in OCP fp8 (e4m3 activations / weights, e5m2 gradients,
         per-tensor current scaling; fp8.py states the recipe).  The reference has no such mode."""
         self.fp8 = bool(on)
         self._fp8_hist = None  # fp8.AmaxHistory: 6 rows per block (gelu(fc1), d fc2-in, xn1, xn3, d mlp-out, d qkv)
-        return self
-
-    def enable_wgrad_overlap(self, on: bool = True):
-        """weight-gradient GEMMs of the blocks on a second stream (see WgradOverlap)"""
-        self._wgrad_overlap = "pending" if on else None
         return self
 
     # --------------------------------------------------------------------- parameters ----
@@ -766,21 +714,12 @@ class DiT(nn.Module):
                              R.g("final_modulation.1.bias"), dc, 1)
         hdp = {64: 64, 72: 96, 128: 128}[hd]
         dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev) if (self.residual_v and self.depth > 1) else None
-        if self._wgrad_overlap == "pending" or (self._wgrad_overlap is None and os.environ.get("VDS_WGRAD_STREAM") == "1"):
-            self._wgrad_overlap = WgradOverlap(dev)
-        wo = self._wgrad_overlap
-        wgrad = wo.wgrad if wo is not None else None
         for i in reversed(range(self.depth)):
             if fs is not None:
                 fs.pre_backward_block(i)
             dX = self.blocks[i]._bwd(self.block_group(i), f"blocks.{i}.", sv.blocks[i], dX, sv, dc, dv0, B, L, Lc,
-                                     i == 0, (self._fp8_hist, i) if self.fp8 else None, wgrad)
+                                     i == 0, (self._fp8_hist, i) if self.fp8 else None)
             sv.blocks[i] = None
-            if wo is not None:
-                if fs is not None:
-                    wo.join()  # the block's reduce-scatter needs its weight gradients
-                else:
-                    wo.end_block()
             if fs is not None:
                 fs.post_backward_block(i)
         # registers + patch embed (model.py:360-362)
@@ -794,8 +733,6 @@ class DiT(nn.Module):
         ops.small_linear_bwd(dc, sv.h1, R.w("time_embed.2.weight"), R.g("time_embed.2.weight"),
                              R.g("time_embed.2.bias"), dh1, 1)
         ops.small_linear_bwd(dh1, sv.temb, None, R.g("time_embed.0.weight"), R.g("time_embed.0.bias"), None, 0)
-        if wo is not None:
-            wo.join()
         if fs is not None:
             fs.post_backward_root()
         else:
