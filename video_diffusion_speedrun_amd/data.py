@@ -17,10 +17,16 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader, Dataset, Sampler
 
 
+HF_DATASET = "fal/cosmos-openvid-1m"
+HF_ROWS_USED = 1979810 // 2     # the reference trains on the first half of the dataset ...
+TEST_ROWS = 40                  # ... whose last 40 rows are its test split (sharded_dataset.py:18-19)
+
+
 def deserialize_tensor(serialized_tensor: bytes, device=None) -> torch.Tensor:
-    """sharded_dataset.py:8-13"""
-    return torch.load(io.BytesIO(serialized_tensor), weights_only=True,
-                      map_location=torch.device(device) if device else None)
+    """bytes written by torch.save -> tensor (the row format of the dataset, sharded_dataset.py:8-13); tensors only"""
+    where = torch.device(device) if device else None
+    with io.BytesIO(serialized_tensor) as stream:
+        return torch.load(stream, map_location=where, weights_only=True)
 
 
 def serialize_tensor(t: torch.Tensor) -> bytes:
@@ -29,29 +35,35 @@ def serialize_tensor(t: torch.Tensor) -> bytes:
     return buf.getvalue()
 
 
+def split_indices(split: str) -> range:
+    """row indices of the reference's train / test split"""
+    first_test = HF_ROWS_USED - TEST_ROWS
+    return range(first_test) if split == "train" else range(first_test, HF_ROWS_USED)
+
+
 class LatentDataset(Dataset):
-    """sharded_dataset.py:16-32.  `rows`: pre-loaded rows; otherwise the HF dataset with the
-    reference's train / test split rule (the last 40 of the first half are the test split)."""
+    """Same contract as the reference's class (sharded_dataset.py:16-32): item = {"latent": tensor on the CPU,
+    "prompt": caption}.  `rows`: pre-loaded rows (any indexable); otherwise the HF dataset, which needs network or a
+    local cache."""
 
     def __init__(self, split="train", cache_dir="./cache", rows: Optional[Sequence[dict]] = None):
         if rows is None:
-            from datasets import load_dataset  # network or local cache required
-            MS = 1979810 // 2
-            rng = range(0, MS - 40) if split == "train" else range(MS - 40, MS)
-            rows = load_dataset("fal/cosmos-openvid-1m", split="train", cache_dir=cache_dir).select(rng)
+            from datasets import load_dataset
+            rows = load_dataset(HF_DATASET, split="train", cache_dir=cache_dir).select(split_indices(split))
         self.dataset = rows
 
     def __len__(self):
         return len(self.dataset)
 
     def __getitem__(self, idx):
-        item = self.dataset[idx]
-        return {"latent": deserialize_tensor(item["serialized_latent"], "cpu"), "prompt": item["caption"]}
+        row = self.dataset[idx]
+        return {"latent": deserialize_tensor(row["serialized_latent"], "cpu"), "prompt": row["caption"]}
 
 
 def collate_fn(batch):
-    """utils.py:21-25"""
-    return {"latent": torch.stack([item["latent"] for item in batch]), "prompt": [item["prompt"] for item in batch]}
+    """list of items -> {"latent": stacked [B, ...], "prompt": list of str} (utils.py:21-25)"""
+    latents, prompts = zip(*((item["latent"], item["prompt"]) for item in batch))
+    return {"latent": torch.stack(latents), "prompt": list(prompts)}
 
 
 class RankShardSampler(Sampler):

@@ -24,16 +24,16 @@ ALPHA = 8.0  # time shift, train.py:95
 
 def encode_prompt_with_t5(text_encoder, tokenizer, max_sequence_length=512, prompt=None, device=None,
                           return_index=-1):
-    """utils.py:38-80 (host-side glue around the caller's frozen encoder)."""
-    prompt = [prompt] if isinstance(prompt, str) else prompt
-    ids = tokenizer(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
-                    return_length=False, return_overflowing_tokens=False, return_tensors="pt").input_ids
-    enc = text_encoder(ids.to(device), return_dict=True, output_hidden_states=True)
-    emb = enc.hidden_states[return_index]
-    if return_index != -1:
-        emb = text_encoder.encoder.final_layer_norm(emb)
-        emb = text_encoder.encoder.dropout(emb)
-    return emb.to(dtype=text_encoder.dtype, device=device)
+    """Caption -> encoder hidden states [B, max_sequence_length, C] in the encoder's dtype, same call contract as
+    the reference's helper (utils.py:38-80).  The encoder is the caller's frozen third-party model: host glue only."""
+    prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+    tokens = tokenizer(prompts, padding="max_length", max_length=max_sequence_length, truncation=True,
+                       return_length=False, return_overflowing_tokens=False, return_tensors="pt")
+    states = text_encoder(tokens.input_ids.to(device), return_dict=True, output_hidden_states=True).hidden_states
+    chosen = states[return_index]
+    if return_index != -1:  # an inner layer: finish it the way the encoder finishes its last one
+        chosen = text_encoder.encoder.dropout(text_encoder.encoder.final_layer_norm(chosen))
+    return chosen.to(device=device, dtype=text_encoder.dtype)
 
 
 class _FlowLoss(torch.autograd.Function):
