@@ -117,17 +117,21 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
   for (int l = l0 + wave; l < l1; l += 4) {
     const long row = (long)b * L + l;
     const float r = rstd[row];
-    u32x4 pdy[NC], px[NC];
+    u32x4 pdy[NC], px[NC], pres[NC];
     float dot = 0.f;
+    // all three streams of the row are requested together: the residual gradient is only needed after the row
+    // reduction, and loading it there would expose a second HBM round trip per row
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         pdy[i] = *reinterpret_cast<const u32x4*>(dy + row * lddy + c * 8);
         px[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
+        pres[i] = dres ? *reinterpret_cast<const u32x4*>(dres + row * lddres + c * 8) : u32x4{0u, 0u, 0u, 0u};
       } else {
         pdy[i] = u32x4{0u, 0u, 0u, 0u};
         px[i] = u32x4{0u, 0u, 0u, 0u};
+        pres[i] = u32x4{0u, 0u, 0u, 0u};
       }
     }
 #pragma unroll
@@ -156,11 +160,7 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
       const int c = lane + 64 * i;
       if (c < nch) {
         float o[8], dyv[8], xv[8];
-        if (dres) unpack8(*reinterpret_cast<const u32x4*>(dres + row * lddres + c * 8), o);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = 0.f;
-        }
+        unpack8(pres[i], o);  // zeros without a residual gradient
         unpack8(pdy[i], dyv);
         unpack8(px[i], xv);
 #pragma unroll
