@@ -629,73 +629,6 @@ __global__ __launch_bounds__(256) void attn_delta_tokmajor_kernel(AttnP p) {
   }
 }
 
-// The same preprocess for 64 consecutive tokens of one sample per workgroup: each wave folds 16 tokens (one at a
-// time, 16-byte loads of the O and dO rows) into per-(token, head) dots in LDS; then thread (head h, token quad)
-// reads lse and writes -delta and lse2 for 4 consecutive tokens of its head with ONE 16-byte access each -- in the
-// [B,H,L] statistics arrays consecutive tokens of a head are contiguous, so what were four scattered 4-byte accesses
-// per (token, head) in attn_delta_tokmajor_kernel become one (the Q-pad annotation, 192-byte stride).
-__global__ __launch_bounds__(256) void attn_delta_tok64_kernel(AttnP p, int blocks_per_sample) {
-  __shared__ float part[4][192];
-  __shared__ float dots[64][17];  // [token][head], padded
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / blocks_per_sample, l0 = (blockIdx.x % blocks_per_sample) * 64;
-  const int nch = p.H * p.hd / 8, cph = p.hd / 8;
-  for (int t = 0; t < 16; ++t) {
-    const int tl = wave * 16 + t, q = l0 + tl;
-    if (q < p.Lq) {
-      const bf16_t* o = p.o + b * p.o_sb + (long)q * p.o_sl;
-      const bf16_t* d = p.d_o + b * p.do_sb + (long)q * p.do_sl;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-          const u32x4 a = *reinterpret_cast<const u32x4*>(o + c * 8);
-          const u32x4 g = *reinterpret_cast<const u32x4*>(d + c * 8);
-          float acc = 0.f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc += bflo(a[e]) * bflo(g[e]) + bfhi(a[e]) * bfhi(g[e]);
-          part[wave][c] = acc;
-        }
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes
-    __builtin_amdgcn_wave_barrier();
-    if (lane < p.H) {
-      float acc = 0.f;
-      if (q < p.Lq)
-        for (int i = 0; i < cph; ++i) acc += part[wave][lane * cph + i];
-      dots[tl][lane] = acc;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
-  const long rows = (long)p.B * p.H * p.Lq;
-  for (int it = threadIdx.x; it < p.H * 16; it += 256) {
-    const int hh = it >> 4, tq = (it & 15) * 4;  // 4 consecutive tokens of head hh
-    const int q = l0 + tq;
-    if (q >= p.Lq) continue;
-    const long row = ((long)b * p.H + hh) * p.Lq + q;
-    if (q + 4 <= p.Lq && ((row & 3) == 0) && ((rows & 3) == 0)) {
-      const f32x4 ls = *reinterpret_cast<const f32x4*>(p.lse + row);
-      f32x4 nd, l2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { nd[e] = -dots[tq + e][hh]; l2[e] = ls[e] * LOG2E; }
-      *reinterpret_cast<f32x4*>(p.delta + row) = nd;
-      *reinterpret_cast<f32x4*>(p.delta + rows + row) = l2;
-      if (p.kv_pad_ones)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) annotate_q(p, b, hh, q + e, l2[e]);
-    } else {
-      for (int e = 0; e < 4 && q + e < p.Lq; ++e) {
-        const float l2 = p.lse[row + e] * LOG2E;
-        p.delta[row + e] = -dots[tq + e][hh];
-        p.delta[rows + row + e] = l2;
-        if (p.kv_pad_ones) annotate_q(p, b, hh, q + e, l2);
-      }
-    }
-  }
-}
-
 // ===================================== dQ ===================================================
 // ONES (k / v rows carry ones columns in their padding, vds_attn_args.kv_pad_ones; head_dim 72): the
 // kernel is bound by the VALU work between its MFMAs, so the per-query constants move into the MFMAs:
@@ -1519,15 +1452,6 @@ int attn_variant() {
   return g_attn_variant;
 }
 
-bool delta_tok64() {  // VDS_ATTN_DELTA64=0: the one-token-per-wave preprocess (A/B)
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("VDS_ATTN_DELTA64");
-    on = e ? atoi(e) : 1;
-  }
-  return on != 0;
-}
-
 template <typename K>
 void set_lds(K kern, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1603,10 +1527,7 @@ int run_bwd(AttnP p, hipStream_t s) {
     vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DELTA, s, 2.0 * rows * p.hd, 2.0 * qb);
     const bool tokmajor = p.o_sh == p.hd && p.do_sh == p.hd && p.o_sl == (long)p.H * p.hd && p.do_sl == p.o_sl &&
                           (p.o_sl & 7) == 0 && (p.o_sb & 7) == 0 && (p.do_sb & 7) == 0 && p.H * p.hd <= 1536 && p.H <= 64;
-    if (tokmajor && p.H <= 16 && delta_tok64()) {
-      const int bps = cdiv(p.Lq, 64);
-      hipLaunchKernelGGL(attn_delta_tok64_kernel, dim3((unsigned)(p.B * bps)), dim3(256), 0, s, p, bps);
-    } else if (tokmajor)
+    if (tokmajor)
       hipLaunchKernelGGL(attn_delta_tokmajor_kernel, dim3((unsigned)(((long)p.B * p.Lq + 3) / 4)), dim3(256), 0, s, p);
     else
       hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
