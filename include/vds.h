@@ -228,6 +228,16 @@ int vds_small_linear_fwd(const float* x, const void* W, const void* bias, float*
 int vds_small_linear_bwd(const float* dy, const float* x, const void* W, float* dW, float* dbias,
                          float* dx, int32_t M, int32_t N, int32_t K, int32_t act_in,
                          vds_stream_t stream);
+/* The same for nb weight sets sharing ONE input x (M <= 16 rows): the adaLN modulation linears of every DiT block
+ * (model.py:89-94,107) in one launch instead of one per block.  W_ptrs / bias_ptrs / dW_ptrs / dbias_ptrs: device
+ * arrays of nb device pointers (bias_ptrs / dbias_ptrs may be NULL); set i writes y + i * y_stride ([M,N] f32) and
+ * reads its output gradient at dy + i * dy_stride; dx (shared, f32 [M,K]) accumulates over all sets. */
+int vds_small_linear_fwd_batched(const float* x, const void* const* W_ptrs, const void* const* bias_ptrs, float* y,
+                                 int64_t y_stride, int32_t nb, int32_t M, int32_t N, int32_t K, int32_t act_in,
+                                 vds_stream_t stream);
+int vds_small_linear_bwd_batched(const float* dy, int64_t dy_stride, const float* x, const void* const* W_ptrs,
+                                 float* const* dW_ptrs, float* const* dbias_ptrs, float* dx, int32_t nb, int32_t M,
+                                 int32_t N, int32_t K, int32_t act_in, vds_stream_t stream);
 /* sinusoid [cos | sin](t * f_i), t unscaled (model.py:12-22), rounded through bf16 like
  * the reference's .to(x.dtype): out f32 [B, D]. */
 int vds_timestep_embedding(const float* t, float* out, int32_t B, int32_t D, vds_stream_t stream);

@@ -571,3 +571,26 @@ def test_attention_ones_columns_mfma_shape_variants(ops, variant, Lq, Lk):
     close("v.dk", dk[..., :hd], dk_ref, 1e-2)
     close("v.dq", dq[..., :hd], dq_ref, 1e-2)
     assert dq[..., hd + 2:].abs().max().item() == 0 and dk[..., hd:].abs().max().item() == 0
+
+
+def test_small_linear_batched_equals_per_set(ops):
+    """the adaLN linears of all blocks in one launch (vds_small_linear_*_batched, device pointer tables) give the same
+    outputs, weight / bias gradients and accumulated input gradient as one launch per block"""
+    nb, M, N, K = 5, 6, 9 * 48, 48
+    x = gen(M, K, seed=120, dtype=f32).cuda()
+    Ws = [gen(N, K, seed=121 + i, scale=0.1).cuda() for i in range(nb)]
+    bs = [gen(N, seed=131 + i, scale=0.1).cuda() for i in range(nb)]
+    y = ops.small_linear_fwd_batched(x, ops.ptr_table(Ws), ops.ptr_table(bs), nb, N, 1)
+    for i in range(nb):
+        assert torch.equal(y[i], ops.small_linear_fwd(x, Ws[i], bs[i], 1))
+    dy = gen(nb, M, N, seed=140, dtype=f32).cuda()
+    dWs = [torch.zeros(N, K, dtype=f32, device="cuda") for _ in range(nb)]
+    dbs = [torch.zeros(N, dtype=f32, device="cuda") for _ in range(nb)]
+    dx = torch.zeros(M, K, dtype=f32, device="cuda")
+    ops.small_linear_bwd_batched(dy, x, ops.ptr_table(Ws), ops.ptr_table(dWs), ops.ptr_table(dbs), dx, 1)
+    dx_ref = torch.zeros(M, K, dtype=f32, device="cuda")
+    for i in range(nb):
+        dW, db = torch.zeros(N, K, dtype=f32, device="cuda"), torch.zeros(N, dtype=f32, device="cuda")
+        ops.small_linear_bwd(dy[i].contiguous(), x, Ws[i], dW, db, dx_ref, 1)
+        assert torch.equal(dWs[i], dW) and torch.equal(dbs[i], db)
+    close("batched.dx", dx, dx_ref, 1e-5)

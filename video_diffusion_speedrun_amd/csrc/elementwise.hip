@@ -596,9 +596,24 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
 // y[b,n] = sum_k act(x[b,k]) W[n,k] + bias[n]; one wave per 4 output columns (the x chunk a lane loads is
 // reused for 4 rows of W), M <= 16 rows.
 // (time_embed model.py:318-322, adaLN_modulation model.py:89-91, final_modulation 339-341)
+// Batched form (blockIdx.z = index into device pointer tables): the same linear layer of nb weight sets applied to
+// ONE shared input x -- the adaLN modulation of every DiT block (model.py:89-94,107) in a single launch.
+struct SLBatch {
+  const void* const* W;       // [nb] bf16 [N,K]; null = not batched
+  const void* const* bias;    // [nb] bf16 [N] or null
+  float* const* dW;           // [nb] f32 [N,K]
+  float* const* dbias;        // [nb] f32 [N]
+  long y_stride;              // elements between the [M,N] outputs / output gradients of consecutive sets
+};
+
 template <int MB>
 __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* x, const bf16_t* W, const bf16_t* bias,
-                                                               float* y, int M, int N, int K, int act_in) {
+                                                               float* y, int M, int N, int K, int act_in, SLBatch bt) {
+  if (bt.W) {
+    W = (const bf16_t*)bt.W[blockIdx.z];
+    bias = bt.bias ? (const bf16_t*)bt.bias[blockIdx.z] : nullptr;
+    y += (long)blockIdx.z * bt.y_stride;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 4 + wave) * 4;
   if (n0 >= N) return;
@@ -641,7 +656,12 @@ __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* x, c
 // dW[n,k] = sum_b dy[b,n] act(x[b,k]);  dbias[n] = sum_b dy[b,n]   (thread per (4 rows n, k-chunk): the
 // activated x chunk is built once and reused for the 4 rows)
 __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* dy, const float* x, float* dW,
-                                                              float* dbias, int M, int N, int K, int act_in) {
+                                                              float* dbias, int M, int N, int K, int act_in, SLBatch bt) {
+  if (bt.dW) {
+    dW = bt.dW[blockIdx.z];
+    dbias = bt.dbias ? bt.dbias[blockIdx.z] : nullptr;
+    dy += (long)blockIdx.z * bt.y_stride;
+  }
   const int kc = K >> 3;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long)((N + 3) / 4) * kc) return;
@@ -685,8 +705,12 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* dy, c
 template <int MB>
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* dy, const float* x, const bf16_t* W,
                                                               float* dx, int M, int N, int K, int act_in,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, SLBatch bt) {
   __shared__ float red[4][8][MB][8];
+  if (bt.W) {
+    W = (const bf16_t*)bt.W[blockIdx.z];
+    dy += (long)blockIdx.z * bt.y_stride;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = tid & 7, r = tid >> 3;
   const int kc = K >> 3, cg = blockIdx.x * 8 + c;
@@ -1100,13 +1124,13 @@ extern "C" int vds_small_linear_fwd(const float* x, const void* W, const void* b
     float* ys = y + (long)r0 * N;
     if (m <= 4)
       hipLaunchKernelGGL(small_linear_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, xs, (const bf16_t*)W,
-                         (const bf16_t*)bias, ys, m, N, K, act_in);
+                         (const bf16_t*)bias, ys, m, N, K, act_in, SLBatch{});
     else if (m <= 8)
       hipLaunchKernelGGL(small_linear_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, xs, (const bf16_t*)W,
-                         (const bf16_t*)bias, ys, m, N, K, act_in);
+                         (const bf16_t*)bias, ys, m, N, K, act_in, SLBatch{});
     else
       hipLaunchKernelGGL(small_linear_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, xs, (const bf16_t*)W,
-                         (const bf16_t*)bias, ys, m, N, K, act_in);
+                         (const bf16_t*)bias, ys, m, N, K, act_in, SLBatch{});
   }
   return ok();
 }
@@ -1116,7 +1140,7 @@ extern "C" int vds_small_linear_bwd(const float* dy, const float* x, const void*
   hipStream_t s = (hipStream_t)stream;
   if (dW) {
     const long n = (long)((N + 3) / 4) * (K >> 3);
-    hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, x, dW, dbias, M, N, K, act_in);
+    hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, x, dW, dbias, M, N, K, act_in, SLBatch{});
   }
   if (dx) {
     if (!W) return VDS_ERR_ARG;
@@ -1131,12 +1155,52 @@ extern "C" int vds_small_linear_bwd(const float* dy, const float* x, const void*
       const float* xs = x + (long)r0 * K;
       float* dxs = dx + (long)r0 * K;
       if (m <= 4)
-        hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows);
+        hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows, SLBatch{});
       else if (m <= 8)
-        hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows);
+        hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows, SLBatch{});
       else
-        hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows);
+        hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows, SLBatch{});
     }
+  }
+  return ok();
+}
+
+// the batched forms: nb weight sets (device pointer tables) applied to one shared input of M <= 16 rows
+extern "C" int vds_small_linear_fwd_batched(const float* x, const void* const* W_ptrs, const void* const* bias_ptrs,
+                                            float* y, int64_t y_stride, int32_t nb, int32_t M, int32_t N, int32_t K,
+                                            int32_t act_in, vds_stream_t stream) {
+  if (!x || !W_ptrs || !y || nb < 1 || M < 1 || M > 16 || (K & 7)) return VDS_ERR_ARG;
+  const dim3 grid((N + 15) / 16, 1, nb);
+  const SLBatch bt{W_ptrs, bias_ptrs, nullptr, nullptr, (long)y_stride};
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 4) hipLaunchKernelGGL(small_linear_fwd_kernel<4>, grid, dim3(256), 0, s, x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, y, M, N, K, act_in, bt);
+  else if (M <= 8) hipLaunchKernelGGL(small_linear_fwd_kernel<8>, grid, dim3(256), 0, s, x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, y, M, N, K, act_in, bt);
+  else hipLaunchKernelGGL(small_linear_fwd_kernel<16>, grid, dim3(256), 0, s, x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, y, M, N, K, act_in, bt);
+  return ok();
+}
+
+extern "C" int vds_small_linear_bwd_batched(const float* dy, int64_t dy_stride, const float* x, const void* const* W_ptrs,
+                                            float* const* dW_ptrs, float* const* dbias_ptrs, float* dx, int32_t nb,
+                                            int32_t M, int32_t N, int32_t K, int32_t act_in, vds_stream_t stream) {
+  if (!dy || !x || nb < 1 || M < 1 || M > 16 || (K & 7)) return VDS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dW_ptrs) {
+    const long n = (long)((N + 3) / 4) * (K >> 3);
+    const SLBatch bt{nullptr, nullptr, dW_ptrs, dbias_ptrs, (long)dy_stride};
+    hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((n + 255) / 256), 1, nb), dim3(256), 0, s, dy, x,
+                       (float*)nullptr, (float*)nullptr, M, N, K, act_in, bt);
+  }
+  if (dx) {
+    if (!W_ptrs) return VDS_ERR_ARG;
+    const int gx = ((K >> 3) + 7) / 8;
+    int ny = max(1, min((N + 31) / 32, (512 + gx - 1) / gx));
+    const int rows = ((N + ny - 1) / ny + 31) / 32 * 32;
+    ny = (N + rows - 1) / rows;
+    const dim3 grid(gx, ny, nb);
+    const SLBatch bt{W_ptrs, nullptr, nullptr, nullptr, (long)dy_stride};
+    if (M <= 4) hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)nullptr, dx, M, N, K, act_in, rows, bt);
+    else if (M <= 8) hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)nullptr, dx, M, N, K, act_in, rows, bt);
+    else hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)nullptr, dx, M, N, K, act_in, rows, bt);
   }
   return ok();
 }

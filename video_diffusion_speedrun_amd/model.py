@@ -309,7 +309,7 @@ class DiTBlock(nn.Module):
                                     rope[1] if rope is not None else None, *params)
 
     # ---- the kernel sequence of one block (used by DiT's whole-model autograd node and by `forward`) ----
-    def _fwd(self, G, pre, X, ctx2d, cvec, v0, cos, sin, B, L, Lc, save, fp8=None):
+    def _fwd(self, G, pre, X, ctx2d, cvec, v0, cos, sin, B, L, Lc, save, fp8=None, mod=None):
         """X [B*L, D] bf16 token buffer -> (X_out, v [B,H,L,hdp], saved).  G: the FlatGroup holding this block's
         parameters under the name prefix `pre`; cvec f32 [B, D]; v0: block 0's v in the padded head-major layout
         or None; cos / sin f32 [L, hd/2]; fp8 = (AmaxHistory | None, block index) when the fp8 linears are on."""
@@ -320,7 +320,8 @@ class DiTBlock(nn.Module):
         W = lambda n: G.w(pre + n)
         Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
         dev = X.device
-        mod = ops.small_linear_fwd(cvec, W("adaLN_modulation.1.weight"), W("adaLN_modulation.1.bias"), 1)
+        if mod is None:  # (DiT.forward computes the modulation of all blocks in one batched launch and passes it in)
+            mod = ops.small_linear_fwd(cvec, W("adaLN_modulation.1.weight"), W("adaLN_modulation.1.bias"), 1)
         # --- self attention (model.py:122-139)
         xn1, rstd1 = ops.rmsnorm_mod_fwd(X, Wo("norm1.weight"), mod, 0, D, B, L)
         f8 = use_fp8 and F8.supported(B * L, 3 * D, D)
@@ -387,7 +388,7 @@ class DiTBlock(nn.Module):
         return X3, v, bs
 
 
-    def _bwd(self, G, pre, bs, dX, sv, dc, dv0, B, L, Lc, first, fp8=None):
+    def _bwd(self, G, pre, bs, dX, sv, dc, dv0, B, L, Lc, first, fp8=None, dmod=None):
         """backward of `_fwd`: dX [B*L, D] bf16 -> d(input tokens); parameter gradients go to G's fp32 gradient
         buffer; dc (f32 [B, D]) and dv0 (f32 [B,H,L,hdp]) accumulate the conditioning / residual-V gradients.
         sv carries cos, sin, v0, ctx2d, cvec.  first: this is the block whose v was handed out as v_0."""
@@ -400,7 +401,9 @@ class DiTBlock(nn.Module):
         Go = lambda n: G.g(pre + n) if G.has(pre + n) else None
         dev = dX.device
         mod = bs.mod
-        dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
+        batched_adaln = dmod is not None  # DiT.backward: the adaLN weight gradients of all blocks in one launch at the end
+        if dmod is None:
+            dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
         # --- MLP
         dy = ops.gate_bwd(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L)
         if bs.f8:
@@ -478,8 +481,9 @@ class DiTBlock(nn.Module):
         dX0 = ops.rmsnorm_mod_bwd(dxn, bs.X, Wo("norm1.weight"), mod, 0, D, bs.rstd1, dX1, dmod, Go("norm1.weight"),
                                   B, L)
         # --- adaLN modulation (model.py:89-94,107)
-        ops.small_linear_bwd(dmod, sv.cvec, W("adaLN_modulation.1.weight"), Gr("adaLN_modulation.1.weight"),
-                             Gr("adaLN_modulation.1.bias"), dc, 1)
+        if not batched_adaln:
+            ops.small_linear_bwd(dmod, sv.cvec, W("adaLN_modulation.1.weight"), Gr("adaLN_modulation.1.weight"),
+                                 Gr("adaLN_modulation.1.bias"), dc, 1)
         return dX0
 
 
@@ -564,6 +568,19 @@ class DiT(nn.Module):
             self._groups = None
         return r
 
+    def _adaln_tables(self):
+        """device pointer tables (weights, biases, weight gradients, bias gradients) of the blocks' adaLN linears for
+        the batched launches; rebuilt when the flat buffers move"""
+        key = tuple(g.full.data_ptr() for g in self._groups[1:]) + tuple(g.gfull.data_ptr() for g in self._groups[1:])
+        if getattr(self, "_adaln_key", None) != key:
+            W = [self.block_group(i).w(f"blocks.{i}.adaLN_modulation.1.weight") for i in range(self.depth)]
+            b = [self.block_group(i).w(f"blocks.{i}.adaLN_modulation.1.bias") for i in range(self.depth)]
+            gW = [self.block_group(i).g(f"blocks.{i}.adaLN_modulation.1.weight") for i in range(self.depth)]
+            gb = [self.block_group(i).g(f"blocks.{i}.adaLN_modulation.1.bias") for i in range(self.depth)]
+            self._adaln_tabs = tuple(ops.ptr_table(t) for t in (W, b, gW, gb))
+            self._adaln_key = key
+        return self._adaln_tabs
+
     @property
     def root_group(self) -> FlatGroup:
         return self._groups[0]
@@ -644,12 +661,19 @@ class DiT(nn.Module):
             sv.ctx2d = ctx2d
             sv.blocks = []
 
+        # adaLN modulation of every block in ONE launch (K4 of SURVEY 2.3): all blocks read the same conditioning vector.
+        # Not under sharding -- it would need every group's gathered weights before block 0 -- nor beyond 16 samples.
+        mods = None
+        if fs is None and B <= 16 and self.depth > 1:
+            wt, bt, _, _ = self._adaln_tables()
+            mods = ops.small_linear_fwd_batched(cvec, wt, bt, self.depth, 9 * D, 1)
         v0 = None
         for i in range(self.depth):
             if fs is not None:
                 fs.pre_forward_block(i)
             X, v, bs = self.blocks[i]._fwd(self.block_group(i), f"blocks.{i}.", X, ctx2d, cvec, v0, cos, sin, B, L, Lc,
-                                           save, (self._fp8_hist, i) if self.fp8 else None)
+                                           save, (self._fp8_hist, i) if self.fp8 else None,
+                                           mods[i] if mods is not None else None)
             if v0 is None:
                 v0 = v
             if save:
@@ -659,6 +683,7 @@ class DiT(nn.Module):
         if save:
             sv.v0 = v0
             sv.x_last = X
+            sv.batched_adaln = mods is not None
 
         # final layer (model.py:386-401)
         fmod = ops.small_linear_fwd(cvec, R.w("final_modulation.1.weight"), R.w("final_modulation.1.bias"), 1)
@@ -714,14 +739,19 @@ class DiT(nn.Module):
                              R.g("final_modulation.1.bias"), dc, 1)
         hdp = {64: 64, 72: 96, 128: 128}[hd]
         dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev) if (self.residual_v and self.depth > 1) else None
+        dmods = torch.zeros(self.depth, B, 9 * D, dtype=f32, device=dev) if sv.batched_adaln else None
         for i in reversed(range(self.depth)):
             if fs is not None:
                 fs.pre_backward_block(i)
             dX = self.blocks[i]._bwd(self.block_group(i), f"blocks.{i}.", sv.blocks[i], dX, sv, dc, dv0, B, L, Lc,
-                                     i == 0, (self._fp8_hist, i) if self.fp8 else None)
+                                     i == 0, (self._fp8_hist, i) if self.fp8 else None,
+                                     dmods[i] if dmods is not None else None)
             sv.blocks[i] = None
             if fs is not None:
                 fs.post_backward_block(i)
+        if dmods is not None:  # adaLN weight / bias gradients of all blocks and their fan-in to dc: one launch each
+            wt, _, gwt, gbt = self._adaln_tables()
+            ops.small_linear_bwd_batched(dmods, sv.cvec, wt, gwt, gbt, dc, 1)
         # registers + patch embed (model.py:360-362)
         ops.registers_bwd(dX, L * D, R.g("register_tokens").view(N_REG, D), B, N_REG, D)
         # patch embedding: weight gradient over all B*L rows (the register rows of `patches` are zero), bias gradient

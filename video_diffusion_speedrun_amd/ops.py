@@ -332,6 +332,30 @@ def small_linear_bwd(dy, x, W, dW, dbias, dx, act_in: int):
                                            _stream()), "vds_small_linear_bwd")
 
 
+def ptr_table(tensors) -> torch.Tensor:
+    """device array of the tensors' device pointers (int64), for the batched entry points"""
+    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=tensors[0].device)
+
+
+def small_linear_fwd_batched(x, W_tab, bias_tab, nb: int, N: int, act_in: int):
+    """y[i] = act(x) W_i^T + b_i for the nb weight sets of the pointer tables; x f32 [M <= 16, K] -> f32 [nb, M, N]"""
+    M, K = x.shape
+    assert x.dtype == f32 and x.is_contiguous() and M <= 16
+    y = torch.empty(nb, M, N, dtype=f32, device=x.device)
+    check(_lib.load().vds_small_linear_fwd_batched(_p(x), _p(W_tab), _p(bias_tab), _p(y), M * N, nb, M, N, K, act_in,
+                                                   _stream()), "vds_small_linear_fwd_batched")
+    return y
+
+
+def small_linear_bwd_batched(dy, x, W_tab, dW_tab, dbias_tab, dx, act_in: int):
+    """dy f32 [nb, M, N]; writes every dW_i / dbias_i, accumulates dx (f32 [M, K]) over the sets"""
+    nb, M, N = dy.shape
+    K = x.shape[1]
+    assert dy.is_contiguous() and x.is_contiguous() and M <= 16
+    check(_lib.load().vds_small_linear_bwd_batched(_p(dy), M * N, _p(x), _p(W_tab), _p(dW_tab), _p(dbias_tab), _p(dx),
+                                                   nb, M, N, K, act_in, _stream()), "vds_small_linear_bwd_batched")
+
+
 def timestep_embedding(t, D):
     B = t.shape[0]
     out = torch.empty(B, D, dtype=f32, device=t.device)
