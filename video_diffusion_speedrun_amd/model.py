@@ -664,7 +664,7 @@ class DiT(nn.Module):
         # adaLN modulation of every block in ONE launch (K4 of SURVEY 2.3): all blocks read the same conditioning vector.
         # Not under sharding -- it would need every group's gathered weights before block 0 -- nor beyond 16 samples.
         mods = None
-        if fs is None and B <= 16 and self.depth > 1:
+        if fs is None and B <= 16 and self.depth > 1 and os.environ.get("VDS_ADALN_BATCH", "1") != "0":
             wt, bt, _, _ = self._adaln_tables()
             mods = ops.small_linear_fwd_batched(cvec, wt, bt, self.depth, 9 * D, 1)
         v0 = None
