@@ -67,6 +67,9 @@ typedef struct vds_gemm_args {
   int32_t split_k;             /* TN + F32 only: 0 = the library picks tiling and K split (atomics iff it splits; C
                                   pre-zeroed), -1 = the same but always accumulating atomically into C, 1 = no
                                   split, > 1 = that many splits + atomics, <= -2 = |split_k| splits, accumulate */
+  float* colsum;               /* VDS_EPI_DGELU only, may be NULL: colsum[n] += sum_m C[m,n] (f32, atomically; the bias
+                                  gradient of the layer below, model.py:84) -- fused into the epilogue of the 256^2
+                                  kernel, a pass over C after the GEMM for the smaller tilings.  Needs C != NULL. */
 } vds_gemm_args;
 
 int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);

@@ -41,7 +41,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_struct_layouts_match_header():
     # vds_gemm_args / vds_attn_args / vds_adamw_tensor: field counts and sizes as declared
     assert C.sizeof(_lib.AdamWTensor) == 5 * 8 + 8 + 4 + 4
-    assert C.sizeof(_lib.GemmArgs) == 5 * 4 + 4 + 8 * 13 + 4 + 4  # 5 int32 + pad, 13 pointer/int64, 2 int32
+    assert C.sizeof(_lib.GemmArgs) == 5 * 4 + 4 + 8 * 13 + 4 + 4 + 8  # 5 int32 + pad, 13 pointer/int64, 2 int32, colsum
+    assert _lib.GemmArgs.colsum.offset == 136 and _lib.GemmArgs.split_k.offset == 132
     assert C.sizeof(_lib.AttnArgs) == 5 * 4 + 4 + 8 * (4 * 4 + 1 + 4 * 4 + 1) + 8  # + kv_pad_ones (padded)
     assert C.sizeof(_lib.ProfStat) == 32
     assert C.sizeof(_lib.Fp8Out) == 7 * 8 + 4 + 4 + 8  # 7 pointer/int64, fmt + pad, colsum

@@ -594,3 +594,17 @@ def test_small_linear_batched_equals_per_set(ops):
         ops.small_linear_bwd(dy[i].contiguous(), x, Ws[i], dW, db, dx_ref, 1)
         assert torch.equal(dWs[i], dW) and torch.equal(dbs[i], db)
     close("batched.dx", dx, dx_ref, 1e-5)
+
+
+def test_gemm_nn_dgelu_with_fused_bias_gradient(ops, tile):
+    """dx = (dy W) * gelu'(pre) with colsum[k] += sum_m dx[m,k] from the same call (the fc1 bias gradient,
+    model.py:84): fused in the 256^2 kernel's epilogue, a follow-up pass for the other tilings; M ragged, N ragged
+    in the last column tile"""
+    M, N, K = 4112, 384, 1096
+    dy, w, pre = gen(M, N, seed=14), gen(N, K, seed=15, scale=0.05), gen(M, K, seed=16)
+    cs = torch.full((K,), 0.5, dtype=f32, device="cuda")          # accumulates on top of what is there
+    dx = ops.linear_dgrad(dy.cuda(), w.cuda(), pre.cuda(), colsum=cs)
+    p = pre.float().requires_grad_(True)
+    O.gelu_erf(p).backward(dy.float() @ w.float())
+    close("dgelu+colsum.dx", dx, p.grad, 5e-3)
+    close("dgelu+colsum.cs", cs - 0.5, dx.float().sum(0), 2e-3)   # sums of the bf16-rounded result

@@ -21,7 +21,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("layout", c_i32), ("epilogue", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("C", c_vp), ("ldc", c_i64),
                 ("C2", c_vp), ("ldc2", c_i64), ("bias", c_vp), ("aux", c_vp), ("ldaux", c_i64),
-                ("gate", c_vp), ("ldgate", c_i64), ("rows_per_batch", c_i32), ("split_k", c_i32)]
+                ("gate", c_vp), ("ldgate", c_i64), ("rows_per_batch", c_i32), ("split_k", c_i32), ("colsum", c_vp)]
 
 
 class AttnArgs(C.Structure):

@@ -604,7 +604,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
   float dq = 1.0f;
   if constexpr (FMT != 0) dq = (p.sa ? *p.sa : 1.0f) * (p.sb ? *p.sb : 1.0f);
-  constexpr bool EMIT = FMT != 0 && (EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU);
+  // EMIT also serves the bf16 DGELU GEMM: no fp8 copies there (e_q / e_qt are null), only the column sums of its
+  // result -- the fc1 bias gradient -- folded into the epilogue instead of a separate pass over the [tokens, 4D] tensor
+  constexpr bool EMIT = (FMT != 0 && (EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU)) || (FMT == 0 && EPI == VDS_EPI_DGELU);
   float cs[8];  // EMIT: per-lane partial column sums of the emitted result over both quadrant rows
   u32x2 ew[2][8];  // EMIT: the fp8 bytes of both quadrant rows (for the transposed copy)
 #pragma unroll
@@ -951,6 +953,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   p.prof_k = a->K;
   p.e_q = p.e_qt = nullptr; p.e_ldq = p.e_ldqt = 0;
   p.e_amax_in = nullptr; p.e_amax_out = p.e_dq_out = p.e_colsum = nullptr; p.e_fmt = 0;
+  if (a->colsum && !(a->epilogue == VDS_EPI_DGELU && a->C)) return VDS_ERR_ARG;
   p.tiles_m = cdiv(a->M, BM);
   p.tiles_n = cdiv(a->N, BN);
   size_t abytes, bbytes;
@@ -1056,7 +1059,14 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     bool use_mid = a->K >= 128 && cost_mid < (use_big ? cost_big : cost_small) && a->layout != VDS_TN;
     (void)rounds_mid;
     if (force_tile == 2) use_mid = true;
+    if (a->colsum && a->layout != VDS_NN) use_mid = false;
     if (force_tile == 128 || force_tile == 256) use_mid = false;
+    if (use_mid && a->colsum) {  // no fused column sums in this tiling either
+      p.tiles_m = tmm;
+      p.tiles_n = tnm;
+      const int rc = mid::launch<VDS_NN, VDS_EPI_DGELU>(p, s);
+      return rc != VDS_OK ? rc : vds_colsum_bf16(a->C, a->ldc, a->colsum, a->M, a->N, stream);
+    }
     if (use_mid) {
       p.tiles_m = tmm;
       p.tiles_n = tnm;
@@ -1073,6 +1083,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   if (use_big) {
     p.tiles_m = tm;
     p.tiles_n = tn;
+    p.e_colsum = a->colsum;  // DGELU only (checked above): column sums of the result in the epilogue
 #define GOB(L, E) if (a->layout == L && a->epilogue == E) return big::launch<L, E>(p, s);
     GOB(VDS_NT, VDS_EPI_STORE)
     GOB(VDS_NT, VDS_EPI_BIAS_GELU)
@@ -1081,6 +1092,12 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     GOB(VDS_NN, VDS_EPI_DGELU)
     GOB(VDS_TN, VDS_EPI_F32)
 #undef GOB
+  }
+  p.tiles_m = cdiv(a->M, BM);
+  p.tiles_n = cdiv(a->N, BN);
+  if (a->colsum) {  // the smaller tilings have no fused column sums: a pass over the result follows the GEMM
+    const int rc = launch<VDS_NN, VDS_EPI_DGELU>(p, s);
+    return rc != VDS_OK ? rc : vds_colsum_bf16(a->C, a->ldc, a->colsum, a->M, a->N, stream);
   }
 #define GO(L, E) if (a->layout == L && a->epilogue == E) return launch<L, E>(p, s);
   GO(VDS_NT, VDS_EPI_STORE)

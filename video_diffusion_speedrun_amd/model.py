@@ -423,9 +423,8 @@ class DiTBlock(nn.Module):
             del q_dy, q_dh
         else:
             ops.linear_wgrad(dy, bs.hact, Gr("mlp.2.weight"))
-            dh = ops.linear_dgrad(dy, W("mlp.2.weight"), pre=bs.hpre)
+            dh = ops.linear_dgrad(dy, W("mlp.2.weight"), pre=bs.hpre, colsum=Gr("mlp.0.bias"))  # + fc1 bias gradient
             ops.linear_wgrad(dh, bs.xn3, Gr("mlp.0.weight"))
-            ops.colsum(dh, Gr("mlp.0.bias"))
             dxn = ops.linear_dgrad(dh, W("mlp.0.weight"))
         del dh
         dX2 = ops.rmsnorm_mod_bwd(dxn, bs.X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, bs.rstd3, dX, dmod,

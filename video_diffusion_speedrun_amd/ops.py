@@ -38,9 +38,9 @@ def _rows(t: torch.Tensor) -> Tuple[int, int]:
 
 # ------------------------------------------------------------------------------- GEMM ----
 def gemm(layout: int, epi: int, M: int, N: int, K: int, A, lda, B, ldb, Cp=None, ldc=0, C2=None, ldc2=0,
-         bias=None, aux=None, ldaux=0, gate=None, ldgate=0, rows_per_batch=0, split_k=1):
+         bias=None, aux=None, ldaux=0, gate=None, ldgate=0, rows_per_batch=0, split_k=1, colsum=None):
     a = GemmArgs(layout, epi, M, N, K, _p(A), lda, _p(B), ldb, _p(Cp), ldc, _p(C2), ldc2, _p(bias), _p(aux),
-                 ldaux, _p(gate), ldgate, rows_per_batch, split_k)
+                 ldaux, _p(gate), ldgate, rows_per_batch, split_k, _p(colsum))
     check(_lib.load().vds_gemm_bf16(C.byref(a), _stream()), f"vds_gemm_bf16(layout={layout},epi={epi},M={M},N={N},K={K})")
 
 
@@ -85,15 +85,18 @@ def linear_fwd_gate_res(x, W, bias, mod, gate_col: int, res, rows_per_batch: int
     return y, xn
 
 
-def linear_dgrad(dy, W, pre: Optional[torch.Tensor] = None):
-    """dx = dy W  (dy [M,N], W [N,K] -> [M,K]); with `pre`: dx *= gelu'(pre) (fused)."""
+def linear_dgrad(dy, W, pre: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None):
+    """dx = dy W  (dy [M,N], W [N,K] -> [M,K]); with `pre`: dx *= gelu'(pre) (fused), and then optionally
+    colsum[k] += sum_m dx[m,k] (f32; the bias gradient of the layer whose pre-activation `pre` is)."""
     M, N = dy.shape
     K = W.shape[1]
     dx = torch.empty(M, K, dtype=bf16, device=dy.device)
     if pre is None:
+        assert colsum is None
         gemm(VDS_NN, EPI_STORE, M, K, N, dy, dy.stride(0), W, W.stride(0), dx, K)
     else:
-        gemm(VDS_NN, EPI_DGELU, M, K, N, dy, dy.stride(0), W, W.stride(0), dx, K, aux=pre, ldaux=pre.stride(0))
+        gemm(VDS_NN, EPI_DGELU, M, K, N, dy, dy.stride(0), W, W.stride(0), dx, K, aux=pre, ldaux=pre.stride(0),
+             colsum=colsum)
     return dx
 
 
@@ -132,7 +135,7 @@ def gemm_fp8(epi: int, M: int, N: int, K: int, A, B, sa, sb, a_fmt: int, Cp=None
     emit = dict(q=, qt=, amax_in=, amax_out=, dq_out=, fmt=, colsum=): fp8 copies of the epilogue result (vds_fp8_out)."""
     assert A.is_contiguous() and B.is_contiguous() and A.shape == (M, K) and B.shape == (N, K)
     a = GemmArgs(VDS_NT, epi, M, N, K, _p(A), K, _p(B), K, _p(Cp), ldc, _p(C2), ldc2, _p(bias), _p(aux), ldaux,
-                 _p(gate), ldgate, rows_per_batch, split_k)
+                 _p(gate), ldgate, rows_per_batch, split_k, None)
     e = None
     if emit is not None:
         q, qt = emit.get("q"), emit.get("qt")
