@@ -7,7 +7,9 @@ MI355X-first re-design of the same contract:
   * one flat buffer per shard group (params.FlatGroup) => ONE RCCL all-gather (bf16) and ONE
     reduce-scatter (fp32, avg) per group per step: 29 + 29 large contiguous collectives for
     DiT-XL instead of per-parameter copy-in/copy-out.  xGMI is point-to-point; few, large
-    messages are what it wants;
+    messages are what it wants.  The collectives are the kernel library's own (`vds_all_gather_bf16`,
+    `vds_reduce_scatter_f32_avg`: csrc/comm.hip drives RCCL on a communicator created from a unique id that
+    torch.distributed ships once at start-up; comm.py);
   * 288 GB of HBM per GPU: the gathered bf16 copy of EVERY group (2.3 GB for DiT-XL) stays
     resident from forward to backward, so the reference's backward re-all-gather
     (`reshard_after_forward`, model.py:525) is not needed at all -- all-gather traffic is halved;
