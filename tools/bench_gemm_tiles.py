@@ -8,7 +8,7 @@ from video_diffusion_speedrun_amd import ops
 
 bf16, f32 = torch.bfloat16, torch.float32
 dev = "cuda"
-B, L, D = int(os.environ.get("B", 12)), 8208, 1152
+B, L, D = int(os.environ.get("B", 12)), int(os.environ.get("L", 8208)), int(os.environ.get("D", 1152))
 ROUNDS, INNER = int(os.environ.get("ROUNDS", 9)), int(os.environ.get("INNER", 5))
 
 
