@@ -147,9 +147,26 @@ __device__ __forceinline__ unsigned cvt4_fp8(int fmt, float a, float b, float c,
 // recorded, and (DGELU) its column sums are accumulated -- the consumers' quantisation and bias-gradient passes
 // disappear.  The fp8 bytes of the tile are also returned in `ew` (row it*8 + lane/8, columns 8*(lane%8)..+7) for
 // the caller's transposed copy.
+// The aux operand of a fused epilogue (GATE_RES: the residual stream, DGELU: the saved pre-activation) is requested
+// for all 8 row groups of the sub-tile BEFORE the accumulators are staged through LDS, so that the 8 loads are in
+// flight together and under the staging instead of one exposed HBM round trip per row group behind the stores.
+template <int EPI>
+__device__ __forceinline__ void epilogue_prefetch(const GemmP& p, int row0, int col0, int lane, u32x4 (&auxr)[8]) {
+  if constexpr (EPI == VDS_EPI_GATE_RES || EPI == VDS_EPI_DGELU) {
+    const int c8 = lane & 7, rin = lane >> 3;
+    const int gcol = col0 + c8 * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const long grow = row0 + it * 8 + rin;
+      auxr[it] = (grow < p.M && gcol < p.N) ? *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol)
+                                            : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+}
+
 template <int EPI, bool EMIT = false>
 __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int row0, int col0, int lane,
-                                               float (&cs)[8], u32x2 (&ew)[8]) {
+                                               float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8]) {
   if constexpr (EPI == VDS_EPI_F32) {
     if (p.atomic) {
       // split-K / accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256
@@ -223,7 +240,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp);
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(gp + 4);
       const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-      const u32x4 xr = *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol);
+      const u32x4 xr = auxr[it];
       u32x4 o, o2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -234,7 +251,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
       if (p.C) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
       *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + grow * p.ldc2 + gcol) = o2;
     } else if constexpr (EPI == VDS_EPI_DGELU) {
-      const u32x4 pr = *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol);
+      const u32x4 pr = auxr[it];
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -362,6 +379,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 
   // ---- epilogue: accumulators -> LDS (fp32) -> 16-byte row segments ----------------------
   float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
+  u32x4 auxr[8];
+  epilogue_prefetch<EPI>(p, m0 + wm * 64, n0 + wn * 64, lane, auxr);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -374,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 
   float cs_unused[8];
   u32x2 ew_unused[8];
-  epilogue_64x64<EPI>(p, stg, m0 + wm * 64, n0 + wn * 64, lane, cs_unused, ew_unused);
+  epilogue_64x64<EPI>(p, stg, m0 + wm * 64, n0 + wn * 64, lane, cs_unused, ew_unused, auxr);
 }
 
 // =====================================================================================
@@ -613,6 +632,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa) {
+    u32x4 auxr[8];
+    epilogue_prefetch<EPI>(p, m0 + wr * 128 + qa * 64, n0 + wc * 64, lane, auxr);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -623,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
               FMT != 0 ? acc[qa * 4 + i][j][r] * dq : acc[qa * 4 + i][j][r];
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_wave_barrier();
-    epilogue_64x64<EPI, EMIT>(p, stg, m0 + wr * 128 + qa * 64, n0 + wc * 64, lane, cs, ew[qa]);
+    epilogue_64x64<EPI, EMIT>(p, stg, m0 + wr * 128 + qa * 64, n0 + wc * 64, lane, cs, ew[qa], auxr);
     __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
   }
   if constexpr (EMIT) {
@@ -873,6 +894,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   u32x2 ew_unused[8];
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa) {
+    u32x4 auxr[8];
+    epilogue_prefetch<EPI>(p, m0 + wm * 128 + qa * 64, n0 + wn * 64, lane, auxr);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -882,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
           stg[(i * 16 + 4 * (lane >> 4) + r) * EPI_LD + j * 16 + (lane & 15)] = acc[qa * 4 + i][j][r];
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_wave_barrier();
-    epilogue_64x64<EPI>(p, stg, m0 + wm * 128 + qa * 64, n0 + wn * 64, lane, cs_unused, ew_unused);
+    epilogue_64x64<EPI>(p, stg, m0 + wm * 128 + qa * 64, n0 + wn * 64, lane, cs_unused, ew_unused, auxr);
     __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
   }
 }
