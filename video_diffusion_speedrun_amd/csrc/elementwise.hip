@@ -363,114 +363,6 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_kernel(const bf16_t* qkv, co
   }
 }
 
-// The same with 16-byte accesses: one thread = 8 elements d..d+7 of the first half of a head and their rotation
-// partners d + hd/2 .. (+ one 4-element thread per head for the remainder of an odd half such as 36).  The partner
-// chunk sits at an 8-byte-aligned address when hd/2 is not a multiple of 8; dwordx4 global accesses only need dword
-// alignment, so they are issued as they are (head_dim 72: 5 threads per head instead of 9, 16 B instead of 8 B per
-// access).  Threads g < (hdp - hd) / 8 also write one 16-byte pad chunk each.
-__global__ __launch_bounds__(256) void qkv_rope_fwd16_kernel(const bf16_t* qkv, const float* cosb, const float* sinb,
-                                                             const bf16_t* v0, const bf16_t* lamp, bf16_t* q,
-                                                             bf16_t* k, bf16_t* v, int B, int L, int H, int hd,
-                                                             int hdp) {
-  const int half = hd >> 1, nfull = half >> 3, rem = half & 7;  // rem is 0 or 4
-  const int ng = nfull + (rem ? 1 : 0);
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long)B * L * H * ng) return;
-  const int g = (int)(gid % ng);
-  const long th = gid / ng;
-  const int hh = (int)(th % H);
-  const long tok = th / H;
-  const int b = (int)(tok / L), l = (int)(tok % L);
-  const int D = H * hd;
-  const bf16_t* src = qkv + tok * 3 * D + hh * hd + 8 * g;
-  const long dst = (((long)b * H + hh) * L + l) * hdp + 8 * g;
-  const float* cp = cosb + (long)l * half + 8 * g;
-  const float* sp = sinb + (long)l * half + 8 * g;
-  float lam = 0.f, oml = 0.f;
-  if (v0) {
-    lam = bf2f(*lamp);
-    oml = bf2f(f2bf(1.0f - lam));
-  }
-  auto mixv = [&](unsigned vr, unsigned v0r) {  // reference (bf16 tensors): lam*v, (1-lam), (1-lam)*v0, sum all round
-    const float a0 = bf2f(f2bf(lam * bflo(vr))) + bf2f(f2bf(oml * bflo(v0r)));
-    const float a1 = bf2f(f2bf(lam * bfhi(vr))) + bf2f(f2bf(oml * bfhi(v0r)));
-    return pack_bf2(a0, a1);
-  };
-  if (g < nfull) {
-    float c8[8], s8[8];
-    load8f(cp, c8);
-    load8f(sp, s8);
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      float x1[8], x2[8], y1[8], y2[8];
-      unpack8(*reinterpret_cast<const u32x4*>(src + which * D), x1);
-      unpack8(*reinterpret_cast<const u32x4*>(src + which * D + half), x2);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        y1[e] = x1[e] * c8[e] + x2[e] * s8[e];
-        y2[e] = x2[e] * c8[e] - x1[e] * s8[e];
-      }
-      bf16_t* o = (which == 0 ? q : k) + dst;
-      *reinterpret_cast<u32x4*>(o) = pack8(y1);
-      *reinterpret_cast<u32x4*>(o + half) = pack8(y2);
-    }
-    u32x4 w1 = *reinterpret_cast<const u32x4*>(src + 2 * D);
-    u32x4 w2 = *reinterpret_cast<const u32x4*>(src + 2 * D + half);
-    if (v0) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(v0 + dst);
-      const u32x4 c = *reinterpret_cast<const u32x4*>(v0 + dst + half);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { w1[e] = mixv(w1[e], a[e]); w2[e] = mixv(w2[e], c[e]); }
-    }
-    *reinterpret_cast<u32x4*>(v + dst) = w1;
-    *reinterpret_cast<u32x4*>(v + dst + half) = w2;
-  } else {  // the 4-element remainder of the half (head_dim 72: elements 32..35 and 68..71)
-    const f32x4 c4 = *reinterpret_cast<const f32x4*>(cp);
-    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp);
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      const u32x2 lo = *reinterpret_cast<const u32x2*>(src + which * D);
-      const u32x2 hi = *reinterpret_cast<const u32x2*>(src + which * D + half);
-      const float x1[4] = {bflo(lo[0]), bfhi(lo[0]), bflo(lo[1]), bfhi(lo[1])};
-      const float x2[4] = {bflo(hi[0]), bfhi(hi[0]), bflo(hi[1]), bfhi(hi[1])};
-      float y1[4], y2[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        y1[e] = x1[e] * c4[e] + x2[e] * s4[e];
-        y2[e] = x2[e] * c4[e] - x1[e] * s4[e];
-      }
-      bf16_t* o = (which == 0 ? q : k) + dst;
-      *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])};
-      *reinterpret_cast<u32x2*>(o + half) = u32x2{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])};
-    }
-    u32x2 w1 = *reinterpret_cast<const u32x2*>(src + 2 * D);
-    u32x2 w2 = *reinterpret_cast<const u32x2*>(src + 2 * D + half);
-    if (v0) {
-      const u32x2 a = *reinterpret_cast<const u32x2*>(v0 + dst);
-      const u32x2 c = *reinterpret_cast<const u32x2*>(v0 + dst + half);
-#pragma unroll
-      for (int e = 0; e < 2; ++e) { w1[e] = mixv(w1[e], a[e]); w2[e] = mixv(w2[e], c[e]); }
-    }
-    *reinterpret_cast<u32x2*>(v + dst) = w1;
-    *reinterpret_cast<u32x2*>(v + dst + half) = w2;
-  }
-  // pad columns hd..hdp (see qkv_rope_fwd_kernel): 8-column chunks, chunk g by thread g
-  if (g < ((hdp - hd) >> 3)) {
-    const long pd = (((long)b * H + hh) * L + l) * hdp + hd + 8 * g;
-    const bool ones = (hdp - hd) >= 8 && g == 0;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    u32x4 kk = z, vv = z;
-    if (ones) {
-      kk[0] = 0x3f803f80u;  // columns hd, hd+1
-      vv[0] = 0x3f80u;      // column hd
-      vv[2] = 0x3f80u;      // column hd+4
-    }
-    *reinterpret_cast<u32x4*>(q + pd) = z;
-    *reinterpret_cast<u32x4*>(k + pd) = kk;
-    *reinterpret_cast<u32x4*>(v + pd) = vv;
-  }
-}
-
 // stand-alone apply_rotary_emb (model.py:266-275): y1 = x1 c + x2 s, y2 = x2 c - x1 s on the two halves of every
 // head row, fp32 math, bf16 out; inverse = the transposed rotation (its backward).  One thread = 4 + 4 elements.
 __global__ __launch_bounds__(256) void rope_apply_kernel(const bf16_t* x, long x_sb, long x_sh, long x_sl,
@@ -1185,19 +1077,6 @@ extern "C" int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float*
   if (((hdp - hd) >> 2) > (hd >> 3)) return VDS_ERR_UNSUPPORTED;
   const long n = (long)B * L * H * (hd >> 3);
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, (hipStream_t)stream, 0.0, (v0 ? 14.0 : 12.0) * B * L * H * hd);
-  static int fwd16 = -1;  // VDS_ROPE_FWD16=0: the 8-byte-access kernel (A/B)
-  if (fwd16 < 0) {
-    const char* e = getenv("VDS_ROPE_FWD16");
-    fwd16 = e ? atoi(e) : 1;
-  }
-  const int half = hd >> 1, ng = (half >> 3) + ((half & 7) ? 1 : 0);
-  if (fwd16 && (half & 3) == 0 && ((half & 7) == 0 || (half & 7) == 4) && (hdp & 7) == 0 && ((hdp - hd) >> 3) <= ng) {
-    const long n16 = (long)B * L * H * ng;
-    hipLaunchKernelGGL(qkv_rope_fwd16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (bf16_t*)q, (bf16_t*)k,
-                       (bf16_t*)v, B, L, H, hd, hdp);
-    return ok();
-  }
   hipLaunchKernelGGL(qkv_rope_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (bf16_t*)q, (bf16_t*)k,
                      (bf16_t*)v, B, L, H, hd, hdp);
