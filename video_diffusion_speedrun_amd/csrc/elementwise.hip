@@ -40,21 +40,13 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
   if (row >= (long)B * L) return;
   const int b = (int)(row / L);
   const int nch = D >> 3;
-  float v[NC][8], sh[NC][8], sc[NC][8];
-  u32x4 pw[NC];
+  float v[NC][8];
   float ss = 0.f;
-  const float* mrow = mod + (long)b * ldmod;
-  // the modulation row (and the norm weight) are requested together with x: they are only needed after the row
-  // reduction, and loading them there would expose a second (L2) round trip in a wave that lives for one row
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
-      const u32x4 px = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
-      load8f(mrow + shift_col + c * 8, sh[i]);
-      load8f(mrow + scale_col + c * 8, sc[i]);
-      pw[i] = w ? *reinterpret_cast<const u32x4*>(w + c * 8) : u32x4{0u, 0u, 0u, 0u};
-      unpack8(px, v[i]);
+      unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + c * 8), v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
     }
@@ -62,17 +54,20 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
   ss = wave_sum(ss);
   const float r = rsqrtf(ss / (float)D + eps);
   if (lane == 0) rstd[row] = r;
+  const float* mrow = mod + (long)b * ldmod;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
-      float o[8], wv[8];
-      if (w) unpack8(pw[i], wv);
+      float sh[8], sc[8], o[8], wv[8];
+      load8f(mrow + shift_col + c * 8, sh);
+      load8f(mrow + scale_col + c * 8, sc);
+      if (w) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float xn = v[i][e] * r;
         if (w) xn *= wv[e];
-        o[e] = xn * (1.0f + sc[i][e]) + sh[i][e];
+        o[e] = xn * (1.0f + sc[e]) + sh[e];
       }
       *reinterpret_cast<u32x4*>(y + row * ldy + c * 8) = pack8(o);
     }
