@@ -137,3 +137,83 @@ def test_gemm_epilogue_emits_fp8_copies(ops, M, N, K):
     assert qd.s.item() == s_ref.item() and rec.item() == amax_dh.item()
     want = dh.float().sum(0)
     assert ((cs - want).abs().max() / want.abs().max()).item() <= 1e-5
+
+
+# ---- producers that emit fp8 themselves: bit-identical to vds_quant_fp8 of the plain kernel's bf16 result -----------
+def _same_as_quant(ops, name, q, dq, rec, plain, fmt, old):
+    """q / dq / recorded amax of an *_fp8 entry point against a quantisation pass over `plain` (bf16, on the GPU)"""
+    rec2 = torch.zeros(1, device="cuda")
+    q2, _, dq2 = ops.quant_fp8(plain, fmt, old, amax_out=rec2)
+    assert torch.equal(q.view(torch.uint8), q2.view(torch.uint8)), name
+    assert dq.item() == dq2.item() and rec.item() == rec2.item() == plain.float().abs().max().item(), name
+
+
+@pytest.mark.parametrize("M,K", [(128, 128), (300, 144), (516, 1152), (4, 16)])
+def test_transpose_fp8(ops, M, K):
+    g = torch.Generator().manual_seed(M * K)
+    q = torch.randint(0, 256, (M, K), generator=g, dtype=torch.uint8).cuda().view(torch.float8_e4m3fn)
+    qt = ops.transpose_fp8(q)
+    assert qt.shape == (K, M) and torch.equal(qt.view(torch.uint8), q.view(torch.uint8).t().contiguous())
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("D,with_w", [(384, False), (1152, False), (1152, True), (2048, False)])
+def test_rmsnorm_mod_fwd_emits_fp8(ops, fmt, D, with_w):
+    B, L = 3, 75
+    x = gen(B * L, D, seed=50).cuda()
+    w = (1 + 0.1 * gen(D, seed=51).float()).to(bf16).cuda() if with_w else None
+    mod = (gen(B, 9 * D, seed=52).float() * 0.5).cuda()
+    y, rstd = ops.rmsnorm_mod_fwd(x, w, mod, 3 * D, 4 * D, B, L)
+    old = y.float().abs().max().reshape(1) * 0.8  # an older, smaller amax: saturation is exercised
+    rec = torch.zeros(1, device="cuda")
+    q, dq, rstd2 = ops.rmsnorm_mod_fwd_fp8(x, w, mod, 3 * D, 4 * D, B, L, fmt, old, rec)
+    assert torch.equal(rstd, rstd2)
+    _same_as_quant(ops, "rmsnorm", q, dq, rec, y, fmt, old)
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_gate_bwd_emits_fp8(ops, fmt):
+    B, L, D = 2, 203, 1152
+    dxn, y = gen(B * L, D, seed=60).cuda(), gen(B * L, D, seed=61).cuda()
+    mod = gen(B, 9 * D, seed=62).float().cuda()
+    dmod, dmod2 = (torch.zeros(B, 9 * D, dtype=f32, device="cuda") for _ in range(2))
+    dbias, dbias2 = (torch.zeros(D, dtype=f32, device="cuda") for _ in range(2))
+    dy = ops.gate_bwd(dxn, y, mod, 5 * D, dmod, dbias, B, L)
+    old = dy.float().abs().max().reshape(1) * 0.9
+    rec = torch.zeros(1, device="cuda")
+    q, dq = ops.gate_bwd_fp8(dxn, y, mod, 5 * D, dmod2, dbias2, B, L, fmt, old, rec)
+    _same_as_quant(ops, "gate_bwd", q, dq, rec, dy, fmt, old)
+    assert torch.equal(dmod, dmod2) or (dmod - dmod2).abs().max().item() <= 1e-5 * dmod.abs().max().item()
+    assert (dbias - dbias2).abs().max().item() <= 1e-5 * dbias.abs().max().item()
+
+
+@pytest.mark.parametrize("hd,hdp,H", [(64, 64, 2), (72, 96, 16), (128, 128, 3)])
+@pytest.mark.parametrize("mix", [True, False])
+def test_qkv_rope_bwd_emits_fp8(ops, hd, hdp, H, mix):
+    from oracle import dit_oracle as O
+    B, thw = 2, (2, 4, 5)
+    L = thw[0] * thw[1] * thw[2] + 16
+    D = H * hd
+    cos, sin = (t.cuda() for t in O.rope_cos_sin(hd, thw, (3, 7, 11)))
+    qkv = gen(B * L, 3 * D, seed=70).cuda()
+    v0 = gen(B, H, L, hdp, seed=71)
+    v0[..., hd:] = 0
+    v0 = v0.cuda()
+    lam = torch.tensor([0.37]).to(bf16).cuda()
+    dq, dk, dv = (gen(B, H, L, hdp, seed=s).cuda() for s in (72, 73, 74))
+    outs = []
+    for emit in (False, True):
+        dv0 = torch.full((B, H, L, hdp), 0.25, dtype=f32, device="cuda")
+        dlam = torch.zeros(1, dtype=f32, device="cuda")
+        args = (dq, dk, dv, cos, sin, qkv if mix else None, v0 if mix else None, lam if mix else None, dv0,
+                dlam if mix else None, mix, not mix, B, L, H, hd, hdp)
+        if not emit:
+            plain = ops.qkv_rope_bwd(*args)
+            old = plain.float().abs().max().reshape(1) * 0.7
+            outs.append((dv0, dlam))
+        else:
+            rec = torch.zeros(1, device="cuda")
+            q, s = ops.qkv_rope_bwd_fp8(*args, 1, old, rec)
+            _same_as_quant(ops, "qkv_rope_bwd", q, s, rec, plain, 1, old)
+            assert torch.equal(dv0, outs[0][0])
+            assert abs(dlam.item() - outs[0][1].item()) <= 1e-5 * max(1.0, abs(dlam.item()))

@@ -115,6 +115,13 @@ SIGNATURES = {
     "vds_gemm_fp8": [C.POINTER(GemmArgs), c_vp, c_vp, c_i32, c_i32, c_vp, c_vp],
     "vds_absmax": [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "vds_quant_fp8": [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "vds_transpose_fp8": [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp],
+    "vds_rmsnorm_mod_fwd_fp8": [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp,
+                                c_vp, c_i32, c_i32, c_i32, c_f32, c_vp],
+    "vds_gate_bwd_fp8": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp,
+                         c_vp, c_i32, c_i32, c_i32, c_vp],
+    "vds_qkv_rope_bwd_fp8": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp,
+                             c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_selftest_lanemaps": [c_vp, c_vp],
     "vds_prof_enable": [C.c_uint32],
     "vds_prof_collect": [c_vp],

@@ -63,6 +63,21 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// ---- OCP fp8 (e4m3fn = format 0, e5m2 = format 1): saturating casts of 4 / 8 scaled values -----------------
+__device__ __forceinline__ float fp8_fmax(int fmt) { return fmt == 0 ? 448.0f : 57344.0f; }
+template <int FMT>
+__device__ __forceinline__ unsigned fp8_cvt4(float a, float b, float c, float d) {
+  int w = 0;
+  if constexpr (FMT == 0) {
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  } else {
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+  }
+  return (unsigned)w;
+}
+
 // Buffer resource (SRD) for bounds-checked raw buffer loads: out-of-range bytes read as 0.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);

@@ -26,18 +26,65 @@ __device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
   f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
 }
 
+// ---- fp8 emission (BASELINE config 5; the recipe is stated in fp8.py / quant.hip) --------------------------------
+// The three producers of the fp8 GEMMs' activation / gradient operands -- RMSNorm+modulate (qkv / fc1 input), gate
+// backward (fc2 output gradient) and the qkv/RoPE backward (qkv output gradient) -- can write their result directly
+// as fp8 (QF = 0: e4m3, 1: e5m2) instead of bf16: the value is rounded to bf16 first, then scaled by fmax / *amax_in
+// (the previous step's amax: delayed scaling) and cast with saturation, i.e. bit-identical to vds_quant_fp8 of the
+// bf16 result; max |x| of the bf16 values goes to *amax_out (atomic max on the float bits), amax_in / fmax to *dq_out.
+struct QOut {
+  unsigned char* q;       // [rows, ldq] fp8, row-major (the transposed copy is vds_transpose_fp8's job)
+  long ldq;
+  const float* amax_in;
+  float* amax_out;        // or null
+  float* dq_out;          // or null
+};
+template <int QF>
+struct QState {
+  float scale, fmax;
+  unsigned mx;
+  __device__ __forceinline__ void init(const QOut& qo, bool writer) {
+    fmax = fp8_fmax(QF);
+    const float am = *qo.amax_in;
+    scale = am > 0.f ? fmax / am : 1.0f;
+    mx = 0u;
+    if (writer && qo.dq_out) *qo.dq_out = am > 0.f ? am / fmax : 1.0f;
+  }
+  // 8 results -> 8 fp8 bytes
+  __device__ __forceinline__ u32x2 cvt(const float (&o)[8]) {
+    const u32x4 pk = pack8(o);
+    float v[8];
+    unpack8(pk, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mx = max(mx, max((pk[e] << 16) & 0x7fffffffu, pk[e] & 0x7fff0000u));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * scale, -fmax), fmax);
+    return u32x2{fp8_cvt4<QF>(v[0], v[1], v[2], v[3]), fp8_cvt4<QF>(v[4], v[5], v[6], v[7])};
+  }
+  // once per wave at the end: same-address atomics serialise, so only a wave that can raise the maximum issues one
+  __device__ __forceinline__ void finish(const QOut& qo) {
+    if (!qo.amax_out) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    unsigned* a = reinterpret_cast<unsigned*>(qo.amax_out);
+    if ((threadIdx.x & 63) == 0 && mx > __atomic_load_n(a, __ATOMIC_RELAXED)) atomicMax(a, mx);
+  }
+};
+
 // ------------------------------------------------------------------ RMSNorm + modulate ---
 // model.py:34-41 (RMSNorm, fp32 statistics, eps 1e-6) fused with model.py:123/144/164/389
 // (norm_x*(1+scale)+shift).  One wave per token row, the row stays in registers; each lane
 // owns 16-byte chunks lane, lane+64, ...  NC = chunks per lane (D <= 512*NC).
-template <int NC>
+template <int NC, int QF = -1>
 __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, long ldx, const bf16_t* w,
                                                               const float* mod, long ldmod, int shift_col,
                                                               int scale_col, bf16_t* y, long ldy, float* rstd,
-                                                              int B, int L, int D, float eps) {
+                                                              int B, int L, int D, float eps, QOut qo) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= (long)B * L) return;
+  QState<(QF < 0 ? 0 : QF)> qs;
+  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0);
   const int b = (int)(row / L);
   const int nch = D >> 3;
   float v[NC][8];
@@ -69,9 +116,11 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
         if (w) xn *= wv[e];
         o[e] = xn * (1.0f + sc[e]) + sh[e];
       }
-      *reinterpret_cast<u32x4*>(y + row * ldy + c * 8) = pack8(o);
+      if constexpr (QF >= 0) *reinterpret_cast<u32x2*>(qo.q + row * qo.ldq + c * 8) = qs.cvt(o);
+      else *reinterpret_cast<u32x4*>(y + row * ldy + c * 8) = pack8(o);
     }
   }
+  if constexpr (QF >= 0) qs.finish(qo);
 }
 
 // (Measured negative, round 2: requesting the next row's dy / x / dres one row ahead in registers -- 36 more VGPRs --
@@ -202,11 +251,11 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
 // ------------------------------------------------------------------------ gate backward ---
 // x_new = x + y*gate (model.py:139,160,165): dy = dx_new*gate, dgate = sum_l dx_new*y,
 // dbias = sum_{b,l} dy.  Same sample-per-blockIdx.y structure as above.
-template <int NC>
+template <int NC, int QF = -1>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long lddxn, const bf16_t* y, long ldy,
                                                        const float* mod, long ldmod, int gate_col, bf16_t* dy,
                                                        long lddy, float* dmod, float* dbias, int B, int L, int D,
-                                                       int rows_per_block) {
+                                                       int rows_per_block, QOut qo) {
   __shared__ float red[4][64 * NC * 8 + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -214,6 +263,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
   const int l0 = blockIdx.x * rows_per_block;
   const int l1 = min(L, l0 + rows_per_block);
   float gt[NC][8], a_g[NC][8], a_b[NC][8];
+  QState<(QF < 0 ? 0 : QF)> qs;
+  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
@@ -236,10 +287,12 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
           o[e] = d[e] * gt[i][e];
           a_b[i][e] += o[e];
         }
-        *reinterpret_cast<u32x4*>(dy + row * lddy + c * 8) = pack8(o);
+        if constexpr (QF >= 0) *reinterpret_cast<u32x2*>(qo.q + row * qo.ldq + c * 8) = qs.cvt(o);
+        else *reinterpret_cast<u32x4*>(dy + row * lddy + c * 8) = pack8(o);
       }
     }
   }
+  if constexpr (QF >= 0) qs.finish(qo);
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1 && !dbias) break;
     __syncthreads();
@@ -488,19 +541,21 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* dq, con
 // Measured on the DiT-XL step (B = 12, same box): 18.8 ms per step against 22.2 ms.  The same restructuring of
 // the FORWARD kernel was slower (14.3 against 13.4 ms: its scattered 144-byte head-row stores gain nothing from
 // 16-byte lanes and it pays the LDS exchange) and is not in the tree.
-template <int NI>
+template <int NI, int QF = -1>
 __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq, const bf16_t* dk, const bf16_t* dv,
                                                                const float* cosb, const float* sinb,
                                                                const bf16_t* qkv_raw, const bf16_t* v0,
                                                                const bf16_t* lamp, float* dv0_acc, float* dlam,
                                                                bf16_t* dqkv, int mix, int add_dv0, int B, int L,
-                                                               int H, int hd, int hdp) {
+                                                               int H, int hd, int hdp, QOut qo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long tok = (long)blockIdx.x * 4 + wave;
   const bool live = tok < (long)B * L;
   float dl = 0.f;
+  QState<(QF < 0 ? 0 : QF)> qs;
+  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0);
   if (live) {
     const int b = (int)(tok / L), l = (int)(tok % L);
     const int D = H * hd, nch = D >> 3, cph = hd >> 3, half = hd >> 1;
@@ -558,8 +613,15 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
           ok_[4 * g4 + e] = gk[4 * g4 + e] * c4[e] + pkf[e] * sg;
         }
       }
-      *reinterpret_cast<u32x4*>(dst + c * 8) = pack8(oq);
-      *reinterpret_cast<u32x4*>(dst + D + c * 8) = pack8(ok_);
+      unsigned char* qdst = nullptr;
+      if constexpr (QF >= 0) {
+        qdst = qo.q + tok * qo.ldq;
+        *reinterpret_cast<u32x2*>(qdst + c * 8) = qs.cvt(oq);
+        *reinterpret_cast<u32x2*>(qdst + D + c * 8) = qs.cvt(ok_);
+      } else {
+        *reinterpret_cast<u32x4*>(dst + c * 8) = pack8(oq);
+        *reinterpret_cast<u32x4*>(dst + D + c * 8) = pack8(ok_);
+      }
       float g[8];
       unpack8(*reinterpret_cast<const u32x4*>(dv + so), g);
       if (mix) {
@@ -581,9 +643,11 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] += a[e];
       }
-      *reinterpret_cast<u32x4*>(dst + 2 * D + c * 8) = pack8(g);
+      if constexpr (QF >= 0) *reinterpret_cast<u32x2*>(qdst + 2 * D + c * 8) = qs.cvt(g);
+      else *reinterpret_cast<u32x4*>(dst + 2 * D + c * 8) = pack8(g);
     }
   }
+  if constexpr (QF >= 0) qs.finish(qo);
   if (mix) {
     dl = wave_sum(dl);
     if (lane == 0) red[wave] = dl;
@@ -995,7 +1059,38 @@ extern "C" int vds_rmsnorm_mod_fwd(const void* x, int64_t ldx, const void* w, co
 #define CALL(NC)                                                                                              \
   hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,          \
                      (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, \
-                     (bf16_t*)y, (long)ldy, rstd, B, L, D, eps)
+                     (bf16_t*)y, (long)ldy, rstd, B, L, D, eps, QOut{})
+  NC_DISPATCH(D, CALL);
+#undef CALL
+  return ok();
+}
+
+static bool qout_ok(const void* q, int64_t ldq, int32_t fmt, const float* amax_in) {
+  return q && amax_in && !(ldq & 7) && (fmt == 0 || fmt == 1);
+}
+
+extern "C" int vds_rmsnorm_mod_fwd_fp8(const void* x, int64_t ldx, const void* w, const float* mod, int64_t ldmod,
+                                       int32_t shift_col, int32_t scale_col, void* q, int64_t ldq, int32_t fmt,
+                                       const float* amax_in, float* amax_out, float* dq_out, float* rstd, int32_t B,
+                                       int32_t L, int32_t D, float eps, vds_stream_t stream) {
+  if (!x || !mod || !rstd || (D & 7) || (ldx & 7) || (shift_col & 3) || (scale_col & 3) || (ldmod & 3) ||
+      !qout_ok(q, ldq, fmt, amax_in))
+    return VDS_ERR_ARG;
+  const long rows = (long)B * L;
+  hipStream_t s = (hipStream_t)stream;
+  const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_out, dq_out};
+  vdsprof::Scope ps(VDS_PROF_RMSNORM_FWD, s, 0.0, 3.0 * rows * D + 4.0 * rows);
+#define CALL(NC)                                                                                               \
+  do {                                                                                                         \
+    if (fmt == 0)                                                                                              \
+      hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC, 0>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,    \
+                         (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, \
+                         (bf16_t*)nullptr, 0L, rstd, B, L, D, eps, qo);                                        \
+    else                                                                                                       \
+      hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,    \
+                         (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, \
+                         (bf16_t*)nullptr, 0L, rstd, B, L, D, eps, qo);                                        \
+  } while (0)
   NC_DISPATCH(D, CALL);
 #undef CALL
   return ok();
@@ -1039,7 +1134,33 @@ extern "C" int vds_gate_bwd(const void* dxn, int64_t lddxn, const void* y, int64
 #define CALL(NC)                                                                                             \
   hipLaunchKernelGGL((gate_bwd_kernel<NC>), grid, dim3(256), 0, s, (const bf16_t*)dxn, (long)lddxn,           \
                      (const bf16_t*)y, (long)ldy, mod, (long)ldmod, gate_col, (bf16_t*)dy, (long)lddy, dmod, \
-                     dbias, B, L, D, rpb)
+                     dbias, B, L, D, rpb, QOut{})
+  NC_DISPATCH(D, CALL);
+#undef CALL
+  return ok();
+}
+
+extern "C" int vds_gate_bwd_fp8(const void* dxn, int64_t lddxn, const void* y, int64_t ldy, const float* mod,
+                                int64_t ldmod, int32_t gate_col, void* q, int64_t ldq, int32_t fmt,
+                                const float* amax_in, float* amax_out, float* dq_out, float* dmod, float* dbias,
+                                int32_t B, int32_t L, int32_t D, vds_stream_t stream) {
+  if (!dxn || !y || !mod || !dmod || (D & 7) || !qout_ok(q, ldq, fmt, amax_in)) return VDS_ERR_ARG;
+  const int rpb = rows_per_block_for(L, B);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((L + rpb - 1) / rpb, B);
+  const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_out, dq_out};
+  vdsprof::Scope ps(VDS_PROF_GATE_BWD, s, 0.0, 5.0 * B * L * D);
+#define CALL(NC)                                                                                                   \
+  do {                                                                                                             \
+    if (fmt == 0)                                                                                                  \
+      hipLaunchKernelGGL((gate_bwd_kernel<NC, 0>), grid, dim3(256), 0, s, (const bf16_t*)dxn, (long)lddxn,          \
+                         (const bf16_t*)y, (long)ldy, mod, (long)ldmod, gate_col, (bf16_t*)nullptr, 0L, dmod, dbias, \
+                         B, L, D, rpb, qo);                                                                        \
+    else                                                                                                           \
+      hipLaunchKernelGGL((gate_bwd_kernel<NC, 1>), grid, dim3(256), 0, s, (const bf16_t*)dxn, (long)lddxn,          \
+                         (const bf16_t*)y, (long)ldy, mod, (long)ldmod, gate_col, (bf16_t*)nullptr, 0L, dmod, dbias, \
+                         B, L, D, rpb, qo);                                                                        \
+  } while (0)
   NC_DISPATCH(D, CALL);
 #undef CALL
   return ok();
@@ -1098,7 +1219,7 @@ extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, 
 #define ROPE_BWD(NI)                                                                                                \
   hipLaunchKernelGGL(qkv_rope_bwd_tok_kernel<NI>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dq,    \
                      (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw, (const bf16_t*)v0,  \
-                     (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp)
+                     (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp, QOut{})
     if (D <= 512) ROPE_BWD(1);
     else if (D <= 1024) ROPE_BWD(2);
     else if (D <= 1536) ROPE_BWD(3);
@@ -1109,6 +1230,39 @@ extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, 
   hipLaunchKernelGGL(qkv_rope_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw,
                      (const bf16_t*)v0, (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp);
+  return ok();
+}
+
+// as vds_qkv_rope_bwd, the [B*L, 3D] result written as fp8 (wave-per-token kernel only)
+extern "C" int vds_qkv_rope_bwd_fp8(const void* dq, const void* dk, const void* dv, const float* cosb,
+                                    const float* sinb, const void* qkv_raw, const void* v0, const void* lam,
+                                    float* dv0_acc, float* dlam, void* q, int64_t ldq, int32_t fmt,
+                                    const float* amax_in, float* amax_out, float* dq_out, int32_t mix,
+                                    int32_t add_dv0, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t hdp,
+                                    vds_stream_t stream) {
+  if (!dq || !dk || !dv || !cosb || !sinb || (hd & 7) || !qout_ok(q, ldq, fmt, amax_in)) return VDS_ERR_ARG;
+  if (mix && (!qkv_raw || !v0 || !lam || !dv0_acc || !dlam)) return VDS_ERR_ARG;
+  if (add_dv0 && !dv0_acc) return VDS_ERR_ARG;
+  if ((hdp & 7) || H * hd > 2048 || ldq < 3 * H * hd) return VDS_ERR_UNSUPPORTED;
+  vdsprof::Scope ps(VDS_PROF_QKV_ROPE_BWD, (hipStream_t)stream, 0.0, (mix ? 21.0 : 9.0) * B * L * H * hd);
+  const int D = H * hd, lds = 4 * (4 * D + 4 * hd);
+  const dim3 grid((unsigned)(((long)B * L + 3) / 4));
+  const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_out, dq_out};
+#define ROPE_BWD_Q(NI, F)                                                                                             \
+  hipLaunchKernelGGL((qkv_rope_bwd_tok_kernel<NI, F>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dq, \
+                     (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw, (const bf16_t*)v0,    \
+                     (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)nullptr, mix, add_dv0, B, L, H, hd, hdp, qo)
+#define ROPE_BWD_F(F)              \
+  do {                             \
+    if (D <= 512) ROPE_BWD_Q(1, F); \
+    else if (D <= 1024) ROPE_BWD_Q(2, F); \
+    else if (D <= 1536) ROPE_BWD_Q(3, F); \
+    else ROPE_BWD_Q(4, F);          \
+  } while (0)
+  if (fmt == 0) ROPE_BWD_F(0);
+  else ROPE_BWD_F(1);
+#undef ROPE_BWD_F
+#undef ROPE_BWD_Q
   return ok();
 }
 

@@ -22,8 +22,6 @@ __device__ __forceinline__ void unpack8(const u32x4& u, float (&f)[8]) {
   for (int e = 0; e < 4; ++e) { f[2 * e] = bflo(u[e]); f[2 * e + 1] = bfhi(u[e]); }
 }
 
-__device__ __forceinline__ float fp8_max(int fmt) { return fmt == 0 ? 448.0f : 57344.0f; }
-
 // one 128 x 128 tile per workgroup, 8 independent 16-byte loads per thread (same indexing as quant_kernel)
 __global__ __launch_bounds__(256) void absmax_kernel(const bf16_t* x, long ldx, int M, int K, float* amax) {
   const int tid = threadIdx.x;
@@ -57,19 +55,6 @@ __global__ __launch_bounds__(256) void absmax_kernel(const bf16_t* x, long ldx, 
   }
 }
 
-template <int FMT>
-__device__ __forceinline__ unsigned cvt4(float a, float b, float c, float d) {
-  int w = 0;
-  if constexpr (FMT == 0) {
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  } else {
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
-  }
-  return (unsigned)w;
-}
-
 template <int FMT, bool TRANS>
 __global__ __launch_bounds__(256) void quant_kernel(const bf16_t* x, long ldx, int M, int K, const float* amax,
                                                     unsigned char* q, long ldq, unsigned char* qt, long ldt,
@@ -79,7 +64,7 @@ __global__ __launch_bounds__(256) void quant_kernel(const bf16_t* x, long ldx, i
   unsigned mx = 0u;  // amax_out: max |x| of this tile (bf16 bit patterns), for the next step's scale
   const int tid = threadIdx.x;
   const int m0 = blockIdx.y * QT, k0 = blockIdx.x * QT;
-  const float fmax = fp8_max(FMT);
+  const float fmax = fp8_fmax(FMT);
   const float am = *amax;
   const float scale = am > 0.f ? fmax / am : 1.0f;
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && dq_out) *dq_out = am > 0.f ? am / fmax : 1.0f;
@@ -98,8 +83,8 @@ __global__ __launch_bounds__(256) void quant_kernel(const bf16_t* x, long ldx, i
         for (int e = 0; e < 4; ++e) mx = max(mx, max((raw[e] << 16) & 0x7fffffffu, raw[e] & 0x7fff0000u));
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * scale, -fmax), fmax);
-      w[0] = cvt4<FMT>(v[0], v[1], v[2], v[3]);
-      w[1] = cvt4<FMT>(v[4], v[5], v[6], v[7]);
+      w[0] = fp8_cvt4<FMT>(v[0], v[1], v[2], v[3]);
+      w[1] = fp8_cvt4<FMT>(v[4], v[5], v[6], v[7]);
       if (q) *reinterpret_cast<u32x2*>(q + (long)m * ldq + k) = w;
     }
     if constexpr (TRANS) *reinterpret_cast<u32x2*>(tile + r * QLD + 8 * c) = w;
@@ -142,7 +127,59 @@ __global__ __launch_bounds__(256) void quant_kernel(const bf16_t* x, long ldx, i
   }
 }
 
+// qt[k, m] = q[m, k] for an fp8 (any 1-byte) matrix: the k-contiguous copy of an operand whose row-major copy was
+// emitted by its producer.  Tile 128 x 128, 16-byte loads (8 per row), transposed through LDS with the 4x4 byte
+// transposes of quant_kernel: every store instruction writes 128 contiguous bytes per row.  1 B read + 1 B written.
+__global__ __launch_bounds__(256) void transpose_u8_kernel(const unsigned char* q, long ldq, int M, int K,
+                                                           unsigned char* qt, long ldt) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[QT * (QT + 16)];
+  constexpr int TLD = QT + 16;  // 16-byte aligned rows (b128 stores), 36 dwords: column reads 4-way conflicted at most
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * QT, k0 = blockIdx.x * QT;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = tid + 256 * it;
+    const int r = idx >> 3, c = idx & 7;
+    const int m = m0 + r, k = k0 + 16 * c;
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (m < M && k < K) w = *reinterpret_cast<const u32x4*>(q + (long)m * ldq + k);  // K % 16 == 0
+    *reinterpret_cast<u32x4*>(tile + r * TLD + 16 * c) = w;
+  }
+  __syncthreads();
+  const int mq = tid & 31;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int kq = (tid >> 5) + 8 * it;
+    unsigned r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const unsigned*>(tile + (4 * mq + i) * TLD + 4 * kq);
+    const unsigned t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
+    const unsigned t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+    const unsigned c[4] = {__builtin_amdgcn_perm(t2, t0, 0x05040100u), __builtin_amdgcn_perm(t2, t0, 0x07060302u),
+                           __builtin_amdgcn_perm(t3, t1, 0x05040100u), __builtin_amdgcn_perm(t3, t1, 0x07060302u)};
+    const int m = m0 + 4 * mq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 4 * kq + j;
+      if (k >= K || m >= M) continue;
+      unsigned char* dst = qt + (long)k * ldt + m;
+      if (m + 4 <= M) *reinterpret_cast<unsigned*>(dst) = c[j];
+      else
+        for (int i = 0; i < M - m; ++i) dst[i] = (unsigned char)(c[j] >> (8 * i));
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int vds_transpose_fp8(const void* q, int64_t ldq, int32_t M, int32_t K, void* qt, int64_t ldt,
+                                 vds_stream_t stream) {
+  if (!q || !qt || M < 1 || K < 16 || (K & 15) || (ldq & 15) || (ldt & 3)) return VDS_ERR_ARG;
+  const dim3 grid((K + QT - 1) / QT, (M + QT - 1) / QT);
+  hipLaunchKernelGGL(transpose_u8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)q, (long)ldq, M,
+                     K, (unsigned char*)qt, (long)ldt);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
 
 extern "C" int vds_absmax(const void* x, int64_t ldx, int32_t M, int32_t K, float* amax, vds_stream_t stream) {
   if (!x || !amax || M < 1 || K < 8 || (K & 7) || (ldx & 7)) return VDS_ERR_ARG;

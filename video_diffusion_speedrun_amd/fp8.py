@@ -10,9 +10,12 @@ The reference trains in bf16 only (model.py:516-518), so the recipe is this buil
   * per-tensor scaling with saturating casts.  Weights are scaled by their current amax.  Activations and
     gradients use delayed scaling in training: the scale comes from the amax the previous step recorded
     (`AmaxHistory`, one device table, no host synchronisation), and the pass that quantises a tensor records its
-    current amax for the next step -- one read of the tensor instead of two.  The two widest tensors -- gelu(fc1)
-    and the fc2 input gradient, [tokens, 4D] -- are not re-read at all: the producing GEMM's epilogue emits them
-    as fp8 (`emit`).  The first step (no history) and no-grad forwards compute each tensor's own amax first;
+    current amax for the next step -- one read of the tensor instead of two.  With a history no operand is
+    quantised by a separate pass over a bf16 tensor: gelu(fc1) and the fc2 input gradient ([tokens, 4D]) leave
+    their GEMM's epilogue as fp8 (`emit`), and the RMSNorm+modulate outputs, the fc2 output gradient (gate
+    backward) and the qkv output gradient (RoPE backward) leave their producer kernels as fp8 (`ops.*_fp8`; the
+    k-contiguous copies are 1-byte transposes, `Q.from_rowmajor`).  The first step (no history) and no-grad
+    forwards compute each tensor's own amax first;
   * every operand is quantised once per use site into a row-major copy and, where the backward pass contracts
     over its other index, a transposed copy, so that all three products of a linear layer are NT GEMMs:
         y  = x_q  W_q^T          dx = dy_q (W_q^T)^T         dW = dy_q^T^T ... = (dy^T)_q (x^T)_q^T
@@ -60,6 +63,16 @@ class Q:
         o.q = torch.empty(M, K, dtype=ops.fp8_dtypes[fmt], device=device) if rowmajor else None
         o.t = torch.empty(K, M, dtype=ops.fp8_dtypes[fmt], device=device) if transposed else None
         o.s = torch.empty(1, dtype=f32, device=device)
+        return o
+
+    @classmethod
+    def from_rowmajor(cls, q: torch.Tensor, s: torch.Tensor, transposed: bool):
+        """wrap the row-major fp8 copy a producer kernel emitted (`ops.*_fp8`); the transposed copy, where the
+        backward pass needs one, is a 1-byte transpose of it (no second pass over a bf16 tensor)"""
+        o = cls()
+        o.rows, o.cols = q.shape
+        o.q, o.s = q, s
+        o.t = ops.transpose_fp8(q) if transposed else None
         return o
 
     def emit_args(self, fmt: int, amax_in, amax_out, colsum=None):

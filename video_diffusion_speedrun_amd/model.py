@@ -36,6 +36,7 @@ from . import ops
 from .params import FlatGroup
 
 _NO_EMIT = os.environ.get("VDS_FP8_NO_EMIT") == "1"  # experiments: quantise every fp8 operand in a separate pass
+_NO_PRODUCER_EMIT = os.environ.get("VDS_FP8_PRODUCER_EMIT") == "0"  # experiments: only the GEMM epilogues emit fp8
 
 bf16, f32 = torch.bfloat16, torch.float32
 N_REG = 16  # register tokens (model.py:316,362,386)
@@ -323,13 +324,22 @@ class DiTBlock(nn.Module):
         if mod is None:  # (DiT.forward computes the modulation of all blocks in one batched launch and passes it in)
             mod = ops.small_linear_fwd(cvec, W("adaLN_modulation.1.weight"), W("adaLN_modulation.1.bias"), 1)
         # --- self attention (model.py:122-139)
-        xn1, rstd1 = ops.rmsnorm_mod_fwd(X, Wo("norm1.weight"), mod, 0, D, B, L)
         f8 = use_fp8 and F8.supported(B * L, 3 * D, D)
         if use_fp8 and not f8:
             raise ValueError(f"fp8 linears need B*L ({B * L}) and hidden size ({D}) to be multiples of 16")
+        hist = fp8_hist if (f8 and save) else None
+        emit = hist is not None and hist.ready and not _NO_EMIT  # delayed scaling: producers write fp8 themselves
+        pemit = emit and not _NO_PRODUCER_EMIT
+        xn1 = xn3 = None
+        if pemit:
+            fq, fs, rstd1 = ops.rmsnorm_mod_fwd_fp8(X, Wo("norm1.weight"), mod, 0, D, B, L, F8.E4M3,
+                                                  hist.prev(6 * i + 2), hist.cur(6 * i + 2))
+            q_xn1 = F8.Q.from_rowmajor(fq, fs, save)
+        else:
+            xn1, rstd1 = ops.rmsnorm_mod_fwd(X, Wo("norm1.weight"), mod, 0, D, B, L)
         if f8:
-            hist = fp8_hist if save else None
-            q_xn1 = F8.Q(xn1, F8.E4M3, True, save, hist, 6 * i + 2)
+            if not pemit:
+                q_xn1 = F8.Q(xn1, F8.E4M3, True, save, hist, 6 * i + 2)
             q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save)
             qkv = torch.empty(B * L, 3 * D, dtype=bf16, device=dev)
             F8.fwd(q_xn1, q_wqkv, qkv, Wo("qkv.bias"))
@@ -357,11 +367,17 @@ class DiTBlock(nn.Module):
         else:
             X2 = X1
         # --- MLP (model.py:163-165)
-        xn3, rstd3 = ops.rmsnorm_mod_fwd(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L)
+        if pemit:
+            fq, fs, rstd3 = ops.rmsnorm_mod_fwd_fp8(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L, F8.E4M3,
+                                                  hist.prev(6 * i + 3), hist.cur(6 * i + 3))
+            q_xn3 = F8.Q.from_rowmajor(fq, fs, save)
+        else:
+            xn3, rstd3 = ops.rmsnorm_mod_fwd(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L)
         if f8:
-            q_xn3 = F8.Q(xn3, F8.E4M3, True, save, hist, 6 * i + 3)
+            if not pemit:
+                q_xn3 = F8.Q(xn3, F8.E4M3, True, save, hist, 6 * i + 3)
             q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save)
-            if hist is not None and hist.ready and not _NO_EMIT:  # gelu(fc1) leaves the GEMM as fp8
+            if emit:  # gelu(fc1) leaves the GEMM as fp8
                 hpre, q_hact = F8.fwd_gelu_emit(q_xn3, q_w1, W("mlp.0.bias"), hist.prev(6 * i), hist.cur(6 * i), save)
                 hact = None
             else:
@@ -405,12 +421,21 @@ class DiTBlock(nn.Module):
         if dmod is None:
             dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
         # --- MLP
-        dy = ops.gate_bwd(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L)
+        hist = fp8_hist if bs.f8 else None
+        emit = hist is not None and hist.ready and not _NO_EMIT
+        pemit = emit and not _NO_PRODUCER_EMIT
+        if pemit:  # the fc2 output gradient leaves gate_bwd as e5m2
+            fq, fs = ops.gate_bwd_fp8(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L, F8.E5M2,
+                                    hist.prev(6 * i + 4), hist.cur(6 * i + 4))
+            q_dy = F8.Q.from_rowmajor(fq, fs, True)
+            dy = None
+        else:
+            dy = ops.gate_bwd(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L)
         if bs.f8:
-            hist = fp8_hist
-            q_dy = F8.Q(dy, F8.E5M2, True, True, hist, 6 * i + 4)
+            if not pemit:
+                q_dy = F8.Q(dy, F8.E5M2, True, True, hist, 6 * i + 4)
             F8.wgrad(q_dy, bs.q_hact, Gr("mlp.2.weight"))
-            if hist.ready and not _NO_EMIT:  # the fc2 input gradient leaves the GEMM as e5m2 (+ transposed, + bias gradient)
+            if emit:  # the fc2 input gradient leaves the GEMM as e5m2 (+ transposed, + bias gradient)
                 dh = None
                 q_dh = F8.dgrad_gelu_emit(q_dy, bs.q_w2, bs.hpre, hist.prev(6 * i + 1), hist.cur(6 * i + 1),
                                           Gr("mlp.0.bias"))
@@ -463,14 +488,21 @@ class DiTBlock(nn.Module):
         ops.attn_bwd(bs.q[..., :hd], bs.k[..., :hd], bs.v[..., :hd], ops.heads_view(bs.attn, B, L, H, hd), bs.lse1,
                      ops.heads_view(dattn, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta,
                      kv_pad_ones=(hdp - hd) >= 8)
-        dqkv = ops.qkv_rope_bwd(dq, dk, dv, sv.cos, sv.sin, bs.qkv if bs.mix else None, sv.v0 if bs.mix else None,
-                                W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),
-                                Gr("lambda_param") if bs.mix else None, bs.mix,
-                                first and dv0 is not None, B, L, H, hd, hdp)
+        rope_args = (dq, dk, dv, sv.cos, sv.sin, bs.qkv if bs.mix else None, sv.v0 if bs.mix else None,
+                     W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),
+                     Gr("lambda_param") if bs.mix else None, bs.mix, first and dv0 is not None, B, L, H, hd, hdp)
+        # the qkv output gradient leaves the RoPE backward as e5m2 (a qkv bias gradient needs the bf16 tensor)
+        emit_dqkv = pemit and not G.has(pre + "qkv.bias") and hdp % 8 == 0 and D <= 2048
+        if emit_dqkv:
+            fq, fs = ops.qkv_rope_bwd_fp8(*rope_args, F8.E5M2, hist.prev(6 * i + 5), hist.cur(6 * i + 5))
+            q_dqkv = F8.Q.from_rowmajor(fq, fs, True)
+        else:
+            dqkv = ops.qkv_rope_bwd(*rope_args)
         if G.has(pre + "qkv.bias"):
             ops.colsum(dqkv, Gr("qkv.bias"))
         if bs.f8:
-            q_dqkv = F8.Q(dqkv, F8.E5M2, True, True, fp8_hist, 6 * i + 5)
+            if not emit_dqkv:
+                q_dqkv = F8.Q(dqkv, F8.E5M2, True, True, fp8_hist, 6 * i + 5)
             F8.wgrad(q_dqkv, bs.q_xn1, Gr("qkv.weight"))
             dxn = F8.dgrad(q_dqkv, bs.q_wqkv)
             del q_dqkv

@@ -244,6 +244,51 @@ def rmsnorm_mod_fwd(x, w, mod, shift_col, scale_col, B, L, eps=1e-6):
     return y, rstd
 
 
+def _fp8_out(rows, cols, fmt, device):
+    return torch.empty(rows, cols, dtype=fp8_dtypes[fmt], device=device), torch.empty(1, dtype=f32, device=device)
+
+
+def transpose_fp8(q: torch.Tensor) -> torch.Tensor:
+    """fp8 [M,K] (contiguous, K % 16 == 0) -> [K,M]"""
+    M, K = q.shape
+    assert q.is_contiguous() and K % 16 == 0 and M % 4 == 0
+    qt = torch.empty(K, M, dtype=q.dtype, device=q.device)
+    check(_lib.load().vds_transpose_fp8(_p(q), K, M, K, _p(qt), M, _stream()), "vds_transpose_fp8")
+    return qt
+
+
+def rmsnorm_mod_fwd_fp8(x, w, mod, shift_col, scale_col, B, L, fmt, amax_in, amax_out, eps=1e-6):
+    """rmsnorm_mod_fwd whose result leaves the kernel as fp8 (row-major) -> (q, dq f32[1], rstd)"""
+    D = x.shape[1]
+    q, dq = _fp8_out(B * L, D, fmt, x.device)
+    rstd = torch.empty(B * L, dtype=f32, device=x.device)
+    check(_lib.load().vds_rmsnorm_mod_fwd_fp8(_p(x), x.stride(0), _p(w), _p(mod), mod.stride(0), shift_col, scale_col,
+                                              _p(q), D, fmt, _p(amax_in), _p(amax_out), _p(dq), _p(rstd), B, L, D,
+                                              eps, _stream()), "vds_rmsnorm_mod_fwd_fp8")
+    return q, dq, rstd
+
+
+def gate_bwd_fp8(dxn, y, mod, gate_col, dmod, dbias, B, L, fmt, amax_in, amax_out):
+    """gate_bwd whose dy leaves the kernel as fp8 (row-major) -> (q, dq f32[1])"""
+    D = y.shape[1]
+    q, dq = _fp8_out(B * L, D, fmt, y.device)
+    check(_lib.load().vds_gate_bwd_fp8(_p(dxn), dxn.stride(0), _p(y), y.stride(0), _p(mod), mod.stride(0), gate_col,
+                                       _p(q), D, fmt, _p(amax_in), _p(amax_out), _p(dq), _p(dmod), _p(dbias), B, L, D,
+                                       _stream()), "vds_gate_bwd_fp8")
+    return q, dq
+
+
+def qkv_rope_bwd_fp8(dq, dk, dv, cos, sin, qkv_raw, v0, lam, dv0_acc, dlam, mix, add_dv0, B, L, H, hd, hdp, fmt,
+                     amax_in, amax_out):
+    """qkv_rope_bwd whose [B*L, 3D] result leaves the kernel as fp8 (row-major) -> (q, dq f32[1])"""
+    q, s = _fp8_out(B * L, 3 * H * hd, fmt, dq.device)
+    check(_lib.load().vds_qkv_rope_bwd_fp8(_p(dq), _p(dk), _p(dv), _p(cos), _p(sin), _p(qkv_raw), _p(v0), _p(lam),
+                                           _p(dv0_acc), _p(dlam), _p(q), 3 * H * hd, fmt, _p(amax_in), _p(amax_out),
+                                           _p(s), int(mix), int(add_dv0), B, L, H, hd, hdp, _stream()),
+          "vds_qkv_rope_bwd_fp8")
+    return q, s
+
+
 def rmsnorm_mod_bwd(dy, x, w, mod, shift_col, scale_col, rstd, dres, dmod, dw, B, L):
     D = x.shape[1]
     dx = torch.empty(B * L, D, dtype=bf16, device=x.device)
