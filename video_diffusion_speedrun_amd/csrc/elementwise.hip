@@ -42,10 +42,13 @@ struct QOut {
 template <int QF>
 struct QState {
   float scale, fmax;
-  unsigned mx;
+  unsigned mx, seen;
   __device__ __forceinline__ void init(const QOut& qo, bool writer) {
     fmax = fp8_fmax(QF);
     const float am = *qo.amax_in;
+    // the running maximum is read HERE, together with the wave's first data loads: read at the end it would add an
+    // exposed L2 round trip to a wave that lives for one row (a stale value only costs a redundant atomic)
+    seen = qo.amax_out ? __atomic_load_n(reinterpret_cast<const unsigned*>(qo.amax_out), __ATOMIC_RELAXED) : 0u;
     scale = am > 0.f ? fmax / am : 1.0f;
     mx = 0u;
     if (writer && qo.dq_out) *qo.dq_out = am > 0.f ? am / fmax : 1.0f;
@@ -66,8 +69,7 @@ struct QState {
     if (!qo.amax_out) return;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-    unsigned* a = reinterpret_cast<unsigned*>(qo.amax_out);
-    if ((threadIdx.x & 63) == 0 && mx > __atomic_load_n(a, __ATOMIC_RELAXED)) atomicMax(a, mx);
+    if ((threadIdx.x & 63) == 0 && mx > seen) atomicMax(reinterpret_cast<unsigned*>(qo.amax_out), mx);
   }
 };
 
