@@ -91,6 +91,9 @@ class AmaxHistory:
 
     def __init__(self, n: int, device):
         self.tab = torch.zeros(n, 2, dtype=f32, device=device)
+        # slot tables of the producer kernels that emit fp8 themselves (vds.h: VDS_AMAX_SLOTS x VDS_AMAX_SLOT_STRIDE
+        # floats per tensor; the current amax of such a tensor is the maximum over its table)
+        self.slot_tab = torch.zeros(n, ops.AMAX_SLOTS * ops.AMAX_SLOT_STRIDE, dtype=f32, device=device)
         self.ready = False
         self._fwd_seen = False   # a training forward recorded its rows since the last roll
         self._bwd_seen = False   # ... and its backward completed (host flag set by DiT._backward_impl)
@@ -98,6 +101,8 @@ class AmaxHistory:
     def roll(self):
         if self._fwd_seen:
             cur = self.tab[:, 1]
+            torch.maximum(cur, self.slot_tab.amax(dim=1), out=cur)
+            self.slot_tab.zero_()
             self.tab[:, 0].copy_(torch.where(cur > 0, cur, self.tab[:, 0]))
             cur.zero_()
             if self._bwd_seen:
@@ -112,6 +117,9 @@ class AmaxHistory:
 
     def cur(self, i: int):
         return self.tab[i, 1:2]
+
+    def slots(self, i: int):
+        return self.slot_tab[i]
 
 
 def supported(M: int, N: int, K: int) -> bool:
