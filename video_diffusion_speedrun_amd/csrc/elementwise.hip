@@ -48,8 +48,8 @@ struct QOut {
 };
 template <int QF>
 struct QState {
-  float scale, fmax;
-  unsigned mx, seen;
+  float scale, fmax, mxf;
+  unsigned seen;
   unsigned* slot;
   __device__ __forceinline__ void init(const QOut& qo, bool writer, unsigned wave_id) {
     fmax = fp8_fmax(QF);
@@ -58,7 +58,7 @@ struct QState {
                          : nullptr;
     seen = slot ? __atomic_load_n(slot, __ATOMIC_RELAXED) : 0u;
     scale = am > 0.f ? fmax / am : 1.0f;
-    mx = 0u;
+    mxf = 0.f;
     if (writer && qo.dq_out) *qo.dq_out = am > 0.f ? am / fmax : 1.0f;
   }
   // 8 results -> 8 fp8 bytes
@@ -66,14 +66,16 @@ struct QState {
     const u32x4 pk = pack8(o);
     float v[8];
     unpack8(pk, v);
+    // (these kernels sit close to VALU-bound with the conversion added: v_max3 with |.| modifiers and v_med3 keep it short)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) mx = max(mx, max((pk[e] << 16) & 0x7fffffffu, pk[e] & 0x7fff0000u));
+    for (int e = 0; e < 4; ++e) mxf = __builtin_fmaxf(mxf, __builtin_fmaxf(__builtin_fabsf(v[2 * e]), __builtin_fabsf(v[2 * e + 1])));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * scale, -fmax), fmax);
+    for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * scale, -fmax, fmax);
     return u32x2{fp8_cvt4<QF>(v[0], v[1], v[2], v[3]), fp8_cvt4<QF>(v[4], v[5], v[6], v[7])};
   }
   __device__ __forceinline__ void finish() {  // once per wave, at its end
     if (!slot) return;
+    unsigned mx = __float_as_uint(mxf);  // non-negative floats order like their bit patterns
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
     if ((threadIdx.x & 63) == 0 && mx > seen) atomicMax(slot, mx);
