@@ -98,15 +98,18 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
   if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0, (unsigned)row);
   const int b = (int)(row / L);
   const int nch = D >> 3;
-  float v[NC][8];
+  u32x4 raw[NC];  // the row stays packed between the two passes (the fp8 form needs the registers: 8 waves / SIMD)
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
+    raw[i] = u32x4{0u, 0u, 0u, 0u};
     if (c < nch) {
-      unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + c * 8), v[i]);
+      raw[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
+      float v[8];
+      unpack8(raw[i], v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+      for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
     }
   }
   ss = wave_sum(ss);
@@ -117,13 +120,14 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
-      float sh[8], sc[8], o[8], wv[8];
+      float sh[8], sc[8], o[8], wv[8], v[8];
       load8f(mrow + shift_col + c * 8, sh);
       load8f(mrow + scale_col + c * 8, sc);
       if (w) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv);
+      unpack8(raw[i], v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float xn = v[i][e] * r;
+        float xn = v[e] * r;
         if (w) xn *= wv[e];
         o[e] = xn * (1.0f + sc[e]) + sh[e];
       }
