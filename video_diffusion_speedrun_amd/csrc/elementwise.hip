@@ -96,15 +96,14 @@ template <int NC, int QF = -1>
 __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, long ldx, const bf16_t* w,
                                                               const float* mod, long ldmod, int shift_col,
                                                               int scale_col, bf16_t* y, long ldy, float* rstd,
-                                                              int B, int L, int D, float eps, QOut qo, int rpw) {
+                                                              int B, int L, int D, float eps, QOut qo) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long row0 = ((long)blockIdx.x * 4 + wave) * rpw;  // rpw consecutive rows per wave
-  if (row0 >= (long)B * L) return;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= (long)B * L) return;
   QState<(QF < 0 ? 0 : QF)> qs;
-  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0, blockIdx.x * 4 + wave);
-  const int nch = D >> 3;
-  for (long row = row0; row < min(row0 + rpw, (long)B * L); ++row) {
+  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0, (unsigned)row);
   const int b = (int)(row / L);
+  const int nch = D >> 3;
   // Every load is UNCONDITIONAL (lanes past the row end re-read its last chunk and are masked afterwards): behind an
   // `if (c < nch)` hipcc emits one exec-masked block per chunk with its own s_waitcnt vmcnt(0), i.e. the three chunk
   // loads of a row -- and later the three modulation loads -- became six serialised round trips per wave.
@@ -115,8 +114,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
     const int cc = min(lane + 64 * i, nch - 1);
     raw[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + cc * 8);
   }
-  if constexpr (QF >= 0)
-    if (row == row0) qs.peek();
+  if constexpr (QF >= 0) qs.peek();
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     if (lane + 64 * i >= nch) raw[i] = u32x4{0u, 0u, 0u, 0u};
@@ -156,7 +154,6 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
     } else {
       if (c < nch) *reinterpret_cast<u32x4*>(y + row * ldy + c * 8) = pack8(o);
     }
-  }
   }
   if constexpr (QF >= 0) qs.finish();
 }
@@ -1089,17 +1086,6 @@ inline int rows_per_block_for(int L, int B) {
     else return VDS_ERR_UNSUPPORTED;               \
   } while (0)
 
-// rows per wave of rmsnorm_mod_fwd (VDS_RMS_ROWS: experiments)
-static int rms_rows_per_wave(long rows) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VDS_RMS_ROWS");
-    v = e ? atoi(e) : 1;
-    if (v < 1) v = 1;
-  }
-  return rows >= 65536 ? v : 1;
-}
-
 extern "C" int vds_rmsnorm_mod_fwd(const void* x, int64_t ldx, const void* w, const float* mod, int64_t ldmod,
                                    int32_t shift_col, int32_t scale_col, void* y, int64_t ldy, float* rstd,
                                    int32_t B, int32_t L, int32_t D, float eps, vds_stream_t stream) {
@@ -1108,11 +1094,10 @@ extern "C" int vds_rmsnorm_mod_fwd(const void* x, int64_t ldx, const void* w, co
   const long rows = (long)B * L;
   hipStream_t s = (hipStream_t)stream;
   vdsprof::Scope ps(VDS_PROF_RMSNORM_FWD, s, 0.0, 4.0 * rows * D + 4.0 * rows);
-  const int rpw = rms_rows_per_wave(rows);
 #define CALL(NC)                                                                                              \
-  hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC>), dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, s, \
+  hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,          \
                      (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, \
-                     (bf16_t*)y, (long)ldy, rstd, B, L, D, eps, QOut{}, rpw)
+                     (bf16_t*)y, (long)ldy, rstd, B, L, D, eps, QOut{})
   NC_DISPATCH(D, CALL);
 #undef CALL
   return ok();
@@ -1133,17 +1118,16 @@ extern "C" int vds_rmsnorm_mod_fwd_fp8(const void* x, int64_t ldx, const void* w
   hipStream_t s = (hipStream_t)stream;
   const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_slots, dq_out};
   vdsprof::Scope ps(VDS_PROF_RMSNORM_FWD, s, 0.0, 3.0 * rows * D + 4.0 * rows);
-  const int rpw = rms_rows_per_wave(rows);
 #define CALL(NC)                                                                                               \
   do {                                                                                                         \
     if (fmt == 0)                                                                                              \
-      hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC, 0>), dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, s, \
+      hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC, 0>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,    \
                          (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, \
-                         (bf16_t*)nullptr, 0L, rstd, B, L, D, eps, qo, rpw);                                   \
+                         (bf16_t*)nullptr, 0L, rstd, B, L, D, eps, qo);                                        \
     else                                                                                                       \
-      hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC, 1>), dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, s, \
+      hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,    \
                          (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, \
-                         (bf16_t*)nullptr, 0L, rstd, B, L, D, eps, qo, rpw);                                   \
+                         (bf16_t*)nullptr, 0L, rstd, B, L, D, eps, qo);                                        \
   } while (0)
   NC_DISPATCH(D, CALL);
 #undef CALL
