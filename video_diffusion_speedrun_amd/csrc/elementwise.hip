@@ -67,9 +67,8 @@ struct QState {
     if (slot) seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // 8 results -> 8 fp8 bytes
-  __device__ __forceinline__ u32x2 cvt(const float (&o)[8], bool live = true) {
-    u32x4 pk = pack8(o);
-    if (!live) pk = u32x4{0u, 0u, 0u, 0u};  // a lane past the row end (its loads were clamped, not skipped)
+  __device__ __forceinline__ u32x2 cvt(const float (&o)[8]) {
+    const u32x4 pk = pack8(o);
     float v[8];
     unpack8(pk, v);
     // (these kernels sit close to VALU-bound with the conversion added: v_max3 with |.| modifiers and v_med3 keep it short)
@@ -104,55 +103,42 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
   if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0, (unsigned)row);
   const int b = (int)(row / L);
   const int nch = D >> 3;
-  // Every load is UNCONDITIONAL (lanes past the row end re-read its last chunk and are masked afterwards): behind an
-  // `if (c < nch)` hipcc emits one exec-masked block per chunk with its own s_waitcnt vmcnt(0), i.e. the three chunk
-  // loads of a row -- and later the three modulation loads -- became six serialised round trips per wave.
   u32x4 raw[NC];  // the row stays packed between the two passes (the fp8 form needs the registers: 8 waves / SIMD)
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
-    const int cc = min(lane + 64 * i, nch - 1);
-    raw[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + cc * 8);
+    const int c = lane + 64 * i;
+    raw[i] = u32x4{0u, 0u, 0u, 0u};
+    if (c < nch) {
+      raw[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
+      float v[8];
+      unpack8(raw[i], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+    }
   }
   if constexpr (QF >= 0) qs.peek();
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    if (lane + 64 * i >= nch) raw[i] = u32x4{0u, 0u, 0u, 0u};
-    float v[8];
-    unpack8(raw[i], v);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
-  }
   ss = wave_sum(ss);
   const float r = rsqrtf(ss / (float)D + eps);
   if (lane == 0) rstd[row] = r;
   const float* mrow = mod + (long)b * ldmod;
-  float sh[NC][8], sc[NC][8];
-  u32x4 wr[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int cc = min(lane + 64 * i, nch - 1);
-    load8f(mrow + shift_col + cc * 8, sh[i]);
-    load8f(mrow + scale_col + cc * 8, sc[i]);
-    if (w) wr[i] = *reinterpret_cast<const u32x4*>(w + cc * 8);
-  }
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
-    float o[8], wv[8], v[8];
-    if (w) unpack8(wr[i], wv);
-    unpack8(raw[i], v);
+    if (c < nch) {
+      float sh[8], sc[8], o[8], wv[8], v[8];
+      load8f(mrow + shift_col + c * 8, sh);
+      load8f(mrow + scale_col + c * 8, sc);
+      if (w) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv);
+      unpack8(raw[i], v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float xn = v[e] * r;
-      if (w) xn *= wv[e];
-      o[e] = xn * (1.0f + sc[i][e]) + sh[i][e];
-    }
-    if constexpr (QF >= 0) {
-      const u32x2 qv = qs.cvt(o, c < nch);
-      if (c < nch) *reinterpret_cast<u32x2*>(qo.q + row * qo.ldq + c * 8) = qv;
-    } else {
-      if (c < nch) *reinterpret_cast<u32x4*>(y + row * ldy + c * 8) = pack8(o);
+      for (int e = 0; e < 8; ++e) {
+        float xn = v[e] * r;
+        if (w) xn *= wv[e];
+        o[e] = xn * (1.0f + sc[e]) + sh[e];
+      }
+      if constexpr (QF >= 0) *reinterpret_cast<u32x2*>(qo.q + row * qo.ldq + c * 8) = qs.cvt(o);
+      else *reinterpret_cast<u32x4*>(y + row * ldy + c * 8) = pack8(o);
     }
   }
   if constexpr (QF >= 0) qs.finish();
