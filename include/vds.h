@@ -117,30 +117,28 @@ int vds_quant_fp8(const void* x, int64_t ldx, int32_t M, int32_t K, int32_t fmt,
 /* qt[k,m] = q[m,k] for a one-byte-per-element matrix q[M,K] (row stride ldq; K, ldq multiples of 16, ldt of 4): the
  * k-contiguous copy of an fp8 operand whose row-major copy came straight out of its producer (the *_fp8 entry points
  * below).  1 B read + 1 B written per element against 2 + 1 + 1 of a vds_quant_fp8 pass over the bf16 tensor. */
-#define VDS_AMAX_SLOTS 64
-#define VDS_AMAX_SLOT_STRIDE 32
 int vds_transpose_fp8(const void* q, int64_t ldq, int32_t M, int32_t K, void* qt, int64_t ldt, vds_stream_t stream);
 
 /* fp8-emitting forms of three producers of the fp8 GEMMs' operands (config 5): the bf16 result of the plain entry
  * point is not written; instead each value, rounded to bf16 first, is scaled by fmax / *amax_in (delayed scaling:
  * the amax the previous step recorded; 0 -> scale 1) and cast with saturation to q[rows, ldq] (fmt 0 = e4m3fn,
  * 1 = e5m2; ldq a multiple of 8) -- bit-identical to vds_quant_fp8 of the plain result.  *dq_out = *amax_in / fmax
- * (may be NULL).  max |result| is recorded in a slot table (may be NULL): amax_slots[VDS_AMAX_SLOTS *
- * VDS_AMAX_SLOT_STRIDE] f32, slot s at index s * VDS_AMAX_SLOT_STRIDE, each wave raising one slot; the tensor's amax
- * is the maximum over the table (these kernels run ~10^5 short waves per launch: one shared word would serialise their
- * atomics or cost every wave a read of it; the caller zeroes the table and reduces it).  All other arguments as in
+ * (may be NULL).  max |result| is recorded per wave with plain stores (amax_part, f32 [B*L], may be NULL): entry w
+ * receives the maximum over the rows wave w handled -- one entry per row / token for the RMSNorm and RoPE kernels, the
+ * first 4 * (number of workgroups) entries for gate backward -- and the tensor's amax is the maximum over the array
+ * (the caller zeroes it before the launch and reduces it afterwards; no atomics: ~10^5 short waves per launch).  All other arguments as in
  * vds_rmsnorm_mod_fwd / vds_gate_bwd / vds_qkv_rope_bwd (the latter needs hdp % 8 == 0 and H*hd <= 2048, else
  * VDS_ERR_UNSUPPORTED). */
 int vds_rmsnorm_mod_fwd_fp8(const void* x, int64_t ldx, const void* w, const float* mod, int64_t ldmod,
                             int32_t shift_col, int32_t scale_col, void* q, int64_t ldq, int32_t fmt,
-                            const float* amax_in, float* amax_slots, float* dq_out, float* rstd, int32_t B, int32_t L,
+                            const float* amax_in, float* amax_part, float* dq_out, float* rstd, int32_t B, int32_t L,
                             int32_t D, float eps, vds_stream_t stream);
 int vds_gate_bwd_fp8(const void* dxn, int64_t lddxn, const void* y, int64_t ldy, const float* mod, int64_t ldmod,
-                     int32_t gate_col, void* q, int64_t ldq, int32_t fmt, const float* amax_in, float* amax_slots,
+                     int32_t gate_col, void* q, int64_t ldq, int32_t fmt, const float* amax_in, float* amax_part,
                      float* dq_out, float* dmod, float* dbias, int32_t B, int32_t L, int32_t D, vds_stream_t stream);
 int vds_qkv_rope_bwd_fp8(const void* dq, const void* dk, const void* dv, const float* cosb, const float* sinb,
                          const void* qkv_raw, const void* v0, const void* lam, float* dv0_acc, float* dlam, void* q,
-                         int64_t ldq, int32_t fmt, const float* amax_in, float* amax_slots, float* dq_out, int32_t mix,
+                         int64_t ldq, int32_t fmt, const float* amax_in, float* amax_part, float* dq_out, int32_t mix,
                          int32_t add_dv0, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t hdp,
                          vds_stream_t stream);
 

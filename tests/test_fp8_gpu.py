@@ -146,7 +146,6 @@ def _same_as_quant(ops, name, q, dq, rec, plain, fmt, old):
     q2, _, dq2 = ops.quant_fp8(plain, fmt, old, amax_out=rec2)
     assert torch.equal(q.view(torch.uint8), q2.view(torch.uint8)), name
     assert dq.item() == dq2.item() and rec.max().item() == rec2.item() == plain.float().abs().max().item(), name
-    assert (rec.reshape(ops.AMAX_SLOTS, ops.AMAX_SLOT_STRIDE)[:, 1:] == 0).all()  # one word per 128-byte slot
 
 
 @pytest.mark.parametrize("M,K", [(128, 128), (300, 144), (516, 1152), (4, 16)])
@@ -166,7 +165,7 @@ def test_rmsnorm_mod_fwd_emits_fp8(ops, fmt, D, with_w):
     mod = (gen(B, 9 * D, seed=52).float() * 0.5).cuda()
     y, rstd = ops.rmsnorm_mod_fwd(x, w, mod, 3 * D, 4 * D, B, L)
     old = y.float().abs().max().reshape(1) * 0.8  # an older, smaller amax: saturation is exercised
-    rec = torch.zeros(ops.AMAX_SLOTS * ops.AMAX_SLOT_STRIDE, device="cuda")
+    rec = torch.zeros(B * L, device="cuda")
     q, dq, rstd2 = ops.rmsnorm_mod_fwd_fp8(x, w, mod, 3 * D, 4 * D, B, L, fmt, old, rec)
     assert torch.equal(rstd, rstd2)
     _same_as_quant(ops, "rmsnorm", q, dq, rec, y, fmt, old)
@@ -181,7 +180,7 @@ def test_gate_bwd_emits_fp8(ops, fmt):
     dbias, dbias2 = (torch.zeros(D, dtype=f32, device="cuda") for _ in range(2))
     dy = ops.gate_bwd(dxn, y, mod, 5 * D, dmod, dbias, B, L)
     old = dy.float().abs().max().reshape(1) * 0.9
-    rec = torch.zeros(ops.AMAX_SLOTS * ops.AMAX_SLOT_STRIDE, device="cuda")
+    rec = torch.zeros(B * L, device="cuda")
     q, dq = ops.gate_bwd_fp8(dxn, y, mod, 5 * D, dmod2, dbias2, B, L, fmt, old, rec)
     _same_as_quant(ops, "gate_bwd", q, dq, rec, dy, fmt, old)
     assert torch.equal(dmod, dmod2) or (dmod - dmod2).abs().max().item() <= 1e-5 * dmod.abs().max().item()
@@ -213,7 +212,7 @@ def test_qkv_rope_bwd_emits_fp8(ops, hd, hdp, H, mix):
             old = plain.float().abs().max().reshape(1) * 0.7
             outs.append((dv0, dlam))
         else:
-            rec = torch.zeros(ops.AMAX_SLOTS * ops.AMAX_SLOT_STRIDE, device="cuda")
+            rec = torch.zeros(B * L, device="cuda")
             q, s = ops.qkv_rope_bwd_fp8(*args, 1, old, rec)
             _same_as_quant(ops, "qkv_rope_bwd", q, s, rec, plain, 1, old)
             assert torch.equal(dv0, outs[0][0])

@@ -26,7 +26,7 @@ x = torch.randn(B * L, D, device="cuda").to(bf16)
 y = torch.randn(B * L, D, device="cuda").to(bf16)
 mod = torch.randn(B, 9 * D, device="cuda") * 0.3
 amax = torch.full((1,), 6.0, device="cuda")
-slots = torch.zeros(ops.AMAX_SLOTS * ops.AMAX_SLOT_STRIDE, device="cuda")
+slots = torch.zeros(B * L, device="cuda")
 dmod = torch.zeros(B, 9 * D, device="cuda")
 print(f"rmsnorm_mod_fwd bf16      {timeit(lambda: ops.rmsnorm_mod_fwd(x, None, mod, 0, D, B, L)):8.1f} us")
 print(f"rmsnorm_mod_fwd fp8       {timeit(lambda: ops.rmsnorm_mod_fwd_fp8(x, None, mod, 0, D, B, L, 0, amax, slots)):8.1f} us")

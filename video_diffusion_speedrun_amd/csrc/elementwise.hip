@@ -32,39 +32,31 @@ __device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
 // as fp8 (QF = 0: e4m3, 1: e5m2) instead of bf16: the value is rounded to bf16 first, then scaled by fmax / *amax_in
 // (the previous step's amax: delayed scaling) and cast with saturation, i.e. bit-identical to vds_quant_fp8 of the
 // bf16 result; amax_in / fmax goes to *dq_out.
-// max |x| of the bf16 values is recorded in a SLOT TABLE, amax_slots[VDS_AMAX_SLOTS * VDS_AMAX_SLOT_STRIDE] (one
-// 128-byte line per slot; the tensor's amax is the maximum over the table, which the caller takes).  These kernels run
-// ~10^5 one-row waves per launch: one shared maximum would either serialise their atomics on one address (~10 ns each)
-// or, filtered by a read of the running value, add an exposed L2 round trip to every wave (measured: 8.2 -> 12.9 ms
-// per step for RMSNorm+modulate; filtered by a read at wave start instead: 19 ms, the first ~10^4 waves all see 0).
-// With 64 slots, each wave reads its slot together with its first data loads and only a wave that raises it issues
-// an atomic.
+// max |x| of the bf16 values is recorded PER WAVE with a plain store: amax_part[w] = maximum over the rows wave w
+// handled (w < B*L); the tensor's amax is the maximum over the array, which the caller takes.  These kernels run up to
+// ~10^5 one-row waves per launch, and every shared-word scheme measured worse on RMSNorm+modulate (101 us per launch
+// without recording): one atomic max filtered by a read of the running value at the end of the wave 128 us (an exposed
+// round trip per wave), filtered by a read at wave start 230 us (the first ~10^4 waves all see 0 and their atomics
+// serialise), 64 slots with the read issued early 116-119 us (a device-coherent read crosses the XCDs' private L2s
+// and, loads returning in order, holds up the modulation loads behind it).
 struct QOut {
   unsigned char* q;       // [rows, ldq] fp8, row-major (the transposed copy is vds_transpose_fp8's job)
   long ldq;
   const float* amax_in;
-  float* amax_slots;      // or null
+  float* amax_part;       // f32 [B*L] or null
   float* dq_out;          // or null
 };
 template <int QF>
 struct QState {
   float scale, fmax, mxf;
-  unsigned seen;
-  unsigned* slot;
-  __device__ __forceinline__ void init(const QOut& qo, bool writer, unsigned wave_id) {
+  float* part;
+  __device__ __forceinline__ void init(const QOut& qo, bool writer, long wave_id) {
     fmax = fp8_fmax(QF);
     const float am = *qo.amax_in;
-    slot = qo.amax_slots ? reinterpret_cast<unsigned*>(qo.amax_slots) + (wave_id % VDS_AMAX_SLOTS) * VDS_AMAX_SLOT_STRIDE
-                         : nullptr;
-    seen = 0u;
+    part = qo.amax_part ? qo.amax_part + wave_id : nullptr;
     scale = am > 0.f ? fmax / am : 1.0f;
     mxf = 0.f;
     if (writer && qo.dq_out) *qo.dq_out = am > 0.f ? am / fmax : 1.0f;
-  }
-  // read the slot: call AFTER the wave's first data loads are issued (loads return in order: in front of them this
-  // L2-coherent read would sit on the critical path of every row; measured 101 -> 116 us per launch)
-  __device__ __forceinline__ void peek() {
-    if (slot) seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // 8 results -> 8 fp8 bytes
   __device__ __forceinline__ u32x2 cvt(const float (&o)[8]) {
@@ -79,11 +71,9 @@ struct QState {
     return u32x2{fp8_cvt4<QF>(v[0], v[1], v[2], v[3]), fp8_cvt4<QF>(v[4], v[5], v[6], v[7])};
   }
   __device__ __forceinline__ void finish() {  // once per wave, at its end
-    if (!slot) return;
-    unsigned mx = __float_as_uint(mxf);  // non-negative floats order like their bit patterns
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-    if ((threadIdx.x & 63) == 0 && mx > seen) __hip_atomic_fetch_max(slot, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!part) return;
+    const float m = wave_max(mxf);
+    if ((threadIdx.x & 63) == 0) *part = m;
   }
 };
 
@@ -100,7 +90,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= (long)B * L) return;
   QState<(QF < 0 ? 0 : QF)> qs;
-  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0, (unsigned)row);
+  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0, row);
   const int b = (int)(row / L);
   const int nch = D >> 3;
   u32x4 raw[NC];  // the row stays packed between the two passes (the fp8 form needs the registers: 8 waves / SIMD)
@@ -117,7 +107,6 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
       for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
     }
   }
-  if constexpr (QF >= 0) qs.peek();
   ss = wave_sum(ss);
   const float r = rsqrtf(ss / (float)D + eps);
   if (lane == 0) rstd[row] = r;
@@ -286,7 +275,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
   float gt[NC][8], a_g[NC][8], a_b[NC][8];
   QState<(QF < 0 ? 0 : QF)> qs;
   if constexpr (QF >= 0)
-    qs.init(qo, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave);
+    qs.init(qo, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, ((long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave);
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + 64 * i;
@@ -294,7 +283,6 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
     for (int e = 0; e < 8; ++e) { a_g[i][e] = 0.f; a_b[i][e] = 0.f; gt[i][e] = 0.f; }
     if (c < nch) load8f(mod + (long)b * ldmod + gate_col + c * 8, gt[i]);
   }
-  if constexpr (QF >= 0) qs.peek();
   for (int l = l0 + wave; l < l1; l += 4) {
     const long row = (long)b * L + l;
 #pragma unroll
@@ -578,7 +566,7 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
   const bool live = tok < (long)B * L;
   float dl = 0.f;
   QState<(QF < 0 ? 0 : QF)> qs;
-  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0, (unsigned)tok);
+  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0, tok);
   if (live) {
     const int b = (int)(tok / L), l = (int)(tok % L);
     const int D = H * hd, nch = D >> 3, cph = hd >> 3, half = hd >> 1;
@@ -607,8 +595,7 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    if constexpr (QF >= 0) qs.peek();
-    const float lam = mix ? bf2f(*lamp) : 0.f, oml = 1.0f - lam;
+      const float lam = mix ? bf2f(*lamp) : 0.f, oml = 1.0f - lam;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = lane + 64 * i;
@@ -671,7 +658,8 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
       else *reinterpret_cast<u32x4*>(dst + 2 * D + c * 8) = pack8(g);
     }
   }
-  if constexpr (QF >= 0) qs.finish();
+  if constexpr (QF >= 0)
+    if (live) qs.finish();  // (wave-uniform; an idle tail wave must not overwrite entry 0)
   if (mix) {
     dl = wave_sum(dl);
     if (lane == 0) red[wave] = dl;
@@ -1095,14 +1083,14 @@ static bool qout_ok(const void* q, int64_t ldq, int32_t fmt, const float* amax_i
 
 extern "C" int vds_rmsnorm_mod_fwd_fp8(const void* x, int64_t ldx, const void* w, const float* mod, int64_t ldmod,
                                        int32_t shift_col, int32_t scale_col, void* q, int64_t ldq, int32_t fmt,
-                                       const float* amax_in, float* amax_slots, float* dq_out, float* rstd, int32_t B,
+                                       const float* amax_in, float* amax_part, float* dq_out, float* rstd, int32_t B,
                                        int32_t L, int32_t D, float eps, vds_stream_t stream) {
   if (!x || !mod || !rstd || (D & 7) || (ldx & 7) || (shift_col & 3) || (scale_col & 3) || (ldmod & 3) ||
       !qout_ok(q, ldq, fmt, amax_in))
     return VDS_ERR_ARG;
   const long rows = (long)B * L;
   hipStream_t s = (hipStream_t)stream;
-  const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_slots, dq_out};
+  const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_part, dq_out};
   vdsprof::Scope ps(VDS_PROF_RMSNORM_FWD, s, 0.0, 3.0 * rows * D + 4.0 * rows);
 #define CALL(NC)                                                                                               \
   do {                                                                                                         \
@@ -1166,13 +1154,13 @@ extern "C" int vds_gate_bwd(const void* dxn, int64_t lddxn, const void* y, int64
 
 extern "C" int vds_gate_bwd_fp8(const void* dxn, int64_t lddxn, const void* y, int64_t ldy, const float* mod,
                                 int64_t ldmod, int32_t gate_col, void* q, int64_t ldq, int32_t fmt,
-                                const float* amax_in, float* amax_slots, float* dq_out, float* dmod, float* dbias,
+                                const float* amax_in, float* amax_part, float* dq_out, float* dmod, float* dbias,
                                 int32_t B, int32_t L, int32_t D, vds_stream_t stream) {
   if (!dxn || !y || !mod || !dmod || (D & 7) || !qout_ok(q, ldq, fmt, amax_in)) return VDS_ERR_ARG;
   const int rpb = rows_per_block_for(L, B);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((L + rpb - 1) / rpb, B);
-  const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_slots, dq_out};
+  const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_part, dq_out};
   vdsprof::Scope ps(VDS_PROF_GATE_BWD, s, 0.0, 5.0 * B * L * D);
 #define CALL(NC)                                                                                                   \
   do {                                                                                                             \
@@ -1261,7 +1249,7 @@ extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, 
 extern "C" int vds_qkv_rope_bwd_fp8(const void* dq, const void* dk, const void* dv, const float* cosb,
                                     const float* sinb, const void* qkv_raw, const void* v0, const void* lam,
                                     float* dv0_acc, float* dlam, void* q, int64_t ldq, int32_t fmt,
-                                    const float* amax_in, float* amax_slots, float* dq_out, int32_t mix,
+                                    const float* amax_in, float* amax_part, float* dq_out, int32_t mix,
                                     int32_t add_dv0, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t hdp,
                                     vds_stream_t stream) {
   if (!dq || !dk || !dv || !cosb || !sinb || (hd & 7) || !qout_ok(q, ldq, fmt, amax_in)) return VDS_ERR_ARG;
@@ -1271,7 +1259,7 @@ extern "C" int vds_qkv_rope_bwd_fp8(const void* dq, const void* dk, const void* 
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_BWD, (hipStream_t)stream, 0.0, (mix ? 21.0 : 9.0) * B * L * H * hd);
   const int D = H * hd, lds = 4 * (4 * D + 4 * hd);
   const dim3 grid((unsigned)(((long)B * L + 3) / 4));
-  const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_slots, dq_out};
+  const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_part, dq_out};
 #define ROPE_BWD_Q(NI, F)                                                                                             \
   hipLaunchKernelGGL((qkv_rope_bwd_tok_kernel<NI, F>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dq, \
                      (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw, (const bf16_t*)v0,    \

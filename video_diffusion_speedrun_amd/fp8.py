@@ -91,9 +91,10 @@ class AmaxHistory:
 
     def __init__(self, n: int, device):
         self.tab = torch.zeros(n, 2, dtype=f32, device=device)
-        # slot tables of the producer kernels that emit fp8 themselves (vds.h: VDS_AMAX_SLOTS x VDS_AMAX_SLOT_STRIDE
-        # floats per tensor; the current amax of such a tensor is the maximum over its table)
-        self.slot_tab = torch.zeros(n, ops.AMAX_SLOTS * ops.AMAX_SLOT_STRIDE, dtype=f32, device=device)
+        # per-wave partial maxima of the producer kernels that emit fp8 themselves (`ops.*_fp8`: one f32 per token
+        # row and tensor, plain stores; the current amax of such a tensor is the maximum over its row of this table),
+        # allocated by the first training forward that knows the token count
+        self.part_tab = None
         self.ready = False
         self._fwd_seen = False   # a training forward recorded its rows since the last roll
         self._bwd_seen = False   # ... and its backward completed (host flag set by DiT._backward_impl)
@@ -101,8 +102,9 @@ class AmaxHistory:
     def roll(self):
         if self._fwd_seen:
             cur = self.tab[:, 1]
-            torch.maximum(cur, self.slot_tab.amax(dim=1), out=cur)
-            self.slot_tab.zero_()
+            if self.part_tab is not None:
+                torch.maximum(cur, self.part_tab.amax(dim=1), out=cur)
+                self.part_tab.zero_()
             self.tab[:, 0].copy_(torch.where(cur > 0, cur, self.tab[:, 0]))
             cur.zero_()
             if self._bwd_seen:
@@ -118,8 +120,12 @@ class AmaxHistory:
     def cur(self, i: int):
         return self.tab[i, 1:2]
 
-    def slots(self, i: int):
-        return self.slot_tab[i]
+    def part(self, i: int, rows: int):
+        """the partial-maxima row of tensor i for a launch over `rows` token rows"""
+        if self.part_tab is None or self.part_tab.shape[1] < rows:
+            assert self.part_tab is None or not bool(self.part_tab.any()), "token count grew inside a step"
+            self.part_tab = torch.zeros(self.tab.shape[0], rows, dtype=f32, device=self.tab.device)
+        return self.part_tab[i]
 
 
 def supported(M: int, N: int, K: int) -> bool:

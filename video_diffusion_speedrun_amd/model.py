@@ -333,7 +333,7 @@ class DiTBlock(nn.Module):
         xn1 = xn3 = None
         if pemit:
             fq, fs, rstd1 = ops.rmsnorm_mod_fwd_fp8(X, Wo("norm1.weight"), mod, 0, D, B, L, F8.E4M3,
-                                                  hist.prev(6 * i + 2), hist.slots(6 * i + 2))
+                                                  hist.prev(6 * i + 2), hist.part(6 * i + 2, B * L))
             q_xn1 = F8.Q.from_rowmajor(fq, fs, save)
         else:
             xn1, rstd1 = ops.rmsnorm_mod_fwd(X, Wo("norm1.weight"), mod, 0, D, B, L)
@@ -369,7 +369,7 @@ class DiTBlock(nn.Module):
         # --- MLP (model.py:163-165)
         if pemit:
             fq, fs, rstd3 = ops.rmsnorm_mod_fwd_fp8(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L, F8.E4M3,
-                                                  hist.prev(6 * i + 3), hist.slots(6 * i + 3))
+                                                  hist.prev(6 * i + 3), hist.part(6 * i + 3, B * L))
             q_xn3 = F8.Q.from_rowmajor(fq, fs, save)
         else:
             xn3, rstd3 = ops.rmsnorm_mod_fwd(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L)
@@ -426,7 +426,7 @@ class DiTBlock(nn.Module):
         pemit = emit and not _NO_PRODUCER_EMIT
         if pemit:  # the fc2 output gradient leaves gate_bwd as e5m2
             fq, fs = ops.gate_bwd_fp8(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L, F8.E5M2,
-                                    hist.prev(6 * i + 4), hist.slots(6 * i + 4))
+                                    hist.prev(6 * i + 4), hist.part(6 * i + 4, B * L))
             q_dy = F8.Q.from_rowmajor(fq, fs, True)
             dy = None
         else:
@@ -494,7 +494,7 @@ class DiTBlock(nn.Module):
         # the qkv output gradient leaves the RoPE backward as e5m2 (a qkv bias gradient needs the bf16 tensor)
         emit_dqkv = pemit and not G.has(pre + "qkv.bias") and hdp % 8 == 0 and D <= 2048
         if emit_dqkv:
-            fq, fs = ops.qkv_rope_bwd_fp8(*rope_args, F8.E5M2, hist.prev(6 * i + 5), hist.slots(6 * i + 5))
+            fq, fs = ops.qkv_rope_bwd_fp8(*rope_args, F8.E5M2, hist.prev(6 * i + 5), hist.part(6 * i + 5, B * L))
             q_dqkv = F8.Q.from_rowmajor(fq, fs, True)
         else:
             dqkv = ops.qkv_rope_bwd(*rope_args)

@@ -103,7 +103,6 @@ def linear_dgrad(dy, W, pre: Optional[torch.Tensor] = None, colsum: Optional[tor
 # --------------------------------------------------------------------------- fp8 GEMM ----
 FP8_E4M3, FP8_E5M2 = 0, 1
 fp8_dtypes = (torch.float8_e4m3fn, torch.float8_e5m2)
-AMAX_SLOTS, AMAX_SLOT_STRIDE = 64, 32  # vds.h: VDS_AMAX_SLOTS, VDS_AMAX_SLOT_STRIDE
 
 
 def absmax(x: torch.Tensor, amax: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -258,41 +257,41 @@ def transpose_fp8(q: torch.Tensor) -> torch.Tensor:
     return qt
 
 
-def _slots_ok(t):
-    assert t is None or (t.dtype == f32 and t.is_contiguous() and t.numel() >= AMAX_SLOTS * AMAX_SLOT_STRIDE)
+def _part_ok(t, rows):
+    assert t is None or (t.dtype == f32 and t.is_contiguous() and t.numel() >= rows)
 
 
-def rmsnorm_mod_fwd_fp8(x, w, mod, shift_col, scale_col, B, L, fmt, amax_in, amax_slots, eps=1e-6):
+def rmsnorm_mod_fwd_fp8(x, w, mod, shift_col, scale_col, B, L, fmt, amax_in, amax_part, eps=1e-6):
     """rmsnorm_mod_fwd whose result leaves the kernel as fp8 (row-major) -> (q, dq f32[1], rstd);
-    amax_slots: f32 [AMAX_SLOTS * AMAX_SLOT_STRIDE] table whose maximum accumulates max |result| (or None)"""
-    _slots_ok(amax_slots)
+    amax_part: f32 [>= B*L], zeroed by the caller: per-wave maxima of |result|; its maximum is the tensor's amax (or None)"""
+    _part_ok(amax_part, B * L)
     D = x.shape[1]
     q, dq = _fp8_out(B * L, D, fmt, x.device)
     rstd = torch.empty(B * L, dtype=f32, device=x.device)
     check(_lib.load().vds_rmsnorm_mod_fwd_fp8(_p(x), x.stride(0), _p(w), _p(mod), mod.stride(0), shift_col, scale_col,
-                                              _p(q), D, fmt, _p(amax_in), _p(amax_slots), _p(dq), _p(rstd), B, L, D,
+                                              _p(q), D, fmt, _p(amax_in), _p(amax_part), _p(dq), _p(rstd), B, L, D,
                                               eps, _stream()), "vds_rmsnorm_mod_fwd_fp8")
     return q, dq, rstd
 
 
-def gate_bwd_fp8(dxn, y, mod, gate_col, dmod, dbias, B, L, fmt, amax_in, amax_slots):
+def gate_bwd_fp8(dxn, y, mod, gate_col, dmod, dbias, B, L, fmt, amax_in, amax_part):
     """gate_bwd whose dy leaves the kernel as fp8 (row-major) -> (q, dq f32[1])"""
-    _slots_ok(amax_slots)
+    _part_ok(amax_part, B * L)
     D = y.shape[1]
     q, dq = _fp8_out(B * L, D, fmt, y.device)
     check(_lib.load().vds_gate_bwd_fp8(_p(dxn), dxn.stride(0), _p(y), y.stride(0), _p(mod), mod.stride(0), gate_col,
-                                       _p(q), D, fmt, _p(amax_in), _p(amax_slots), _p(dq), _p(dmod), _p(dbias), B, L, D,
+                                       _p(q), D, fmt, _p(amax_in), _p(amax_part), _p(dq), _p(dmod), _p(dbias), B, L, D,
                                        _stream()), "vds_gate_bwd_fp8")
     return q, dq
 
 
 def qkv_rope_bwd_fp8(dq, dk, dv, cos, sin, qkv_raw, v0, lam, dv0_acc, dlam, mix, add_dv0, B, L, H, hd, hdp, fmt,
-                     amax_in, amax_slots):
+                     amax_in, amax_part):
     """qkv_rope_bwd whose [B*L, 3D] result leaves the kernel as fp8 (row-major) -> (q, dq f32[1])"""
-    _slots_ok(amax_slots)
+    _part_ok(amax_part, B * L)
     q, s = _fp8_out(B * L, 3 * H * hd, fmt, dq.device)
     check(_lib.load().vds_qkv_rope_bwd_fp8(_p(dq), _p(dk), _p(dv), _p(cos), _p(sin), _p(qkv_raw), _p(v0), _p(lam),
-                                           _p(dv0_acc), _p(dlam), _p(q), 3 * H * hd, fmt, _p(amax_in), _p(amax_slots),
+                                           _p(dv0_acc), _p(dlam), _p(q), 3 * H * hd, fmt, _p(amax_in), _p(amax_part),
                                            _p(s), int(mix), int(add_dv0), B, L, H, hd, hdp, _stream()),
           "vds_qkv_rope_bwd_fp8")
     return q, s
