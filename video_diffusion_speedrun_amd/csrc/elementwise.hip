@@ -285,29 +285,19 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
   }
   for (int l = l0 + wave; l < l1; l += 4) {
     const long row = (long)b * L + l;
-    // all loads of the row first, unconditionally (a lane past the row end re-reads the last chunk; its sums land in
-    // columns >= D, which the reduction below drops): behind `if (c < nch)` hipcc emits one exec-masked block per
-    // chunk, each with its own wait -- three serialised round trips per row
-    u32x4 rd[NC], ry[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int cc = min(lane + 64 * i, nch - 1);
-      rd[i] = *reinterpret_cast<const u32x4*>(dxn + row * lddxn + cc * 8);
-      ry[i] = *reinterpret_cast<const u32x4*>(y + row * ldy + cc * 8);
-    }
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
-      float d[8], yv[8], o[8];
-      unpack8(rd[i], d);
-      unpack8(ry[i], yv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        a_g[i][e] += d[e] * yv[e];
-        o[e] = d[e] * gt[i][e];
-        a_b[i][e] += o[e];
-      }
       if (c < nch) {
+        float d[8], yv[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dxn + row * lddxn + c * 8), d);
+        unpack8(*reinterpret_cast<const u32x4*>(y + row * ldy + c * 8), yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          a_g[i][e] += d[e] * yv[e];
+          o[e] = d[e] * gt[i][e];
+          a_b[i][e] += o[e];
+        }
         if constexpr (QF >= 0) *reinterpret_cast<u32x2*>(qo.q + row * qo.ldq + c * 8) = qs.cvt(o);
         else *reinterpret_cast<u32x4*>(dy + row * lddy + c * 8) = pack8(o);
       }
