@@ -14,6 +14,10 @@ rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o c3b --output-format csv -- $
 for c in FETCH_SIZE WRITE_SIZE; do
   B=12 REPS=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o x --output-format csv -- $PY tools/prof_attn.py > "$OUT/pmc_$c.log" 2>&1
 done
+# 2b. the same two passes over the linear-layer GEMMs at the DiT-XL shapes (B = 12)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmcg_$c" -o x --output-format csv -- $PY tools/prof_gemm.py > "$OUT/pmcg_$c.log" 2>&1
+done
 # 3. SQ counters of the attention kernels (B = 6) and of the GEMMs (B = 12), 4 counters per pass
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
@@ -24,6 +28,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
   rocprofv3 --kernel-trace --pmc $set -d "$OUT/sq_gemm_$i" -o x --output-format csv -- $PY tools/prof_gemm.py > "$OUT/sq_gemm_$i.log" 2>&1
 done
 $PY tools/pmc_summary.py $(find "$OUT" -path "*pmc_*" -name "*counter_collection.csv") > "$OUT/attn_hbm_traffic_pmc.txt" 2>&1
+$PY tools/pmc_summary.py $(find "$OUT" -path "*pmcg_*" -name "*counter_collection.csv") > "$OUT/gemm_hbm_traffic_pmc.txt" 2>&1
 $PY tools/pmc_summary.py $(find "$OUT" -path "*sq_attn_*" -name "*counter_collection.csv") > "$OUT/attn_sq_counters.txt" 2>&1
 $PY tools/pmc_summary.py $(find "$OUT" -path "*sq_gemm_*" -name "*counter_collection.csv") > "$OUT/gemm_sq_counters.txt" 2>&1
 find "$OUT" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c3b_kernel_stats.csv"
