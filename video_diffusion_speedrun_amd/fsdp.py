@@ -27,6 +27,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -64,7 +66,11 @@ class ShardRuntime:
         self.cast_fn = cast_fn
         self.pg = process_group
         self.cuda = model._groups[0].device.type == "cuda"
-        self.comm = torch.cuda.Stream(device=model._groups[0].device) if self.cuda else None
+        # high-priority stream (as FSDP2's all-gather / reduce-scatter streams): a collective enqueued while a long
+        # attention / GEMM kernel fills the chip gets the next free workgroup slots instead of alternating with that
+        # kernel's remaining workgroups (VDS_COMM_PRIORITY=0: default priority, for A/B)
+        prio = int(os.environ.get("VDS_COMM_PRIORITY", "-1"))
+        self.comm = torch.cuda.Stream(device=model._groups[0].device, priority=prio) if self.cuda else None
         self.gather_ev = [None] * len(model._groups)
         self.n_all_gather = 0
         self.n_reduce_scatter = 0
