@@ -46,6 +46,7 @@ struct GemmP {
   unsigned a_bytes, b_bytes;
   int tiles_m, tiles_n;
   int group_m;
+  int joint_xcd;   // split-K launches: XCD-aware order over the joint (split, tile) list
   const float* sa; const float* sb;  // fp8 path: per-tensor dequantisation factors (device), else unused
   double prof_k;                      // contraction length in elements (profiler flop count)
   // fp8 path, optional: the epilogue also emits its result (gelu output / gelu' product) as fp8 (vds_fp8_out)
@@ -808,8 +809,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  int pid = blockIdx.x;
-  {
+  int pid = blockIdx.x, split = blockIdx.y;
+  if (p.split_k > 1 && p.joint_xcd) {
+    // split-K (weight gradients): the tiles of ONE split stream the same token range, so the (split, tile) list as a
+    // whole -- split-major -- is cut into 8 contiguous chunks, one per XCD (workgroups are handed to the XCDs round
+    // robin in flattened-id order): an XCD then streams one token range for a compact block of output tiles instead
+    // of a slice of every split
+    const int total = nwg * p.split_k;
+    int L = blockIdx.y * nwg + blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    split = L / nwg;
+    pid = L - split * nwg;
+  } else {
     int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -824,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   int kt_begin = 0, kt_end = kt_total;
   if (p.split_k > 1) {
     int per = (kt_total + p.split_k - 1) / p.split_k;
-    kt_begin = blockIdx.y * per;
+    kt_begin = split * per;
     kt_end = min(kt_total, kt_begin + per);
     if (kt_begin >= kt_end) return;
   }
@@ -1027,6 +1039,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     group_m = e ? atoi(e) : 4;  // groups of 4 row tiles (1024 rows) measured best at the DiT shapes
   }
   p.group_m = group_m;
+  p.joint_xcd = 0;
   if (a->layout == VDS_TN) {
     // weight gradients: few output tiles, every tile of a split streams the same token range; groups of 2 row tiles
     // measured 4-5 % faster than 4 at the DiT-XL shapes (106.4 -> 101.5 ms per step), 3 in between
@@ -1037,6 +1050,12 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
       if (group_m_tn < 1) group_m_tn = 1;
     }
     p.group_m = group_m_tn;
+    static int joint = -1;
+    if (joint < 0) {
+      const char* e = getenv("VDS_GEMM_TN_JOINT");
+      joint = e ? atoi(e) : 1;
+    }
+    p.joint_xcd = joint;
   }
   if (auto_split) {
     // weight gradient dW[M = out features, N = in features] = dy^T x over K = tokens: few output tiles, long K.
@@ -1171,6 +1190,7 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   p.a_bytes = (unsigned)abytes;
   p.b_bytes = (unsigned)bbytes;
   p.group_m = 4;
+  p.joint_xcd = 0;
   p.e_q = p.e_qt = nullptr; p.e_ldq = p.e_ldqt = 0;
   p.e_amax_in = nullptr; p.e_amax_out = p.e_dq_out = p.e_colsum = nullptr; p.e_fmt = 0;
   if (emit) {
