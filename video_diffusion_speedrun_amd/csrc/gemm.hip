@@ -1041,15 +1041,16 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   p.group_m = group_m;
   p.joint_xcd = 0;
   if (a->layout == VDS_TN) {
-    // weight gradients: few output tiles, every tile of a split streams the same token range; groups of 2 row tiles
-    // measured 4-5 % faster than 4 at the DiT-XL shapes (106.4 -> 101.5 ms per step), 3 in between
+    // weight gradients: few output tiles, every tile of a split streams the same token range.  Fixed groups of 2 row
+    // tiles measured 4-5 % faster than 4 at the DiT-XL shapes (106.4 -> 101.5 ms per step); 0 (default) = sized at the
+    // launch so that one XCD's chunk of the joint (split, tile) list is one group (tn_group below): 97 ms
     static int group_m_tn = -1;
     if (group_m_tn < 0) {
       const char* e = getenv("VDS_GEMM_GROUP_M_TN");
-      group_m_tn = e ? atoi(e) : 2;
-      if (group_m_tn < 1) group_m_tn = 1;
+      group_m_tn = e ? atoi(e) : 0;
+      if (group_m_tn < 0) group_m_tn = 0;
     }
-    p.group_m = group_m_tn;
+    p.group_m = group_m_tn ? group_m_tn : 2;
     static int joint = -1;
     if (joint < 0) {
       const char* e = getenv("VDS_GEMM_TN_JOINT");
@@ -1088,6 +1089,13 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
       if (best_tile == 2) {
         p.tiles_m = cdiv(a->M, 256);
         p.tiles_n = cdiv(a->N, 128);
+        if (p.joint_xcd && !getenv("VDS_GEMM_GROUP_M_TN")) {
+          // one XCD's chunk = (tiles x splits) / 8 consecutive entries of the split-major list: make it a block of
+          // whole tile rows of one split (qkv weight gradient: 14 x 9 tiles x 4 splits -> 7 rows x 9 columns per XCD)
+          const long chunk = ((long)p.tiles_m * p.tiles_n * p.split_k + 7) / 8;
+          long g = (chunk + p.tiles_n / 2) / p.tiles_n;
+          p.group_m = (int)(g < 1 ? 1 : (g > p.tiles_m ? p.tiles_m : g));
+        }
         return mid::launch<VDS_TN, VDS_EPI_F32>(p, s);
       }
       return launch<VDS_TN, VDS_EPI_F32>(p, s);
