@@ -481,15 +481,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
 
   // ---- tile id: XCD-aware + grouped order (as the 128^2 kernel) ---------------------------
   const int nwg = p.tiles_m * p.tiles_n;
-  int pid = blockIdx.x, split = blockIdx.y;
-  if (p.split_k > 1 && p.joint_xcd) {  // split-K: XCD-aware order over the joint (split, tile) list (see mid::gemm_kernel)
-    const int total = nwg * p.split_k;
-    int L = blockIdx.y * nwg + blockIdx.x;
-    const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
-    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    split = L / nwg;
-    pid = L - split * nwg;
-  } else {
+  int pid = blockIdx.x;
+  {
     int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -504,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   int kt_begin = 0, kt_end = kt_total;
   if (p.split_k > 1) {
     int per = (kt_total + p.split_k - 1) / p.split_k;
-    kt_begin = split * per;
+    kt_begin = blockIdx.y * per;
     kt_end = min(kt_total, kt_begin + per);
     if (kt_begin >= kt_end) return;
   }
@@ -1206,12 +1199,6 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   p.b_bytes = (unsigned)bbytes;
   p.group_m = 4;
   p.joint_xcd = 0;
-  if (p.split_k > 1 && !getenv("VDS_GEMM_FP8_NO_JOINT")) {  // weight gradients: as the bf16 256 x 128 path
-    p.joint_xcd = 1;
-    const long chunk = ((long)p.tiles_m * p.tiles_n * p.split_k + 7) / 8;
-    const long g = (chunk + p.tiles_n / 2) / p.tiles_n;
-    p.group_m = (int)(g < 1 ? 1 : (g > p.tiles_m ? p.tiles_m : g));
-  }
   p.e_q = p.e_qt = nullptr; p.e_ldq = p.e_ldqt = 0;
   p.e_amax_in = nullptr; p.e_amax_out = p.e_dq_out = p.e_colsum = nullptr; p.e_fmt = 0;
   if (emit) {
