@@ -348,7 +348,7 @@ def main():
             # operand read once, every result written once) against the HBM peak; MFMA classes as TFLOP/s
             out["kernel_rates"] = {
                 k: ({"TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1), "frac_of_peak": round(v["flops"] / v["ms"] / 1e9 / (2 * PEAK_BF16_TFLOPS if k == "gemm_fp8" else PEAK_BF16_TFLOPS), 4)}
-                    if v["flops"] > 0 else
+                    if v["flops"] > 0 and k != "attn_bwd_delta" else  # (the delta preprocess streams O and dO: HBM-bound)
                     {"GB/s": round(v["bytes"] / v["ms"] / 1e6, 1), "frac_of_peak": round(v["bytes"] / v["ms"] / 1e6 / PEAK_HBM_GBS, 4)})
                 for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}
             if args.breakdown:
