@@ -1135,7 +1135,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qrow0 = qt * 256 + wave * 64 + (lane & 15);  // query of block 0; block cb = + 16 cb
   const int hd_kv = p.hd + 8;
-  const bool wave_active = qt * 256 + wave * 64 < p.Lq;  // wave-uniform
 
   const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
   const srd_t rk = slice_srd(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, hd_kv);
@@ -1182,9 +1181,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
     }
     const char* kt = smem + par * 2 * TILE;
     const char* vt = kt + TILE;
-    // a wave whose 64 queries all lie past Lq (the last workgroup of a head: L = 8208 leaves 16 of its 256 rows) only
-    // takes part in the staging and the barriers: the chip is power-limited, MFMAs on rows nobody stores are not free
-    if (wave_active)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x4 s[2][4];
