@@ -361,6 +361,8 @@ int vds_adamw_multi_dev(const vds_adamw_tensor* desc_dev, const int32_t* chunk_t
  * all-pairs exchange over the point-to-point xGMI mesh (one ncclSend/ncclRecv per peer + a local averaging kernel
  * with a fixed summation order); it needs vds_reduce_scatter_workspace_bytes(shard_elems) bytes of caller memory. */
 #define VDS_COMM_ID_BYTES 128
+int vds_comm_available(void); /* VDS_OK when RCCL could be bound (local, no communication): every rank checks this and
+                                 the ranks agree on it BEFORE any of them enters the collective vds_comm_init */
 int vds_comm_unique_id(void* out, size_t bytes);
 int vds_comm_init(int32_t rank, int32_t world, const void* unique_id, size_t bytes);
 int vds_comm_info(int32_t* rank, int32_t* world, int32_t* rccl_version, int32_t* allpairs); /* NULLs allowed */

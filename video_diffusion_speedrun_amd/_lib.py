@@ -100,6 +100,7 @@ SIGNATURES = {
     "vds_cfg_euler_step": [c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i64, c_vp],
     "vds_adamw_multi": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32, c_vp],
     "vds_adamw_multi_dev": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_f32, c_vp],
+    "vds_comm_available": [],
     "vds_comm_unique_id": [c_vp, C.c_size_t],
     "vds_comm_init": [c_i32, c_i32, c_vp, C.c_size_t],
     "vds_comm_info": [c_vp, c_vp, c_vp, c_vp],

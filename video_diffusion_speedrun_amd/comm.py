@@ -20,7 +20,7 @@ import torch.distributed as dist
 from . import _lib
 
 ID_BYTES = 128
-_state = {"group": None, "active": False, "rank": 0, "world": 1}
+_state = {"group": None, "active": False, "rank": 0, "world": 1, "fallback": None}
 
 
 def enabled() -> bool:
@@ -45,34 +45,56 @@ def ensure(group=None) -> bool:
         raise RuntimeError("vds communicator already spans another process group; comm.destroy() it first")
     lib = _lib.load()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    buf = (C.c_ubyte * ID_BYTES)()
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+    def agree(ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) == 1
+
+    def fall_back(err):
+        import sys
+        _state["fallback"] = err or "another rank failed"
+        print(f"[vds comm] rank {rank}: the library's RCCL communicator is NOT in use ({_state['fallback']}); "
+              "collectives run on torch.distributed's RCCL communicator instead", file=sys.stderr, flush=True)
+        return False
+
+    # phase 1 -- local, no communication inside the library: RCCL binds (dlopen + symbols) and rank 0 draws the id.
+    # The ranks agree on it BEFORE anyone enters ncclCommInitRank (itself a collective: a rank that failed earlier
+    # would otherwise leave the others blocked inside it).
     err = None
-    if rank == 0:
+    buf = (C.c_ubyte * ID_BYTES)()
+    rc = lib.vds_comm_available()
+    if rc != 0:
+        err = f"vds_comm_available -> {rc} {lib.vds_last_error().decode()}"
+    elif rank == 0:
         rc = lib.vds_comm_unique_id(buf, ID_BYTES)
         if rc != 0:
             err = f"vds_comm_unique_id -> {rc} {lib.vds_last_error().decode()}"
-    box = [bytes(buf), err]
+    if not agree(err is None):
+        return fall_back(err)
+    box = [bytes(buf)]
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast_object_list(box, src=src, group=group)
-    ok = box[1] is None
-    if ok:
-        ident = (C.c_ubyte * ID_BYTES).from_buffer_copy(box[0])
-        rc = lib.vds_comm_init(rank, world, ident, ID_BYTES)
-        if rc != 0:
-            ok, err = False, f"vds_comm_init(rank={rank}, world={world}) -> {rc} {lib.vds_last_error().decode()}"
-    # every rank must take the same path: agree on success
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
-                        device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) != 1:
-        import sys
-        print(f"[vds comm] rank {rank}: the library's RCCL communicator is NOT in use ({err or 'another rank failed'}); "
-              "collectives run on torch.distributed's RCCL communicator instead", file=sys.stderr, flush=True)
+    # phase 2 -- the collective init, entered by every rank; then agree on its outcome
+    ident = (C.c_ubyte * ID_BYTES).from_buffer_copy(box[0])
+    rc = lib.vds_comm_init(rank, world, ident, ID_BYTES)
+    ok = rc == 0
+    if not ok:
+        err = f"vds_comm_init(rank={rank}, world={world}) -> {rc} {lib.vds_last_error().decode()}"
+    if not agree(ok):
         if ok:
             lib.vds_comm_destroy()
-        return False
+        return fall_back(err)
+    _state["fallback"] = None
     _state.update(group=group, active=True, rank=rank, world=world)
     return True
+
+
+def fallback_reason() -> Optional[str]:
+    """why `ensure` last fell back to torch.distributed's communicator (None: it did not).  bench.py exits non-zero
+    on it: a scaling number must not silently come from another communicator than the one it names."""
+    return _state["fallback"]
 
 
 def info() -> dict:

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void allpairs_average_kernel(const float* __re
 }  // namespace
 
 extern "C" int vds_comm_unique_id(void* out, size_t bytes) {
+  vdserr::clear();  // a message describes the LAST failing call only
   if (!out || bytes < NCCL_UNIQUE_ID_BYTES) return VDS_ERR_ARG;
   if (!bind()) return VDS_ERR_UNSUPPORTED;
   ncclUniqueId id;
@@ -134,7 +135,13 @@ extern "C" int vds_comm_unique_id(void* out, size_t bytes) {
   return VDS_OK;
 }
 
+extern "C" int vds_comm_available(void) {
+  vdserr::clear();
+  return bind() ? VDS_OK : VDS_ERR_UNSUPPORTED;
+}
+
 extern "C" int vds_comm_init(int32_t rank, int32_t world, const void* unique_id, size_t bytes) {
+  vdserr::clear();  // a message describes the LAST failing call only
   if (!unique_id || bytes < NCCL_UNIQUE_ID_BYTES || world < 1 || rank < 0 || rank >= world) return VDS_ERR_ARG;
   if (g_comm) {
     vdserr::set("vds_comm_init: a communicator already exists (vds_comm_destroy it first)");
@@ -158,11 +165,13 @@ extern "C" int vds_comm_info(int32_t* rank, int32_t* world, int32_t* rccl_versio
   if (rccl_version) {
     *rccl_version = 0;
     if (bind()) (void)R.GetVersion(rccl_version);
+    else vdserr::clear();  // reported through the version field (0), not through vds_last_error
   }
   return g_comm ? VDS_OK : VDS_ERR_ARG;
 }
 
 extern "C" int vds_comm_destroy(void) {
+  vdserr::clear();  // a message describes the LAST failing call only
   if (!g_comm) return VDS_OK;
   ncclComm_t c = g_comm;
   g_comm = nullptr;
@@ -173,6 +182,7 @@ extern "C" int vds_comm_destroy(void) {
 }
 
 extern "C" int vds_all_gather_bf16(const void* shard, void* full, int64_t shard_elems, vds_stream_t stream) {
+  vdserr::clear();  // a message describes the LAST failing call only
   if (int e = need_comm("vds_all_gather_bf16")) return e;
   if (!shard || !full || shard_elems <= 0) return VDS_ERR_ARG;
   RCCL_TRY(R.AllGather(shard, full, (size_t)shard_elems, ncclBfloat16, g_comm, (hipStream_t)stream), "ncclAllGather(bf16)");
@@ -180,6 +190,7 @@ extern "C" int vds_all_gather_bf16(const void* shard, void* full, int64_t shard_
 }
 
 extern "C" int vds_all_gather_f32(const float* shard, float* full, int64_t shard_elems, vds_stream_t stream) {
+  vdserr::clear();  // a message describes the LAST failing call only
   if (int e = need_comm("vds_all_gather_f32")) return e;
   if (!shard || !full || shard_elems <= 0) return VDS_ERR_ARG;
   RCCL_TRY(R.AllGather(shard, full, (size_t)shard_elems, ncclFloat32, g_comm, (hipStream_t)stream), "ncclAllGather(f32)");
@@ -205,6 +216,7 @@ extern "C" size_t vds_reduce_scatter_workspace_bytes(int64_t shard_elems) {
 
 extern "C" int vds_reduce_scatter_f32_avg(const float* full, float* shard, int64_t shard_elems, void* workspace,
                                           size_t ws_bytes, vds_stream_t stream) {
+  vdserr::clear();  // a message describes the LAST failing call only
   if (int e = need_comm("vds_reduce_scatter_f32_avg")) return e;
   if (!full || !shard || shard_elems <= 0) return VDS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -221,16 +233,24 @@ extern "C" int vds_reduce_scatter_f32_avg(const float* full, float* shard, int64
   float* stage = (float*)workspace;
   RCCL_TRY(R.GroupStart(), "ncclGroupStart");
   int p = 0;
-  for (int r = 0; r < g_world; ++r) {
+  ncclResult_t bad = ncclSuccess;
+  const char* bad_what = "";
+  for (int r = 0; r < g_world && bad == ncclSuccess; ++r) {
     if (r == g_rank) continue;
-    RCCL_TRY(R.Send(full + (long)r * shard_elems, (size_t)shard_elems, ncclFloat32, r, g_comm, s), "ncclSend");
-    RCCL_TRY(R.Recv(stage + (long)(p++) * shard_elems, (size_t)shard_elems, ncclFloat32, r, g_comm, s), "ncclRecv");
+    bad = R.Send(full + (long)r * shard_elems, (size_t)shard_elems, ncclFloat32, r, g_comm, s);
+    bad_what = "ncclSend";
+    if (bad != ncclSuccess) break;
+    bad = R.Recv(stage + (long)(p++) * shard_elems, (size_t)shard_elems, ncclFloat32, r, g_comm, s);
+    bad_what = "ncclRecv";
   }
-  RCCL_TRY(R.GroupEnd(), "ncclGroupEnd");
+  const ncclResult_t ge = R.GroupEnd();  // always: an error must not leave the group open
+  if (bad != ncclSuccess) return fail(bad, bad_what);
+  if (ge != ncclSuccess) return fail(ge, "ncclGroupEnd");
   return vds_average_chunks_f32(full + (long)g_rank * shard_elems, stage, shard, shard_elems, g_world, g_rank, stream);
 }
 
 extern "C" int vds_all_reduce_f32_avg(float* buf, int64_t n, vds_stream_t stream) {
+  vdserr::clear();  // a message describes the LAST failing call only
   if (int e = need_comm("vds_all_reduce_f32_avg")) return e;
   if (!buf || n <= 0) return VDS_ERR_ARG;
   RCCL_TRY(R.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclAvg, g_comm, (hipStream_t)stream), "ncclAllReduce(f32, avg)");

@@ -99,6 +99,15 @@ class AmaxHistory:
         self._fwd_seen = False   # a training forward recorded its rows since the last roll
         self._bwd_seen = False   # ... and its backward completed (host flag set by DiT._backward_impl)
 
+    def ensure_part(self, rows: int):
+        """allocate the partial-maxima table for launches over `rows` token rows.  Called by every training forward
+        BEFORE `roll()`, whether or not delayed scaling is armed yet: `roll()` must always contain the fold of the
+        table (a HIP-graph capture of the first armed step would otherwise freeze a roll without it, and the rows the
+        producer kernels feed would keep their first scale for ever)."""
+        if self.part_tab is None or self.part_tab.shape[1] < rows:
+            assert self.part_tab is None or not bool(self.part_tab.any()), "token count grew inside a step"
+            self.part_tab = torch.zeros(self.tab.shape[0], rows, dtype=f32, device=self.tab.device)
+
     def roll(self):
         if self._fwd_seen:
             cur = self.tab[:, 1]
@@ -123,8 +132,7 @@ class AmaxHistory:
     def part(self, i: int, rows: int):
         """the partial-maxima row of tensor i for a launch over `rows` token rows"""
         if self.part_tab is None or self.part_tab.shape[1] < rows:
-            assert self.part_tab is None or not bool(self.part_tab.any()), "token count grew inside a step"
-            self.part_tab = torch.zeros(self.tab.shape[0], rows, dtype=f32, device=self.tab.device)
+            self.ensure_part(rows)
         return self.part_tab[i]
 
 

@@ -93,8 +93,12 @@ class GraphedTrainStep:
         if "context" not in batch:
             raise ValueError("GraphedTrainStep takes pre-encoded batches: {'latent', 'context'}")
         self._stage(batch)
-        if self.eager_left > 0:
-            self.eager_left -= 1
+        hist = getattr(self.model, "_fp8_hist", None) if getattr(self.model, "fp8", False) else None
+        fp8_unarmed = getattr(self.model, "fp8", False) and (hist is None or not hist.ready or hist.part_tab is None)
+        if self.eager_left > 0 or (self.graph is None and fp8_unarmed):
+            # fp8: the capture must see delayed scaling armed (a complete recorded step) and the partial-maxima table
+            # allocated, or the captured amax roll would differ from the one every later step needs
+            self.eager_left = max(0, self.eager_left - 1)
             loss = self._body(self._draw_rope()).detach().clone()
         else:
             if self.graph is None:

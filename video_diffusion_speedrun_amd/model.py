@@ -670,6 +670,7 @@ class DiT(nn.Module):
             if getattr(self, "_fp8_hist", None) is None or self._fp8_hist.tab.device != dev:
                 self._fp8_hist = F8.AmaxHistory(6 * self.depth, dev)
             if save:
+                self._fp8_hist.ensure_part(B * (t * h * w + N_REG))  # before roll(): see AmaxHistory.ensure_part
                 self._fp8_hist.roll()
 
         # patch embed + register tokens -> token buffer X [B*L, D]   (model.py:360-362).  ONE GEMM over all B*L rows:
@@ -740,15 +741,7 @@ class DiT(nn.Module):
         R = self.root_group
         # gradients already held in p.grad (a second backward before zero_grad: micro-batch accumulation, like
         # autograd's accumulate-into-.grad in the reference loop) are set aside and added back at the end
-        held = None
-        if any(q.grad is not None for g in self._groups for q in g.params.values()):
-            for g in self._groups:
-                for q in g.params.values():
-                    if q.grad is not None and q.grad.data_ptr() != q._vds_grad_view.data_ptr():
-                        raise RuntimeError("DiT backward: a parameter's .grad was replaced by a foreign tensor; "
-                                           "call zero_grad(set_to_none=True) before backward")
-            held = [g.gshard.clone() if any(q.grad is not None for q in g.params.values()) else None
-                    for g in self._groups]
+        held = [g.hold_grads() for g in self._groups]  # per parameter: only slices whose .grad is live are kept
         for g in self._groups:
             g.gfull.zero_()
         if fs is not None:
@@ -799,10 +792,8 @@ class DiT(nn.Module):
         else:
             for g in self._groups:
                 g.publish_grads()
-        if held is not None:
-            for g, h in zip(self._groups, held):
-                if h is not None:
-                    g.gshard.add_(h)
+        for g, h in zip(self._groups, held):
+            g.add_held(h)
         if self.fp8 and getattr(self, "_fp8_hist", None) is not None:
             self._fp8_hist.backward_done()
 
@@ -908,9 +899,7 @@ class _BlockFunction(torch.autograd.Function):
         block, G, pre, bs, sv, (B, L, Lc, D, H, hd, hdp), xdt, cdt, v0dt = ctx.state
         ctx.state = None
         dev = sv.cvec.device
-        held = None
-        if any(p.grad is not None for p in G.params.values()):  # accumulate like autograd (see DiT._backward_impl)
-            held = G.gshard.clone()
+        held = G.hold_grads()  # accumulate like autograd (see DiT._backward_impl)
         G.gfull.zero_()
         dX = (dx.reshape(B * L, D).to(bf16).contiguous() if dx is not None
               else torch.zeros(B * L, D, dtype=bf16, device=dev))
@@ -926,8 +915,7 @@ class _BlockFunction(torch.autograd.Function):
             dv0[..., :hd].copy_(dv_out)
         dX0 = block._bwd(G, pre, bs, dX, sv, dc, dv0, B, L, Lc, first=(not bs.mix and dv0 is not None))
         G.publish_grads()
-        if held is not None:
-            G.gshard.add_(held)
+        G.add_held(held)
         gv0 = dv0[..., :hd].to(v0dt) if (bs.mix and v0dt is not None) else None
         n_params = len(list(block.parameters()))
         return (None, None, dX0.view(B, L, D).to(xdt), None, dc.to(cdt), gv0, None, None) + (None,) * n_params

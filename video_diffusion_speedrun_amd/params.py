@@ -172,8 +172,37 @@ class FlatGroup:
             reduce_scatter_avg(self.gshard, self.gfull, group)
 
     def publish_grads(self):
+        """point `.grad` of every trainable parameter at its slice of the reduced gradient shard (frozen parameters --
+        `requires_grad_(False)` -- get none: no optimizer would ever clear it again)"""
         for n in self.names:
-            self.params[n].grad = self.params[n]._vds_grad_view
+            p = self.params[n]
+            if p.requires_grad:
+                p.grad = p._vds_grad_view
+
+    def hold_grads(self) -> Optional[torch.Tensor]:
+        """Gradients the caller already holds in `.grad` (a second backward before `zero_grad()`: micro-batch
+        accumulation, like autograd's accumulate-into-.grad): a copy of the gradient shard in which the slices of
+        parameters WITHOUT a held gradient (`.grad is None`: cleared by zero_grad, frozen, never used) are zero, to be
+        added back by `add_held` after this backward has overwritten the shard.  None when nothing is held."""
+        live = [n for n in self.names if self.params[n].grad is not None]
+        if not live:
+            return None
+        for n in live:
+            q = self.params[n]
+            if q.grad.data_ptr() != q._vds_grad_view.data_ptr():
+                raise RuntimeError("DiT backward: a parameter's .grad was replaced by a foreign tensor; "
+                                   "call zero_grad(set_to_none=True) before backward")
+        if len(live) == len(self.names):
+            return self.gshard.clone()
+        held = torch.zeros_like(self.gshard)
+        for n in live:
+            lo, hi = self.local_range(n)
+            held[lo:hi].copy_(self.gshard[lo:hi])
+        return held
+
+    def add_held(self, held: Optional[torch.Tensor]):
+        if held is not None:
+            self.gshard.add_(held)
 
     def w(self, name: str) -> torch.Tensor:
         o = self.offsets[name]
