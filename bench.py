@@ -65,7 +65,10 @@ import torch
 import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_JSON = "r03_traffic.json"  # committed rocprofv3 PMC pass of the dominant kernel (tools/collect_profiles.sh)
+FP8_CLASSES = ("gemm_fp8", "attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq")
 
 # name -> (DiT kwargs, latent [C,T,H,W], default per-GPU batch, description)
 WORKLOADS = {
@@ -83,7 +86,8 @@ WORKLOADS = {
            "C4 DiT-XL/2 bf16, latents [16,33,64,64] pt=1 -> 33792+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[4]: the C3b shapes with the qkv / MLP GEMMs on the fp8 MFMA path (fp8.py)
     "c5": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 12,
-           "C5 DiT-XL/2 fp8 (e4m3 activations/weights, e5m2 gradients in the qkv + MLP GEMMs; rest bf16), "
+           "C5 DiT-XL/2 fp8 (e4m3 activations/weights/P, e5m2 gradients: qkv + MLP GEMMs and the self-attention "
+           "products on the fp8 MFMA; cross-attention, 1152^2 projections, norms, optimizer bf16/fp32), "
            "latents [16,16,64,64] pt=2 -> 8192+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[0] shape, on the GPU
     "c1": (dict(hidden_size=384, depth=12, num_heads=6, time_patch_size=2), (16, 8, 16, 16), 4,
@@ -155,6 +159,94 @@ def cpu_baseline(kw, latent_shape, flops_per_sample):
                       f"fwd+bwd+AdamW in {dt:.1f} s (~{one_block / dt / 1e12:.2f} TFLOP/s); samples/s = 1/(depth x t)"}
 
 
+def require_vds_comm(sharded: bool, comm_mod):
+    """A sharded run must be on the library's own RCCL communicator: when `comm.ensure` fell back to
+    torch.distributed's (it says so on stderr) the bench exits non-zero instead of reporting a number from a
+    communicator the JSON line does not name.  `VDS_COMM=torch` measures that path on purpose."""
+    if sharded and comm_mod.enabled() and comm_mod.fallback_reason() is not None:
+        raise SystemExit(f"bench.py: the vds RCCL communicator could not be created ({comm_mod.fallback_reason()}); "
+                         "refusing to report a number from the torch.distributed fallback (set VDS_COMM=torch to "
+                         "measure that path on purpose)")
+
+
+def comm_knobs(world, device):
+    """everything that shapes the collectives of this run, for the JSON `comm` object"""
+    env = {k: os.environ[k] for k in sorted(os.environ)
+           if k.startswith(("VDS_COMM", "NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES",
+                                                                     "ROCR_VISIBLE_DEVICES")}
+    devs = [torch.cuda.current_device()]
+    if world > 1:
+        t = torch.tensor([torch.cuda.current_device()], device=device)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        devs = [int(x.item()) for x in allr]
+    return {"comm_stream_priority": int(os.environ.get("VDS_COMM_PRIORITY", "0")),
+            "schedule_env": os.environ.get("VDS_COMM_SCHEDULE", "rccl"), "env": env, "device_ids": devs}
+
+
+def comm_only(model, args, world, rank, device, desc, B):
+    """Time the step's collectives alone on the communication stream: per shard group one bf16 all-gather of the
+    compute copy and one fp32 reduce-scatter-average of the gradient buffer, exactly the calls of a train step
+    (params.FlatGroup.gather / reduce_grads) with no compute beside them.  One JSON line: bytes, ms and GB/s per
+    collective and in total, per rank."""
+    from video_diffusion_speedrun_amd import comm, ops
+    fs = model._fsdp
+    stream = fs.comm
+    groups = model._groups
+    res = {"all_gather": [], "reduce_scatter": []}
+
+    def timed(fn, n):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        with torch.cuda.stream(stream):
+            for _ in range(max(1, args.warmup)):
+                fn()
+            if world > 1:
+                dist.barrier()
+            stream.synchronize()
+            ev[0].record(stream)
+            for _ in range(n):
+                fn()
+            ev[1].record(stream)
+        stream.synchronize()
+        return ev[0].elapsed_time(ev[1]) / n
+
+    n = max(1, args.steps)
+    for g in groups:
+        g.refresh_shadow(ops.cast_f32_bf16)
+        ms = timed(lambda g=g: g.gather(ops.cast_f32_bf16, fs.pg, skip_cast=True), n)
+        res["all_gather"].append({"group": g.name, "bytes": 2 * g.padded, "ms": round(ms, 4),
+                                  "GB/s": round(2 * g.padded / ms / 1e6, 1)})
+        ms = timed(lambda g=g: g.reduce_grads(fs.pg), n)
+        res["reduce_scatter"].append({"group": g.name, "bytes": 4 * g.padded, "ms": round(ms, 4),
+                                      "GB/s": round(4 * g.padded / ms / 1e6, 1)})
+    tot = {k: {"collectives": len(v), "bytes": sum(x["bytes"] for x in v), "ms": round(sum(x["ms"] for x in v), 3)}
+           for k, v in res.items()}
+    for k in tot:
+        tot[k]["GB/s"] = round(tot[k]["bytes"] / tot[k]["ms"] / 1e6, 1) if tot[k]["ms"] > 0 else None
+    mine = torch.tensor([tot["all_gather"]["ms"], tot["reduce_scatter"]["ms"]], device=device, dtype=torch.float64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    ci = comm.info()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "collectives of one train step, alone on the communication stream", "unit": "ms",
+            "value": tot["all_gather"]["ms"] + tot["reduce_scatter"]["ms"], "higher_is_better": False, "n_gpus": world,
+            "steps": n, "warmup": args.warmup, "config": {"workload": desc, "per_gpu_batch": B},
+            "backend": "vds_comm (RCCL from csrc/comm.hip)" if ci["active"] else "torch.distributed nccl",
+            "rccl_version": ci["rccl_version"], "reduce_scatter_schedule": ci["schedule"], "totals": tot,
+            "per_rank_ms": [[round(float(t[0]), 3), round(float(t[1]), 3)] for t in allr],
+            "largest_groups": {k: sorted(v, key=lambda x: -x["bytes"])[:2] for k, v in res.items()},
+            **comm_knobs(world, device)}), flush=True)
+    if world > 1:
+        dist.barrier()
+    if dist.is_initialized():
+        comm.destroy()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +261,10 @@ def main():
                     help="replay the whole step as one captured HIP graph (1 GPU; launch-bound workloads)")
     ap.add_argument("--force-shard-runtime", action="store_true",
                     help="1 GPU only: run the sharding runtime (streams, events, RCCL collectives on a 1-rank group)")
+    ap.add_argument("--comm-only", action="store_true",
+                    help="time only the step's collectives (one bf16 all-gather + one fp32 reduce-scatter-average per "
+                         "shard group) on the communication stream, under both reduce-scatter schedules; no compute")
+    ap.add_argument("--no-fp8-attention", action="store_true", help="c5: keep the attention products in bf16")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,7 +292,7 @@ def main():
 
     model = build_model(kw, device, seed=1234)  # same init on every rank
     if args.workload == "c5":
-        model.enable_fp8()
+        model.enable_fp8(attention=not args.no_fp8_attention)
     if world > 1:
         model = apply_fsdp(model, torch.bfloat16, torch.float32)
         model._fsdp.measure = True
@@ -206,6 +302,13 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
         model = apply_fsdp(model, torch.bfloat16, torch.float32, force_runtime=True)
         model._fsdp.measure = True
+    from video_diffusion_speedrun_amd import comm as _comm
+    require_vds_comm(getattr(model, "_fsdp", None) is not None, _comm)
+    if args.comm_only:
+        if getattr(model, "_fsdp", None) is None:
+            raise SystemExit("bench.py --comm-only needs the sharding runtime: --gpus N > 1 or --force-shard-runtime")
+        comm_only(model, args, world, rank, device, desc, B)
+        return
     groups, _ = model.get_mup_setup(1e-4, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
     opt = MuAdamW(groups, betas=(0.95, 0.99))
     sched = get_schedule(opt, "cosine", 20, 10000)
@@ -223,7 +326,8 @@ def main():
     if args.graph:  # whole-step HIP-graph replay (graph.py); world_size 1 only
         from video_diffusion_speedrun_amd.graph import GraphedTrainStep
         graphed = GraphedTrainStep(model, opt, sched, device, eager_steps=1)
-        for _ in range(2):  # one eager step, then capture + first replay (untimed)
+        # eager step(s), then capture + first replay (untimed); fp8 needs a second eager step (armed amax history)
+        for _ in range(3 if args.workload == "c5" else 2):
             graphed.step(batch)
 
     def sync():
@@ -248,7 +352,8 @@ def main():
         dominant = "attn_bwd_dkv" if (kw["hidden_size"] // kw["num_heads"]) == 72 else "attn_bwd_dkv_plain"
     names = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_delta", "attn_bwd_dkv", "attn_bwd_dq",
              "rmsnorm_mod_fwd", "rmsnorm_mod_bwd", "adamw", "qkv_rope_fwd", "qkv_rope_bwd", "gate_bwd",
-             "attn_fwd_plain", "attn_bwd_dkv_plain", "attn_bwd_dq_plain", "gemm_fp8"]
+             "attn_fwd_plain", "attn_bwd_dkv_plain", "attn_bwd_dq_plain", "gemm_fp8", "attn_fp8_fwd", "attn_fp8_dkv",
+             "attn_fp8_dq"]
 
     # ---- timed region: exactly K steps between barrier + synchronize --------------------------
     sync()
@@ -258,11 +363,16 @@ def main():
         n_ag0, n_rs0 = fs.n_all_gather, fs.n_reduce_scatter
     if dominant is not None and graphed is None:
         ops.prof_enable(1 << names.index(dominant))  # events around the dominant kernel's launches only
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # per-step times (median); no syncs
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = graphed.step(batch) if graphed is not None else one_step()
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = (step_ms[(len(step_ms) - 1) // 2] + step_ms[len(step_ms) // 2]) / 2 if step_ms else float("nan")
     if graphed is not None:  # a replay has no per-launch events: the kernel's duration comes from the eager warmup step
         dom = breakdown.get(dominant)
     else:
@@ -287,7 +397,8 @@ def main():
                      "reduce_scatters_per_step": (fs.n_reduce_scatter - n_rs0) / args.steps,
                      "all_gather_bytes_per_step": 2 * gbytes, "reduce_scatter_bytes_per_step": 4 * gbytes,
                      "per_rank_ms_per_step": [round(float(t[0]), 3) for t in allr],
-                     "per_rank_exposed_comm_ms_per_step": [round(float(t[1]), 3) for t in allr]}
+                     "per_rank_exposed_comm_ms_per_step": [round(float(t[1]), 3) for t in allr],
+                     **comm_knobs(world, device)}
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -302,6 +413,9 @@ def main():
         out = {
             "metric": "train-step samples/sec (video latents)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            # BASELINE.md §4 asks for the median of the timed steps: HIP events on the compute stream between the steps
+            # of rank 0 (`value` / `ms_per_step` stay the contract's total over the K steps, max over ranks)
+            "ms_per_step_median": median_ms, "value_at_median": world * B / (median_ms * 1e-3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8+bf16" if args.workload == "c5" else "bf16",
             "data": "synthetic (N(0,1) latents/context, random-init weights, zero-init tensors re-drawn N(0,0.02))",
@@ -320,7 +434,7 @@ def main():
             mfma_bound = dom["flops"] > 0
             if mfma_bound:
                 ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-                peak, unit = PEAK_BF16_TFLOPS, "TFLOP/s"
+                peak, unit = (PEAK_FP8_TFLOPS if dominant in FP8_CLASSES else PEAK_BF16_TFLOPS), "TFLOP/s"
             else:
                 ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
                 peak, unit = PEAK_HBM_GBS, "GB/s"
@@ -329,11 +443,11 @@ def main():
             # stamped with the commit and kernel symbol it was taken on; null when there is none
             traffic, traffic_src = None, None
             try:
-                tj = json.load(open(os.path.join(REPO, "profiles", "r02_traffic.json")))
+                tj = json.load(open(os.path.join(REPO, "profiles", TRAFFIC_JSON)))
                 if tj["workload"] == args.workload and tj["per_gpu_batch"] == B and dominant in tj["kernels"]:
                     k = tj["kernels"][dominant]
                     traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
-                    traffic_src = f"profiles/r02_traffic.json: rocprofv3 PMC pass of {k['symbol']} at commit {tj['commit']}"
+                    traffic_src = f"profiles/{TRAFFIC_JSON}: rocprofv3 PMC pass of {k['symbol']} at commit {tj['commit']}"
             except (OSError, KeyError, ValueError):
                 pass
             out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": ach, "peak": peak, "unit": unit,
@@ -347,7 +461,8 @@ def main():
             # the HBM-bound glue is reported separately, as achieved GB/s (algorithmic bytes: every
             # operand read once, every result written once) against the HBM peak; MFMA classes as TFLOP/s
             out["kernel_rates"] = {
-                k: ({"TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1), "frac_of_peak": round(v["flops"] / v["ms"] / 1e9 / (2 * PEAK_BF16_TFLOPS if k == "gemm_fp8" else PEAK_BF16_TFLOPS), 4)}
+                k: ({"TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1), "frac_of_peak": round(v["flops"] / v["ms"] / 1e9 / (PEAK_FP8_TFLOPS if k in FP8_CLASSES else PEAK_BF16_TFLOPS), 4),
+                     "dtype": "fp8" if k in FP8_CLASSES else "bf16"}
                     if v["flops"] > 0 and k != "attn_bwd_delta" else  # (the delta preprocess streams O and dO: HBM-bound)
                     {"GB/s": round(v["bytes"] / v["ms"] / 1e6, 1), "frac_of_peak": round(v["bytes"] / v["ms"] / 1e6 / PEAK_HBM_GBS, 4)})
                 for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}

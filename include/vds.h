@@ -384,6 +384,46 @@ int vds_cast_f32_bf16(const float* src, void* dst, int64_t n, vds_stream_t strea
 /* bf16 -> f32 */
 int vds_cast_bf16_f32(const void* src, float* dst, int64_t n, vds_stream_t stream);
 
+/* ------------------------------------------------ fp8 attention (BASELINE config 5) -------
+ * F.scaled_dot_product_attention (model.py:136) and its backward on v_mfma_f32_16x16x128_f8f6f4: Q / K / V / P in
+ * OCP e4m3, dO / dS in e5m2, fp32 accumulation and softmax statistics (csrc/attention_fp8.hip; recipe: fp8.py).  The
+ * reference trains in bf16 only.  q, k, v, d_o: fp8 rows [B,H,L,128] (contiguous; bytes [0, head_dim) data, byte
+ * head_dim of every V row = 1.0 (0x38), all other pad bytes 0) as written by vds_qkv_rope_fwd_fp8 / vds_attn_fp8_delta;
+ * deq: device float[4] = dequantisation factors {s_q, s_k, s_v, s_do} (x = x_q * s), written by the same two producers.
+ * o: bf16, any strides (last dim contiguous); lse f32 [B,H,Lq]; dq, dk, dv: bf16 strided like attention's.
+ * stats: the f32 [2,B,H,Lq] workspace vds_attn_fp8_delta filled (vds_attn_fp8_bwd_workspace_bytes).  head_dim 72. */
+typedef struct vds_attn_fp8_args {
+  int32_t B, H, Lq, Lk, head_dim;
+  const void* q; const void* k; const void* v;
+  void* o; int64_t o_sb, o_sh, o_sl;
+  float* lse;
+  const void* d_o;
+  void* dq; int64_t dq_sb, dq_sh, dq_sl;
+  void* dk; int64_t dk_sb, dk_sh, dk_sl;
+  void* dv; int64_t dv_sb, dv_sh, dv_sl;
+  const float* stats;
+  const float* deq;
+} vds_attn_fp8_args;
+int vds_attn_fp8_supported(int32_t head_dim); /* 1 / 0 */
+int vds_attn_fp8_fwd(const vds_attn_fp8_args* a, vds_stream_t stream);
+size_t vds_attn_fp8_bwd_workspace_bytes(const vds_attn_fp8_args* a);
+/* backward preprocess over the token-major bf16 O / dO ([B*Lq, H*head_dim], row strides o_sl / do_sl, batch strides
+ * o_sb / do_sb, in elements): stats (see above), dO as e5m2 rows into doq ([B,H,Lq,128], pad bytes left untouched: zero
+ * the buffer once), scaled by the previous step's amax (*amax_prev; 0 = unscaled) with the current one accumulated
+ * into *amax_cur; writes deq[3] and reads deq[2]. */
+int vds_attn_fp8_delta(const void* o, int64_t o_sb, int64_t o_sl, const void* d_o, int64_t do_sb, int64_t do_sl,
+                       const float* lse, float* stats, void* doq, const float* amax_prev, float* amax_cur, float* deq,
+                       int32_t B, int32_t H, int32_t Lq, int32_t head_dim, vds_stream_t stream);
+int vds_attn_fp8_bwd(const vds_attn_fp8_args* a, vds_stream_t stream);
+/* vds_qkv_rope_fwd with fp8 outputs (the values quantised are that kernel's bf16 results): q8 / k8 / v8 e4m3 rows
+ * [B,H,L,128]; v_out (may be NULL): additionally the bf16 v in the padded head-major layout [B,H,L,hdp]; amax_prev /
+ * amax_cur: the q, k, v amax entries at element stride amax_stride (delayed scaling: scale = 448 / previous amax);
+ * writes deq[0..2]. */
+int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const float* sinb, const void* v0, const void* lam,
+                         void* q8, void* k8, void* v8, void* v_out, const float* amax_prev, float* amax_cur,
+                         int32_t amax_stride, float* deq, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t hdp,
+                         vds_stream_t stream);
+
 /* ------------------------------------------------------------------ live profiling ----
  * Per-kernel-class timing with HIP events recorded on the launch stream around each launch of
  * an enabled class (bench.py's roofline leg).  Off by default (no events, no overhead).
@@ -394,6 +434,7 @@ enum { VDS_PROF_GEMM_NT = 0, VDS_PROF_GEMM_NN, VDS_PROF_GEMM_TN, VDS_PROF_ATTN_F
        VDS_PROF_QKV_ROPE_FWD, VDS_PROF_QKV_ROPE_BWD, VDS_PROF_GATE_BWD,
        /* the attention kernel instances without the ones-column contract (cross-attention, hd 64/128) */
        VDS_PROF_ATTN_FWD_PLAIN, VDS_PROF_ATTN_BWD_DKV_PLAIN, VDS_PROF_ATTN_BWD_DQ_PLAIN, VDS_PROF_GEMM_FP8,
+       VDS_PROF_ATTN_FP8_FWD, VDS_PROF_ATTN_FP8_DKV, VDS_PROF_ATTN_FP8_DQ,
        VDS_PROF_NCLASS };
 typedef struct vds_prof_stat { int64_t launches; double ms; double flops; double bytes; } vds_prof_stat;
 int vds_prof_enable(uint32_t class_mask);

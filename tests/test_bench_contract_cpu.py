@@ -66,3 +66,27 @@ def test_launcher_world_size_must_match_gpus_flag():
         out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"],
                              capture_output=True, text=True, env=env, timeout=300)
         assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+def test_a_fallen_back_communicator_fails_the_bench():
+    """`bench.py --gpus N` must exit non-zero when comm.ensure fell back to torch.distributed"""
+    b = load_bench()
+
+    class Fake:
+        def __init__(self, on, why):
+            self._on, self._why = on, why
+
+        def enabled(self):
+            return self._on
+
+        def fallback_reason(self):
+            return self._why
+    b.require_vds_comm(True, Fake(True, None))                      # the library's communicator is in use
+    b.require_vds_comm(False, Fake(True, "dlopen failed"))          # not sharded: nothing to check
+    b.require_vds_comm(True, Fake(False, "dlopen failed"))          # VDS_COMM=torch: the torch path on purpose
+    with pytest.raises(SystemExit) as e:
+        b.require_vds_comm(True, Fake(True, "vds_comm_init(rank=1, world=2) -> -3"))
+    assert e.value.code not in (0, None) and "vds_comm_init" in str(e.value.code)
+    for flag in ("--comm-only", "--force-shard-runtime", "--batch"):
+        assert flag in subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--help"], capture_output=True,
+                                      text=True).stdout

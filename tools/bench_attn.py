@@ -62,3 +62,34 @@ for hd, H, hdp in SHAPES:
     for kname in ("attn_bwd_dkv", "attn_bwd_dq", "attn_bwd_delta"):
         r = st.get(kname) or st[kname + "_plain"]
         print(f"{tag} {kname} hd{hd}: {r['ms']/r['launches']:8.3f} ms {r['flops']/r['ms']/1e9:7.1f} TF/s")
+
+    if hd == 72 and ops.attn_fp8_supported(hd):  # the fp8 kernels (attention_fp8.hip) on the same problem
+        E4, E5 = torch.float8_e4m3fn, torch.float8_e5m2
+
+        def rows(x, fmt, target):
+            a = target / x.abs().max().item()
+            r = torch.zeros(B, H, Lq, 128, dtype=torch.uint8, device=dev)
+            r[..., :hd] = (x[..., :hd].float() * a).to(fmt).view(torch.uint8)
+            return r, 1.0 / a
+        q8, sq = rows(q, E4, 448.0)
+        k8, sk = rows(k, E4, 448.0)
+        v8, sv = rows(v, E4, 448.0)
+        v8[..., hd] = 0x38
+        q8, k8, v8 = q8.view(E4), k8.view(E4), v8.view(E4)
+        deq = torch.tensor([sq, sk, sv, 0.0], dtype=f32, device=dev)
+        t = timeit(lambda: ops.attn_fp8_fwd(q8, k8, v8, deq, ov, lse, hd))
+        print(f"{tag} fp8 fwd hd{hd}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TF/s")
+        doq = torch.zeros(B, H, Lq, 128, dtype=E5, device=dev)
+        ap = do.float().abs().max().reshape(1)
+        ac = torch.zeros(1, dtype=f32, device=dev)
+        stats = ops.attn_fp8_delta(o, do, lse, doq, ap, ac, deq, B, H, Lq, hd)
+        t = timeit(lambda: ops.attn_fp8_delta(o, do, lse, doq, ap, ac, deq, B, H, Lq, hd))
+        print(f"{tag} fp8 delta hd{hd}: {t*1e3:8.3f} ms")
+        ops.prof_enable()
+        for _ in range(4):
+            ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dq[..., :hd], dk[..., :hd], dv[..., :hd], hd)
+        st = ops.prof_collect()
+        ops.prof_enable(0)
+        for kname in ("attn_fp8_dkv", "attn_fp8_dq"):
+            r = st[kname]
+            print(f"{tag} {kname} hd{hd}: {r['ms']/r['launches']:8.3f} ms {r['flops']/r['ms']/1e9:7.1f} TF/s")

@@ -38,6 +38,17 @@ class AttnArgs(C.Structure):
                 ("delta", c_vp), ("kv_pad_ones", c_i32)]
 
 
+class Attn8Args(C.Structure):  # vds_attn_fp8_args
+    _fields_ = [("B", c_i32), ("H", c_i32), ("Lq", c_i32), ("Lk", c_i32), ("head_dim", c_i32),
+                ("q", c_vp), ("k", c_vp), ("v", c_vp),
+                ("o", c_vp), ("o_sb", c_i64), ("o_sh", c_i64), ("o_sl", c_i64),
+                ("lse", c_vp), ("d_o", c_vp),
+                ("dq", c_vp), ("dq_sb", c_i64), ("dq_sh", c_i64), ("dq_sl", c_i64),
+                ("dk", c_vp), ("dk_sb", c_i64), ("dk_sh", c_i64), ("dk_sl", c_i64),
+                ("dv", c_vp), ("dv_sb", c_i64), ("dv_sh", c_i64), ("dv_sl", c_i64),
+                ("stats", c_vp), ("deq", c_vp)]
+
+
 class Fp8Out(C.Structure):  # vds_fp8_out
     _fields_ = [("q", C.c_void_p), ("ldq", C.c_int64), ("qt", C.c_void_p), ("ldqt", C.c_int64),
                 ("amax_in", C.c_void_p), ("amax_out", C.c_void_p), ("dq_out", C.c_void_p), ("fmt", C.c_int32),
@@ -48,7 +59,7 @@ class ProfStat(C.Structure):
     _fields_ = [("launches", c_i64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-PROF_NCLASS = 17
+PROF_NCLASS = 20
 
 
 class AdamWTensor(C.Structure):
@@ -123,6 +134,14 @@ SIGNATURES = {
                          c_vp, c_i32, c_i32, c_i32, c_vp],
     "vds_qkv_rope_bwd_fp8": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp,
                              c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_attn_fp8_supported": [c_i32],
+    "vds_attn_fp8_fwd": [C.POINTER(Attn8Args), c_vp],
+    "vds_attn_fp8_bwd_workspace_bytes": [C.POINTER(Attn8Args)],
+    "vds_attn_fp8_delta": [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                           c_i32, c_i32, c_vp],
+    "vds_attn_fp8_bwd": [C.POINTER(Attn8Args), c_vp],
+    "vds_qkv_rope_fwd_fp8": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
+                             c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_selftest_lanemaps": [c_vp, c_vp],
     "vds_prof_enable": [C.c_uint32],
     "vds_prof_collect": [c_vp],

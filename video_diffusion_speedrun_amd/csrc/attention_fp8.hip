@@ -1,0 +1,870 @@
+// OCP-fp8 flash attention for gfx950 on v_mfma_f32_16x16x128_f8f6f4 (BASELINE config 5: "fp8 weights + activations
+// on CDNA4 fp8 MFMA"): forward, dK/dV and dQ of F.scaled_dot_product_attention (model.py:136) with e4m3 Q / K / V / P
+// and e5m2 dO / dS, fp32 accumulation, fp32 softmax statistics (running max, LSE, delta) exactly as in the bf16
+// kernels of attention.hip.  The reference trains in bf16 only; the recipe is this build's (fp8.py states it).
+//
+// Why the shapes below: the fp8 MFMA contracts 128 elements in 32 cycles (bf16: 32 elements in 16), so
+//   * a QK^T-type product covers the whole head dimension (72 data bytes of a 128-byte row) in ONE instruction
+//     (bf16: three 16x16x32, 48 cycles) -- no 72 -> 96 padding pressure, the row pad is free;
+//   * a PV-type product (contraction over keys / queries) runs at 2x the bf16 rate when it contracts 128 rows at
+//     once, so every streamed tile is 128 rows x 128 B = 16 KiB and P / dS are packed 32 bytes per lane.
+// Data flow (same product forms as attention.hip: softmax statistics stay on the lane that owns the column):
+//   forward   S^T = K Q^T        A = 16 key rows from LDS (2 x ds_read_b128), B = 16 queries in registers
+//             O^T += V^T P^T     A = V^T by ds_read_b64_tr_b8 (8 keys x 16 columns per 16-lane group), B = the eight
+//                                16-key S^T accumulators of a tile, exponentiated and packed in place: lane (c, g)
+//                                ends up with keys 32g .. 32g+31 of query c = exactly its B-operand bytes
+//   dQ        S^T, dP^T = V dO^T;  dQ^T += K^T dS^T   (K^T by transposing reads of the same K tile)
+//   dK, dV    S = Q K^T, dP = dO V^T (key on the lane);  dV^T += dO^T P,  dK^T += Q^T dS
+// so that a 16-row block i of a tile uses the tile rows 32 (m >> 2) + 4 i + (m & 3) as its MFMA rows m = 0..15:
+// accumulator register r of lane (c, g) is then tile row 32 g + 4 i + r, and the eight blocks fill the lane's 32
+// contraction bytes in natural order.
+// Row constants ride in for free: dP accumulates onto C = -delta (scaled), the exponent is one v_fma_f32
+// (score * cs + (8 - lse2)) per element.  P is kept as P * 2^8 (e4m3 tops out at 448): forward <= 2^8.8 relative
+// to the lazily raised running maximum, backward = 256 * the true probability (covers 2^-17 .. 1).
+// LDS image: row-major 128-B rows, 16-B chunk c of row r stored at chunk c ^ swz8(r), swz8(r) = ((r >> 1) & 3) |
+// ((r >> 3) & 4): conflict-free for the row reads (16 lanes x 16 B over 256 B) and for the transposing reads
+// (2 x 8 rows x 16 B per 32-lane half); applied to the per-lane SOURCE address of the LDS-DMA.
+#include "common.h"
+#include <type_traits>
+#include "prof.h"
+#include "../../include/vds.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr int ROWB = 128;            // bytes of an fp8 row (global memory and LDS)
+constexpr int TILE = 128 * ROWB;     // one streamed tile: 128 rows
+constexpr float P_SHIFT = 8.0f;      // P is held as P * 2^8
+constexpr float P_LIMIT = 8.75f;
+constexpr float SEED_HEADROOM = 4.0f; // forward: the first block's maximum + 4 seeds the running maximum     // forward: raise the running maximum when a score exceeds it by 2^0.75 (e4m3 max 448 = 2^8.8)
+
+struct Attn8P {
+  int B, H, Lq, Lk, hd;
+  const unsigned char *q, *k, *v, *d_o;  // [B,H,L,128] fp8 rows: bytes [0,hd) data, V byte hd = 1.0, the rest 0
+  bf16_t* o; long o_sb, o_sh, o_sl;
+  float* lse;                            // [B,H,Lq]
+  bf16_t* dq; long dq_sb, dq_sh, dq_sl;
+  bf16_t* dk; long dk_sb, dk_sh, dk_sl;
+  bf16_t* dv; long dv_sb, dv_sh, dv_sl;
+  const float* stats;                    // backward: [2][B,H,Lq]: -delta / (s_do s_v), then 8 - lse log2(e)
+  const float* deq;                      // dequantisation factors {s_q, s_k, s_v, s_do}: x = x_q * s
+  float scale;
+  int n_rt;
+};
+
+__device__ __forceinline__ int swz8(int row) { return ((row >> 1) & 3) | ((row >> 3) & 4); }
+
+// Per-lane LDS byte offsets of the fragment reads, relative to a tile's base: computed once per kernel so that every
+// read in the tile loops is `base VGPR + immediate` (tile / buffer / block offsets are compile-time constants).
+//   row form  (A operand of a QK^T-type product): MFMA row m of block i = tile row 32 (m >> 2) + 4 i + (m & 3); lane
+//     (m, g) takes bytes 32g .. 32g+31 = chunks 2g, 2g+1 at slots (2g + h) ^ swz8(row); swz8(row) = s0 ^ 2 (i & 1)
+//     with s0 = ((m >> 1) & 1) | (((m >> 2) & 1) << 2): odd blocks flip bit 5 of the even blocks' byte offset.
+//   transposed form (A operand of a PV-type product): (T^T)[16 db + d][k], lane (d = l & 15, g) takes tile rows
+//     k = 32g .. 32g+31 of column 16 db + d: four ds_read_b64_tr_b8, each an 8-row x 16-byte block per 16-lane group
+//     (lane 2q + p supplies the address of row q, bytes 8p .. 8p+7; lane d receives column d of the 8 rows, row q in
+//     byte q -- tools/probe_tr8.hip); swz8(32g + 8t + q) = ((q >> 1) & 3) | ((g & 1) << 2) does not depend on t.
+struct Frag8 {
+  unsigned rowoff[2][2];  // [block parity][chunk 2g / 2g+1]
+  unsigned tr[5];         // column block db, t = 0
+  __device__ __forceinline__ void init(int lane) {
+    const int m = lane & 15, g = lane >> 4;
+    const int s0 = ((m >> 1) & 1) | (((m >> 2) & 1) << 2);
+    const unsigned e0 = (unsigned)((32 * (m >> 2) + (m & 3)) * ROWB + (((2 * g) ^ s0) << 4));
+    rowoff[0][0] = e0;
+    rowoff[0][1] = e0 ^ 16u;
+    rowoff[1][0] = e0 ^ 32u;
+    rowoff[1][1] = e0 ^ 48u;
+    const int q = m >> 1, pp = m & 1;
+    const int st = ((q >> 1) & 3) | ((g & 1) << 2);
+#pragma unroll
+    for (int db = 0; db < 5; ++db) tr[db] = (unsigned)((32 * g + q) * ROWB + ((db ^ st) << 4) + 8 * pp);
+  }
+  template <int I>
+  __device__ __forceinline__ i32x8 row(const char* tile) const {
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(tile + rowoff[I & 1][0] + I * 4 * ROWB);
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(tile + rowoff[I & 1][1] + I * 4 * ROWB);
+    return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+  template <int DB>
+  __device__ __forceinline__ i32x8 trans(const char* tile) const {
+    i32x8 r;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const char* p = tile + tr[DB] + t * 8 * ROWB;
+      const i32x2_t w = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2_t*)LDS_PTR(p));
+      r[2 * t] = w[0];
+      r[2 * t + 1] = w[1];
+    }
+    return r;
+  }
+};
+// cbsz / blgp: format of A / B (0 e4m3, 1 e5m2); the block scales are unused (0 selects the unscaled instruction)
+template <int FA, int FB>
+__device__ __forceinline__ f32x4 mfma8(const i32x8& a, const i32x8& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, FA, FB, 0, 0, 0, 0);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ int cvt4_e4m3(const f32x4& x) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w, true);
+  return w;
+}
+__device__ __forceinline__ int cvt4_e5m2(const f32x4& x) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_bf8_f32(x[0], x[1], w, false);
+  w = __builtin_amdgcn_cvt_pk_bf8_f32(x[2], x[3], w, true);
+  return w;
+}
+
+// LDS-DMA staging of a 128-row tile (16 pieces of 1 KiB, 4 per wave): lane i of piece pc fills LDS bytes
+// pc*1024 + 16 i = slot (i & 7) of row 8 pc + (i >> 3), so it fetches chunk slot ^ swz8(row) of that row.
+struct Stage8 {
+  unsigned voff[4];
+  __device__ __forceinline__ void init(int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = wave * 4 + i;
+      const int row = 8 * pc + (lane >> 3);
+      const int ch = (lane & 7) ^ swz8(row);
+      voff[i] = (unsigned)(row * ROWB + ch * 16);
+    }
+  }
+  // row0_bytes = first row of the tile * 128; rows past the tensor read as zero (SRD bounds)
+  __device__ __forceinline__ void issue(srd_t rs, char* tile, unsigned row0_bytes, int wave) const {
+    const unsigned base = lds_addr_of(tile) + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_dma16(rs, base + i * 1024, voff[i] + row0_bytes);
+  }
+};
+
+__device__ __forceinline__ bool decode_block(int n_rt, int BH, int& bh, int& rt) {
+  const int pid = blockIdx.x, xcd = pid & 7, idx = pid >> 3;
+  bh = (idx / n_rt) * 8 + xcd;
+  rt = idx % n_rt;
+  return bh < BH;
+}
+__device__ __forceinline__ float max_over_lane_groups(float x) {  // max over the 4 lanes (l & 15) + 16 g
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ i32x8 load_row32(__amdgpu_buffer_rsrc_t rs, long row, int g) {
+  const unsigned off = (unsigned)(row * ROWB + 32 * g);
+  const i32x4 lo = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+  const i32x4 hi = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0));
+  return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ void retire(const i32x8& f) { asm volatile("" ::"v"(f)); }
+__device__ __forceinline__ void retire(float f) { asm volatile("" ::"v"(f)); }
+
+// ===================================== forward ==============================================
+// Workgroup = 256 queries (4 waves x 4 column blocks of 16); K / V tiles of 128 keys, double-buffered, one barrier
+// per tile.  Lazy online softmax per 16-key block: the exponent x = score * cs + (8 - m) is checked against
+// P_LIMIT; when some query of the wave exceeds it (wave-uniform, rare after the first tiles) its running maximum
+// m is raised, O (whose row `hd` is the softmax denominator, from V's ones column) is rescaled, and the tile is
+// restarted -- the blocks already packed with the old m have not entered O yet, so they are simply recomputed.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
+  static_assert(HD == 72, "ones column of V at byte 72: row 72 of O^T = block 4, lanes g = 2, register 0");
+  constexpr int NDB = 5;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qrow0 = qt * 256 + wave * 64 + (lane & 15);
+  const long head = (long)b * p.H + hh;
+
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q + head * p.Lq * ROWB, (unsigned)(p.Lq * ROWB));
+  const srd_t rk = make_srd(p.k + head * p.Lk * ROWB, (unsigned)(p.Lk * ROWB));
+  const srd_t rv = make_srd(p.v + head * p.Lk * ROWB, (unsigned)(p.Lk * ROWB));
+  Stage8 st;
+  st.init(wave, lane);
+  st.issue(rk, smem, 0, wave);
+  st.issue(rv, smem + TILE, 0, wave);
+
+  i32x8 qf[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) qf[cb] = load_row32(rq, qrow0 + 16 * cb, g);
+  const float cs = p.scale * LOG2E * p.deq[0] * p.deq[1];
+  const float sv = p.deq[2];
+  Frag8 fr;
+  fr.init(lane);
+
+  f32x4 o[NDB][4];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) o[db][cb] = zero4();
+  float m[4];  // running maximum (log2 domain), seeded below
+  const int nkt = (p.Lk + 127) / 128;
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) retire(qf[cb]);
+  retire(cs);
+  retire(sv);
+  VDS_WAIT_VM(0);
+  __syncthreads();
+
+  // seed the running maxima from the first 16-key block plus SEED_HEADROOM: the largest P of the first tiles is then
+  // ~2^(8 - headroom), 13+ binades above e4m3's smallest value, and the maximum is raised (and a tile recomputed)
+  // only when a later score exceeds the seed by more than headroom + 0.75 in the log2 domain
+  {
+    const i32x8 kf = fr.row<0>(smem);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const f32x4 s0 = mfma8<0, 0>(kf, qf[cb], zero4());
+      float t = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (32 * g + r < p.Lk) t = fmaxf(t, s0[r]);
+      m[cb] = max_over_lane_groups(t) * cs + SEED_HEADROOM;
+    }
+  }
+
+  // scores -> packed P of one tile with the current maxima; mt: largest exponent per query block.  Software-pipelined by
+  // hand: the S products of block i+1 are issued before the softmax VALU work of block i, and the sched_barrier keeps
+  // hipcc from hoisting all 32 independent MFMAs (128 live accumulator registers).  RAGGED (last tile only): keys past
+  // Lk -- zero rows -- are kept out of the maximum and of P.
+  auto s_phase = [&](const char* kt, i32x8 (&pq)[4], float (&mt)[4], int key_lim, auto RAG) {
+    constexpr bool ragged = decltype(RAG)::value;
+    float nm[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) { nm[cb] = P_SHIFT - m[cb]; mt[cb] = -INFINITY; }
+    f32x4 xn[4];
+    {
+      const i32x8 kf = fr.row<0>(kt);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) xn[cb] = mfma8<0, 0>(kf, qf[cb], zero4());
+    }
+    static_for<8>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      f32x4 x[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) x[cb] = xn[cb];
+      if constexpr (i < 7) {
+        const i32x8 kf = fr.row<i + 1>(kt);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) xn[cb] = mfma8<0, 0>(kf, qf[cb], zero4());
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[cb][r] = __builtin_fmaf(x[cb][r], cs, nm[cb]);
+        if constexpr (ragged) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * i + r >= key_lim) x[cb][r] = -INFINITY;
+        }
+        mt[cb] = fmaxf(fmaxf(mt[cb], fmaxf(x[cb][0], x[cb][1])), fmaxf(x[cb][2], x[cb][3]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[cb][r] = __builtin_amdgcn_exp2f(x[cb][r]);
+        int w = cvt4_e4m3(x[cb]);
+        asm volatile("" : "+v"(w));  // pins exp2 + pack here: LLVM otherwise sinks them below the (rare) raise-the-maximum
+                                     // branch, which keeps all 128 exponents of the tile live
+        pq[cb][i] = w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  auto kv_tile = [&](int j, auto PAR, auto RAG) {
+    constexpr int par = decltype(PAR)::value;
+    if (j + 1 < nkt) {
+      char* nk = smem + (par ^ 1) * 2 * TILE;
+      st.issue(rk, nk, (unsigned)(j + 1) * TILE, wave);
+      st.issue(rv, nk + TILE, (unsigned)(j + 1) * TILE, wave);
+    }
+    const char* kt = smem + par * 2 * TILE;
+    const char* vt = kt + TILE;
+    const int key_lim = p.Lk - j * 128 - 32 * g;  // keys of this lane's 32-byte range that exist: [0, key_lim)
+    i32x8 pq[4];
+    float mt[4];
+    s_phase(kt, pq, mt, key_lim, RAG);
+    const float mxa = fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]));
+    if (__builtin_amdgcn_ballot_w64(mxa > P_LIMIT) != 0) {  // wave-uniform, rare after the first tiles
+      asm volatile("; raise the running maxima to this tile's, rescale O, recompute the tile's P" ::: "memory");
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const float t = max_over_lane_groups(mt[cb]) - (P_SHIFT - m[cb]);  // largest score of the tile, log2 domain
+        if (t > m[cb]) {  // (the same decision in the 4 lanes of a query)
+          const float alpha = __builtin_amdgcn_exp2f(m[cb] - t);
+          m[cb] = t;
+#pragma unroll
+          for (int db = 0; db < NDB; ++db) o[db][cb] *= alpha;
+        }
+      }
+      s_phase(kt, pq, mt, key_lim, RAG);  // every exponent of the tile is now <= 8
+    }
+    static_for<NDB>([&](auto DB) {
+      constexpr int db = decltype(DB)::value;
+      const i32x8 vf = fr.trans<db>(vt);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) o[db][cb] = mfma8<0, 0>(vf, pq[cb], o[db][cb]);
+    });
+    VDS_WAIT_VM(0);
+    __syncthreads();
+  };
+  const bool last_ragged = (p.Lk & 127) != 0;
+  const int n_full = last_ragged ? nkt - 1 : nkt;
+  int j = 0;
+  for (; j + 1 < n_full; j += 2) {
+    kv_tile(j, std::integral_constant<int, 0>{}, std::false_type{});
+    kv_tile(j + 1, std::integral_constant<int, 1>{}, std::false_type{});
+  }
+  if (j < n_full) {
+    kv_tile(j, std::integral_constant<int, 0>{}, std::false_type{});
+    if (last_ragged) kv_tile(j + 1, std::integral_constant<int, 1>{}, std::true_type{});
+  } else if (last_ragged) {
+    kv_tile(j, std::integral_constant<int, 0>{}, std::true_type{});
+  }
+
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int qrow = qrow0 + 16 * cb;
+    // denominator: row HD of O^T (V's ones column) = block 4, lanes g = 2, register 0
+    const float lt = __shfl(o[NDB - 1][cb][0], (lane & 15) | 32, 64);
+    if (qrow < p.Lq) {
+      const float inv = sv / lt;
+      bf16_t* orow = p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const int d = db * 16 + 4 * g;
+        if (d < HD) {
+          const u32x2 w = {pack_bf2(o[db][cb][0] * inv, o[db][cb][1] * inv), pack_bf2(o[db][cb][2] * inv, o[db][cb][3] * inv)};
+          *reinterpret_cast<u32x2*>(orow + d) = w;
+        }
+      }
+      if (g == 0) p.lse[head * p.Lq + qrow] = (m[cb] - P_SHIFT + __builtin_amdgcn_logf(lt)) * LN2;
+    }
+  }
+}
+
+// ===================================== dK, dV ===============================================
+// Workgroup = 128 keys (4 waves x 2 column blocks of 16), K / V rows of the wave as B operands in registers; Q / dO
+// tiles of 128 queries and their row statistics (8 - lse2, -delta') by LDS-DMA, double-buffered.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
+  static_assert(HD == 72, "5 output blocks of 16");
+  constexpr int NDB = 5;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* stats = smem + 4 * TILE;  // [2 bufs][nl[128] | nd[128]] floats
+  int bh, kt_idx;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, kt_idx)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int key0 = kt_idx * 128 + wave * 32 + (lane & 15);
+  const long head = (long)b * p.H + hh;
+  const long nrows = (long)p.B * p.H * p.Lq;
+
+  const srd_t rq = make_srd(p.q + head * p.Lq * ROWB, (unsigned)(p.Lq * ROWB));
+  const srd_t rdo = make_srd(p.d_o + head * p.Lq * ROWB, (unsigned)(p.Lq * ROWB));
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(p.k + head * p.Lk * ROWB, (unsigned)(p.Lk * ROWB));
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.v + head * p.Lk * ROWB, (unsigned)(p.Lk * ROWB));
+  const srd_t rnd = make_srd(p.stats + head * p.Lq, (unsigned)(p.Lq * 4));
+  const srd_t rnl = make_srd(p.stats + nrows + head * p.Lq, (unsigned)(p.Lq * 4));
+
+  Stage8 st;
+  st.init(wave, lane);
+  auto issue_tile = [&](int j, int par) {
+    char* nb = smem + par * 2 * TILE;
+    st.issue(rq, nb, (unsigned)j * TILE, wave);
+    st.issue(rdo, nb + TILE, (unsigned)j * TILE, wave);
+    if (wave < 2) {  // 128 rows x 4 B per statistic: wave 0 -> 8 - lse2, wave 1 -> -delta'
+      const unsigned sa = lds_addr_of(stats + par * 1024 + wave * 512);
+      const srd_t rs = wave == 0 ? rnl : rnd;
+      lds_dma4(rs, sa, (unsigned)((j * 128 + lane) * 4));
+      lds_dma4(rs, sa + 256, (unsigned)((j * 128 + 64 + lane) * 4));
+    }
+  };
+  issue_tile(0, 0);
+
+  i32x8 kf[2], vf[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    kf[cb] = load_row32(rk, key0 + 16 * cb, g);
+    vf[cb] = load_row32(rv, key0 + 16 * cb, g);
+  }
+  const float s_q = p.deq[0], s_k = p.deq[1], s_v = p.deq[2], s_do = p.deq[3];
+  const float cs = p.scale * LOG2E * s_q * s_k;
+  Frag8 fr;
+  fr.init(lane);
+
+  f32x4 dk[NDB][2], dv[NDB][2];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) { dk[db][cb] = zero4(); dv[db][cb] = zero4(); }
+  const int nqt = (p.Lq + 127) / 128;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) { retire(kf[cb]); retire(vf[cb]); }
+  retire(cs);
+  VDS_WAIT_VM(0);
+  __syncthreads();
+
+  auto q_tile = [&](int j, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    if (j + 1 < nqt) issue_tile(j + 1, par ^ 1);
+    const char* qt = smem + par * 2 * TILE;
+    const char* dot = qt + TILE;
+    const float* stl = reinterpret_cast<const float*>(stats + par * 1024);
+    i32x8 pq[2], dsq[2];
+    static_for<8>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const i32x8 aq = fr.row<i>(qt);
+      const i32x8 ad = fr.row<i>(dot);
+      // accumulator register r <-> query 32 g + 4 i + r of the tile
+      const f32x4 nl4 = *reinterpret_cast<const f32x4*>(stl + 32 * g + 4 * i);
+      const f32x4 nd4 = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g + 4 * i);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const f32x4 s = mfma8<0, 0>(aq, kf[cb], zero4());
+        const f32x4 dp = mfma8<1, 0>(ad, vf[cb], nd4);  // dO (e5m2) V^T - delta, in units of s_do s_v
+        f32x4 pr, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cs, nl4[r]));  // 256 P
+          ds[r] = pr[r] * dp[r];
+        }
+        pq[cb][i] = cvt4_e4m3(pr);
+        dsq[cb][i] = cvt4_e5m2(ds);
+      }
+    });
+    static_for<NDB>([&](auto DB) {
+      constexpr int db = decltype(DB)::value;
+      const i32x8 ado = fr.trans<db>(dot);
+      const i32x8 aqt = fr.trans<db>(qt);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        dv[db][cb] = mfma8<1, 0>(ado, pq[cb], dv[db][cb]);
+        dk[db][cb] = mfma8<0, 1>(aqt, dsq[cb], dk[db][cb]);
+      }
+    });
+    VDS_WAIT_VM(0);
+    __syncthreads();
+  };
+  for (int j = 0; j < nqt; j += 2) {
+    q_tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nqt) q_tile(j + 1, std::integral_constant<int, 1>{});
+  }
+  const float fk = p.scale * s_do * s_v * s_q * (1.0f / 256.0f);  // dS_q = 256 dS / (s_do s_v)
+  const float fv = s_do * (1.0f / 256.0f);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int krow = key0 + 16 * cb;
+    if (krow >= p.Lk) continue;
+    bf16_t* dkp = p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl;
+    bf16_t* dvp = p.dv + b * p.dv_sb + hh * p.dv_sh + (long)krow * p.dv_sl;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      const int d = db * 16 + 4 * g;
+      if (d >= HD) continue;
+      const u32x2 wk = {pack_bf2(dk[db][cb][0] * fk, dk[db][cb][1] * fk), pack_bf2(dk[db][cb][2] * fk, dk[db][cb][3] * fk)};
+      const u32x2 wv = {pack_bf2(dv[db][cb][0] * fv, dv[db][cb][1] * fv), pack_bf2(dv[db][cb][2] * fv, dv[db][cb][3] * fv)};
+      *reinterpret_cast<u32x2*>(dkp + d) = wk;
+      *reinterpret_cast<u32x2*>(dvp + d) = wv;
+    }
+  }
+}
+
+// ===================================== dQ ===================================================
+// Workgroup = 128 queries (4 waves x 2 column blocks of 16), Q / dO rows as B operands in registers, the query's
+// 8 - lse2 as the exponent's addend and -delta' as the dP accumulator's start; K / V tiles of 128 keys by LDS-DMA.
+// Keys past Lk are zero rows of K: whatever dS they get multiplies a zero column of K^T.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
+  static_assert(HD == 72, "5 output blocks of 16");
+  constexpr int NDB = 5;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bh, qt;
+  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  const int b = bh / p.H, hh = bh % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qrow0 = qt * 128 + wave * 32 + (lane & 15);
+  const long head = (long)b * p.H + hh;
+  const long nrows = (long)p.B * p.H * p.Lq;
+
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q + head * p.Lq * ROWB, (unsigned)(p.Lq * ROWB));
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(p.d_o + head * p.Lq * ROWB, (unsigned)(p.Lq * ROWB));
+  const srd_t rk = make_srd(p.k + head * p.Lk * ROWB, (unsigned)(p.Lk * ROWB));
+  const srd_t rv = make_srd(p.v + head * p.Lk * ROWB, (unsigned)(p.Lk * ROWB));
+  Stage8 st;
+  st.init(wave, lane);
+  st.issue(rk, smem, 0, wave);
+  st.issue(rv, smem + TILE, 0, wave);
+
+  i32x8 qf[2], dof[2];
+  float nl[2];
+  f32x4 nd4[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int qrow = qrow0 + 16 * cb;
+    qf[cb] = load_row32(rq, qrow, g);
+    dof[cb] = load_row32(rdo, qrow, g);
+    const long srow = head * p.Lq + min(qrow, p.Lq - 1);
+    const float nd = p.stats[srow];
+    nl[cb] = p.stats[nrows + srow];
+    nd4[cb] = f32x4{nd, nd, nd, nd};
+  }
+  const float s_q = p.deq[0], s_k = p.deq[1], s_v = p.deq[2], s_do = p.deq[3];
+  const float cs = p.scale * LOG2E * s_q * s_k;
+  Frag8 fr;
+  fr.init(lane);
+
+  f32x4 dq[NDB][2];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) dq[db][cb] = zero4();
+  const int nkt = (p.Lk + 127) / 128;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) { retire(qf[cb]); retire(dof[cb]); retire(nl[cb]); retire(nd4[cb][0]); }
+  retire(cs);
+  VDS_WAIT_VM(0);
+  __syncthreads();
+
+  auto kv_tile = [&](int j, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    if (j + 1 < nkt) {
+      char* nk = smem + (par ^ 1) * 2 * TILE;
+      st.issue(rk, nk, (unsigned)(j + 1) * TILE, wave);
+      st.issue(rv, nk + TILE, (unsigned)(j + 1) * TILE, wave);
+    }
+    const char* kt = smem + par * 2 * TILE;
+    const char* vt = kt + TILE;
+    i32x8 dsq[2];
+    static_for<8>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const i32x8 ak = fr.row<i>(kt);
+      const i32x8 av = fr.row<i>(vt);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const f32x4 s = mfma8<0, 0>(ak, qf[cb], zero4());
+        const f32x4 dp = mfma8<0, 1>(av, dof[cb], nd4[cb]);
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cs, nl[cb])) * dp[r];
+        dsq[cb][i] = cvt4_e5m2(ds);
+      }
+    });
+    static_for<NDB>([&](auto DB) {
+      constexpr int db = decltype(DB)::value;
+      const i32x8 akt = fr.trans<db>(kt);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) dq[db][cb] = mfma8<0, 1>(akt, dsq[cb], dq[db][cb]);
+    });
+    VDS_WAIT_VM(0);
+    __syncthreads();
+  };
+  for (int j = 0; j < nkt; j += 2) {
+    kv_tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
+  }
+  const float fq = p.scale * s_do * s_v * s_k * (1.0f / 256.0f);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int qrow = qrow0 + 16 * cb;
+    if (qrow >= p.Lq) continue;
+    bf16_t* dqp = p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      const int d = db * 16 + 4 * g;
+      if (d >= HD) continue;
+      const u32x2 w = {pack_bf2(dq[db][cb][0] * fq, dq[db][cb][1] * fq), pack_bf2(dq[db][cb][2] * fq, dq[db][cb][3] * fq)};
+      *reinterpret_cast<u32x2*>(dqp + d) = w;
+    }
+  }
+}
+
+// ===================================== preprocess ===========================================
+// delta preprocess of the fp8 backward: one wave per token of the token-major O / dO ([B*Lq, H*hd] bf16, what the
+// model passes).  Per head:  stats[0][b,h,q] = -rowsum(dO o O) / (s_do s_v),  stats[1][b,h,q] = 8 - lse log2(e);
+// dO leaves as e5m2 rows [B,H,Lq,128] (bytes [hd,128) are never written: the buffer is zeroed once by its owner),
+// scaled so that the previous step's amax lands on DO_TARGET; the current amax is recorded (delayed scaling).
+constexpr float DO_TARGET = 0.0625f;  // dO_q in [2^-16, 2^-4]: dS_q = 256 P dP' then stays below the e5m2 maximum
+__global__ __launch_bounds__(256) void attn8_delta_kernel(const bf16_t* o, long o_sb, long o_sl, const bf16_t* d_o,
+                                                          long do_sb, long do_sl, const float* lse, float* stats,
+                                                          unsigned char* doq, const float* amax_prev, float* amax_cur,
+                                                          float* deq, int B, int H, int Lq, int hd) {
+  __shared__ float part[4][192];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long tok = (long)blockIdx.x * 4 + wave;
+  const float ap = *amax_prev;
+  const float alpha = ap > 0.f ? DO_TARGET / ap : 1.0f;
+  const float s_do = 1.0f / alpha;
+  if (blockIdx.x == 0 && threadIdx.x == 0) deq[3] = s_do;
+  if (tok >= (long)B * Lq) return;
+  const int b = (int)(tok / Lq), q = (int)(tok % Lq);
+  const int nch = H * hd / 8, cph = hd / 8;
+  const bf16_t* orow = o + b * o_sb + (long)q * o_sl;
+  const bf16_t* drow = d_o + b * do_sb + (long)q * do_sl;
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(orow + c * 8);
+      const u32x4 gq = *reinterpret_cast<const u32x4*>(drow + c * 8);
+      float acc = 0.f;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f[2 * e] = bflo(gq[e]);
+        f[2 * e + 1] = bfhi(gq[e]);
+        acc += bflo(a[e]) * f[2 * e] + bfhi(a[e]) * f[2 * e + 1];
+      }
+      part[wave][c] = acc;
+      u32x2 w;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        int x = 0;
+        x = __builtin_amdgcn_cvt_pk_bf8_f32(f[4 * e] * alpha, f[4 * e + 1] * alpha, x, false);
+        x = __builtin_amdgcn_cvt_pk_bf8_f32(f[4 * e + 2] * alpha, f[4 * e + 3] * alpha, x, true);
+        w[e] = (unsigned)x;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+      const int hh = c / cph, ci = c % cph;
+      *reinterpret_cast<u32x2*>(doq + (((long)b * H + hh) * Lq + q) * ROWB + 8 * ci) = w;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes
+  __builtin_amdgcn_wave_barrier();
+  if (lane < H) {
+    float acc = 0.f;
+    for (int i = 0; i < cph; ++i) acc += part[wave][lane * cph + i];
+    const long rows = (long)B * H * Lq;
+    const long row = ((long)b * H + lane) * Lq + q;
+    stats[row] = -acc / (s_do * deq[2]);
+    stats[rows + row] = P_SHIFT - lse[row] * LOG2E;
+  }
+  amax = wave_max(amax);
+  if (lane == 0 && amax > *amax_cur) atomicMax(reinterpret_cast<int*>(amax_cur), __float_as_int(amax));
+}
+
+// qkv head split + 3-D RoPE + residual-V mix (model.py:125-134,266-275) with fp8 outputs: q, k, v leave as e4m3 rows
+// [B,H,L,128] (bytes [hd,128) zero, V byte hd = 1.0: the softmax denominator's ones column), each scaled so that the
+// previous step's amax of the tensor lands on 448; the current amax is recorded.  The values quantised are the bf16
+// results of the bf16 kernel (vds_qkv_rope_fwd), rounding points included.  v_out (optional): the bf16 v in the
+// padded head-major layout -- block 0's v feeds the residual-V mix of the later blocks.
+// One thread = one 16-byte output chunk (16 head-dim columns) of one (tensor, token, head); blockIdx.y = tensor.
+__global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_kernel(const bf16_t* qkv, const float* cosb, const float* sinb,
+                                                               const bf16_t* v0, const bf16_t* lamp, unsigned char* q8,
+                                                               unsigned char* k8, unsigned char* v8, bf16_t* v_out,
+                                                               const float* amax_prev, float* amax_cur, int amax_stride,
+                                                               float* deq, int B, int L, int H, int hd, int hdp) {
+  const int which = blockIdx.y;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)B * H * L * 8;
+  const float ap = amax_prev[which * amax_stride];
+  const float alpha = ap > 0.f ? 448.0f / ap : 1.0f;
+  if (gid == 0) deq[which] = 1.0f / alpha;
+  float amax = 0.f;
+  if (gid < n) {
+    const int c = (int)(gid & 7);
+    const long row = gid >> 3;  // (b*H + h)*L + l
+    const int l = (int)(row % L);
+    const long bhx = row / L;
+    const int hh = (int)(bhx % H), b = (int)(bhx / H);
+    const int half = hd >> 1, D = H * hd;
+    const bf16_t* src = qkv + ((long)b * L + l) * 3 * D + which * D + hh * hd;
+    unsigned char* dst = (which == 0 ? q8 : which == 1 ? k8 : v8) + row * ROWB + 16 * c;
+    float y[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) y[e] = 0.f;
+    const int d0 = 16 * c;
+    if (d0 < hd) {
+      if (which < 2) {
+        const float* cr = cosb + (long)l * half;
+        const float* sr = sinb + (long)l * half;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int d = d0 + e;
+          if (d < hd) {
+            const bool lo = d < half;
+            const int j = lo ? d : d - half;
+            const float x = bf2f(src[d]), pt = bf2f(src[lo ? d + half : d - half]);
+            const float v = lo ? x * cr[j] + pt * sr[j] : x * cr[j] - pt * sr[j];
+            y[e] = bf2f(f2bf(v));
+          }
+        }
+      } else {
+        float lam = 0.f, oml = 0.f;
+        const bf16_t* v0r = nullptr;
+        if (v0) {
+          lam = bf2f(*lamp);
+          oml = bf2f(f2bf(1.0f - lam));
+          v0r = v0 + row * hdp;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int d = d0 + e;
+          if (d < hd) {
+            float x = bf2f(src[d]);
+            if (v0) x = bf2f(f2bf(bf2f(f2bf(lam * x)) + bf2f(f2bf(oml * bf2f(v0r[d])))));
+            y[e] = x;
+          }
+        }
+        if (v_out) {
+          bf16_t* vo = v_out + row * hdp;
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (d0 + e < hdp) vo[d0 + e] = d0 + e < hd ? f2bf(y[e]) : (bf16_t)(((hdp - hd) >= 8 && (d0 + e == hd || d0 + e == hd + 4)) ? 0x3f80 : 0);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(y[e]));
+    } else if (which == 2 && v_out) {
+      bf16_t* vo = v_out + row * hdp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (d0 + e < hdp) vo[d0 + e] = 0;
+    }
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = fp8_cvt4<0>(y[4 * e] * alpha, y[4 * e + 1] * alpha, y[4 * e + 2] * alpha, y[4 * e + 3] * alpha);
+    if (which == 2 && hd >= d0 && hd < d0 + 16) {  // ones column: byte hd of every V row = 1.0 (e4m3 0x38)
+      const int e = hd - d0;
+      w[e >> 2] = (w[e >> 2] & ~(0xffu << (8 * (e & 3)))) | (0x38u << (8 * (e & 3)));
+    }
+    *reinterpret_cast<u32x4*>(dst) = w;
+  }
+  amax = wave_max(amax);
+  float* ac = amax_cur + which * amax_stride;
+  if ((threadIdx.x & 63) == 0 && amax > *ac) atomicMax(reinterpret_cast<int*>(ac), __float_as_int(amax));
+}
+
+template <typename K>
+void set_lds(K kern, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+bool args_ok(const vds_attn_fp8_args* a, bool bwd) {
+  if (!a || !a->q || !a->k || !a->v || !a->deq || a->B <= 0 || a->H <= 0 || a->Lq <= 0 || a->Lk <= 0) return false;
+  if ((long)a->Lq * ROWB > 0x7fffffffL || (long)a->Lk * ROWB > 0x7fffffffL) return false;
+  if (!bwd) return a->o && a->lse && (a->o_sb % 4 == 0) && (a->o_sh % 4 == 0) && (a->o_sl % 4 == 0);
+  return a->d_o && a->stats && a->dq && a->dk && a->dv && (a->dq_sl % 4 == 0) && (a->dk_sl % 4 == 0) &&
+         (a->dv_sl % 4 == 0) && (a->dq_sh % 4 == 0) && (a->dk_sh % 4 == 0) && (a->dv_sh % 4 == 0) &&
+         (a->dq_sb % 4 == 0) && (a->dk_sb % 4 == 0) && (a->dv_sb % 4 == 0);
+}
+
+Attn8P to_p(const vds_attn_fp8_args* a) {
+  Attn8P p;
+  p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.hd = a->head_dim;
+  p.q = (const unsigned char*)a->q; p.k = (const unsigned char*)a->k; p.v = (const unsigned char*)a->v;
+  p.d_o = (const unsigned char*)a->d_o;
+  p.o = (bf16_t*)a->o; p.o_sb = a->o_sb; p.o_sh = a->o_sh; p.o_sl = a->o_sl;
+  p.lse = a->lse;
+  p.dq = (bf16_t*)a->dq; p.dq_sb = a->dq_sb; p.dq_sh = a->dq_sh; p.dq_sl = a->dq_sl;
+  p.dk = (bf16_t*)a->dk; p.dk_sb = a->dk_sb; p.dk_sh = a->dk_sh; p.dk_sl = a->dk_sl;
+  p.dv = (bf16_t*)a->dv; p.dv_sb = a->dv_sb; p.dv_sh = a->dv_sh; p.dv_sl = a->dv_sl;
+  p.stats = a->stats;
+  p.deq = a->deq;
+  p.scale = 1.0f / sqrtf((float)a->head_dim);
+  p.n_rt = 0;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int vds_attn_fp8_supported(int32_t head_dim) { return head_dim == 72 ? 1 : 0; }
+
+extern "C" int vds_attn_fp8_fwd(const vds_attn_fp8_args* a, vds_stream_t stream) {
+  if (!args_ok(a, false)) return VDS_ERR_ARG;
+  if (a->head_dim != 72) return VDS_ERR_UNSUPPORTED;
+  constexpr int LDS = 4 * TILE;
+  static bool once = false;
+  if (!once) { set_lds(attn8_fwd_kernel<72>, LDS); once = true; }
+  Attn8P p = to_p(a);
+  p.n_rt = cdiv(p.Lq, 256);
+  const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
+  hipStream_t s = (hipStream_t)stream;
+  vdsprof::Scope ps(VDS_PROF_ATTN_FP8_FWD, s, 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd,
+                    (double)p.B * p.H * (ROWB * (p.Lq + 2.0 * p.Lk) + 2.0 * p.hd * p.Lq));
+  hipLaunchKernelGGL((attn8_fwd_kernel<72>), dim3(grid), dim3(256), LDS, s, p);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+extern "C" size_t vds_attn_fp8_bwd_workspace_bytes(const vds_attn_fp8_args* a) {
+  if (!a || a->B <= 0 || a->H <= 0 || a->Lq <= 0) return 0;
+  return (size_t)2 * a->B * a->H * a->Lq * sizeof(float);
+}
+
+// dO preprocess: o / d_o token-major bf16 [B*Lq, H*hd] (row strides o_sl / do_sl elements, batch strides o_sb / do_sb)
+extern "C" int vds_attn_fp8_delta(const void* o, int64_t o_sb, int64_t o_sl, const void* d_o, int64_t do_sb,
+                                  int64_t do_sl, const float* lse, float* stats, void* doq, const float* amax_prev,
+                                  float* amax_cur, float* deq, int32_t B, int32_t H, int32_t Lq, int32_t head_dim,
+                                  vds_stream_t stream) {
+  if (!o || !d_o || !lse || !stats || !doq || !amax_prev || !amax_cur || !deq || B <= 0 || H <= 0 || Lq <= 0)
+    return VDS_ERR_ARG;
+  if ((head_dim & 7) || (o_sl & 7) || (o_sb & 7) || (do_sl & 7) || (do_sb & 7)) return VDS_ERR_ARG;
+  if (H * head_dim > 1536 || H > 64 || head_dim > ROWB) return VDS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const double rows = (double)B * H * Lq;
+  vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DELTA, s, 2.0 * rows * head_dim, 5.0 * rows * head_dim);
+  hipLaunchKernelGGL(attn8_delta_kernel, dim3((unsigned)(((long)B * Lq + 3) / 4)), dim3(256), 0, s, (const bf16_t*)o,
+                     (long)o_sb, (long)o_sl, (const bf16_t*)d_o, (long)do_sb, (long)do_sl, lse, stats,
+                     (unsigned char*)doq, amax_prev, amax_cur, deq, B, H, Lq, head_dim);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+extern "C" int vds_attn_fp8_bwd(const vds_attn_fp8_args* a, vds_stream_t stream) {
+  if (!args_ok(a, true)) return VDS_ERR_ARG;
+  if (a->head_dim != 72) return VDS_ERR_UNSUPPORTED;
+  constexpr int LDS_DKV = 4 * TILE + 2 * 1024, LDS_DQ = 4 * TILE;
+  static bool once = false;
+  if (!once) {
+    set_lds(attn8_bwd_dkv_kernel<72>, LDS_DKV);
+    set_lds(attn8_bwd_dq_kernel<72>, LDS_DQ);
+    once = true;
+  }
+  Attn8P p = to_p(a);
+  hipStream_t s = (hipStream_t)stream;
+  const double prod = 2.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;  // credit as in attention.hip: 2 + 2 products
+  const double bytes = (double)p.B * p.H * ROWB * (2.0 * p.Lq + 2.0 * p.Lk);
+  p.n_rt = cdiv(p.Lk, 128);
+  int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
+  {
+    vdsprof::Scope ps(VDS_PROF_ATTN_FP8_DKV, s, 2.0 * prod, bytes + 4.0 * p.B * p.H * p.hd * (double)p.Lk);
+    hipLaunchKernelGGL((attn8_bwd_dkv_kernel<72>), dim3(grid), dim3(256), LDS_DKV, s, p);
+  }
+  p.n_rt = cdiv(p.Lq, 128);
+  grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
+  {
+    vdsprof::Scope ps(VDS_PROF_ATTN_FP8_DQ, s, 2.0 * prod, bytes + 2.0 * p.B * p.H * p.hd * (double)p.Lq);
+    hipLaunchKernelGGL((attn8_bwd_dq_kernel<72>), dim3(grid), dim3(256), LDS_DQ, s, p);
+  }
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+// amax_prev / amax_cur: the q, k, v entries at element stride `amax_stride` (fp8.AmaxHistory rows are [prev, cur] pairs)
+extern "C" int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const float* sinb, const void* v0,
+                                    const void* lam, void* q8, void* k8, void* v8, void* v_out, const float* amax_prev,
+                                    float* amax_cur, int32_t amax_stride, float* deq, int32_t B, int32_t L, int32_t H,
+                                    int32_t hd, int32_t hdp, vds_stream_t stream) {
+  if (!qkv || !cosb || !sinb || !q8 || !k8 || !v8 || !amax_prev || !amax_cur || !deq || (hd & 7) || hd >= ROWB ||
+      hdp < hd)
+    return VDS_ERR_ARG;
+  if (v0 && !lam) return VDS_ERR_ARG;
+  const long n = (long)B * H * L * 8;
+  hipStream_t s = (hipStream_t)stream;
+  vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, s, 0.0, (double)B * L * H * (6.0 * hd + 3.0 * ROWB + (v0 ? 2.0 * hd : 0.0)));
+  hipLaunchKernelGGL(qkv_rope_fwd_fp8_kernel, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, s, (const bf16_t*)qkv,
+                     cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (unsigned char*)q8, (unsigned char*)k8,
+                     (unsigned char*)v8, (bf16_t*)v_out, amax_prev, amax_cur, amax_stride, deq, B, L, H, hd, hdp);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}

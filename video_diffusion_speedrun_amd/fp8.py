@@ -33,6 +33,10 @@ from ._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_F32, EPI_GATE_RES, EPI_STORE
 
 bf16, f32 = torch.bfloat16, torch.float32
 E4M3, E5M2 = ops.FP8_E4M3, ops.FP8_E5M2
+# rows of the delayed-scaling table per DiT block: 0 gelu(fc1), 1 d(fc2 input), 2 xn1 (qkv input), 3 xn3 (fc1 input),
+# 4 d(mlp output), 5 d(qkv output); fp8 attention: 6 q, 7 k, 8 v (post-RoPE / lambda-mix), 9 d(attention output)
+ROWS = 10
+ROW_Q, ROW_DO = 6, 9
 
 
 class Q:
@@ -119,6 +123,12 @@ class AmaxHistory:
             if self._bwd_seen:
                 self.ready = True
         self._fwd_seen, self._bwd_seen = True, False
+
+    def scratch(self, n: int):
+        """n zeroed floats for a producer's amax record that nobody reads (no-grad forwards)"""
+        if getattr(self, "_scratch", None) is None or self._scratch.numel() < n:
+            self._scratch = torch.zeros(max(n, 8), dtype=f32, device=self.tab.device)
+        return self._scratch[:n]
 
     def backward_done(self):
         self._bwd_seen = True

@@ -317,7 +317,7 @@ class DiTBlock(nn.Module):
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
         hdp = {64: 64, 72: 96, 128: 128}[hd]
         use_fp8 = fp8 is not None
-        fp8_hist, i = fp8 if use_fp8 else (None, 0)
+        fp8_hist, i, fp8_attn = fp8 if use_fp8 else (None, 0, False)
         W = lambda n: G.w(pre + n)
         Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
         dev = X.device
@@ -333,25 +333,42 @@ class DiTBlock(nn.Module):
         xn1 = xn3 = None
         if pemit:
             fq, fs, rstd1 = ops.rmsnorm_mod_fwd_fp8(X, Wo("norm1.weight"), mod, 0, D, B, L, F8.E4M3,
-                                                  hist.prev(6 * i + 2), hist.part(6 * i + 2, B * L))
+                                                  hist.prev(F8.ROWS * i + 2), hist.part(F8.ROWS * i + 2, B * L))
             q_xn1 = F8.Q.from_rowmajor(fq, fs, save)
         else:
             xn1, rstd1 = ops.rmsnorm_mod_fwd(X, Wo("norm1.weight"), mod, 0, D, B, L)
         if f8:
             if not pemit:
-                q_xn1 = F8.Q(xn1, F8.E4M3, True, save, hist, 6 * i + 2)
+                q_xn1 = F8.Q(xn1, F8.E4M3, True, save, hist, F8.ROWS * i + 2)
             q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save)
             qkv = torch.empty(B * L, 3 * D, dtype=bf16, device=dev)
             F8.fwd(q_xn1, q_wqkv, qkv, Wo("qkv.bias"))
         else:
             qkv = ops.linear_fwd(xn1, W("qkv.weight"), Wo("qkv.bias"))
         mix = self.residual_v and v0 is not None
-        q, k, v = ops.qkv_rope_fwd(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None, B, L, H,
-                                   hd, hdp)
         attn = torch.empty(B * L, D, dtype=bf16, device=dev)
         lse1 = torch.empty(B, H, L, dtype=f32, device=dev)
-        ops.attn_fwd(q[..., :hd], k[..., :hd], v[..., :hd], ops.heads_view(attn, B, L, H, hd), lse1,
-                     kv_pad_ones=(hdp - hd) >= 8)
+        # fp8 attention (csrc/attention_fp8.hip): delayed scaling only -- q, k, v leave the RoPE kernel as e4m3 scaled by
+        # the previous step's amax; until a complete step has been recorded the bf16 kernels run and the amax is taken
+        a8_on = use_fp8 and fp8_attn and ops.attn_fp8_supported(hd)
+        a8 = a8_on and fp8_hist.ready
+        q = k = q8 = k8 = v8 = deq = None
+        if a8:
+            r0 = F8.ROWS * i + F8.ROW_Q
+            deq = torch.empty(4, dtype=f32, device=dev)
+            cur = fp8_hist.tab[r0:r0 + 3, 1] if save else fp8_hist.scratch(3)  # (no-grad forwards record nothing)
+            q8, k8, v8, v = ops.qkv_rope_fwd_fp8(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None,
+                                                 B, L, H, hd, hdp, fp8_hist.tab[r0:r0 + 3, 0], cur, 2, deq,
+                                                 want_v=self.residual_v and v0 is None)
+            ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(attn, B, L, H, hd), lse1, hd)
+        else:
+            q, k, v = ops.qkv_rope_fwd(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None, B, L, H,
+                                       hd, hdp)
+            ops.attn_fwd(q[..., :hd], k[..., :hd], v[..., :hd], ops.heads_view(attn, B, L, H, hd), lse1,
+                         kv_pad_ones=(hdp - hd) >= 8)
+            if a8_on and save:  # first steps: record the amax the next step quantises with
+                for j, t in enumerate((q, k, v)):
+                    ops.absmax(t.view(B * H * L, hdp)[:, :hd], fp8_hist.cur(F8.ROWS * i + F8.ROW_Q + j))
         y_sa, X1 = ops.linear_fwd_gate_res(attn, W("attn_proj.weight"), None, mod, 2 * D, X, L)
         # --- cross attention (model.py:142-160)
         has_cross = G.has(pre + "q_cross.weight")
@@ -369,20 +386,20 @@ class DiTBlock(nn.Module):
         # --- MLP (model.py:163-165)
         if pemit:
             fq, fs, rstd3 = ops.rmsnorm_mod_fwd_fp8(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L, F8.E4M3,
-                                                  hist.prev(6 * i + 3), hist.part(6 * i + 3, B * L))
+                                                  hist.prev(F8.ROWS * i + 3), hist.part(F8.ROWS * i + 3, B * L))
             q_xn3 = F8.Q.from_rowmajor(fq, fs, save)
         else:
             xn3, rstd3 = ops.rmsnorm_mod_fwd(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L)
         if f8:
             if not pemit:
-                q_xn3 = F8.Q(xn3, F8.E4M3, True, save, hist, 6 * i + 3)
+                q_xn3 = F8.Q(xn3, F8.E4M3, True, save, hist, F8.ROWS * i + 3)
             q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save)
             if emit:  # gelu(fc1) leaves the GEMM as fp8
-                hpre, q_hact = F8.fwd_gelu_emit(q_xn3, q_w1, W("mlp.0.bias"), hist.prev(6 * i), hist.cur(6 * i), save)
+                hpre, q_hact = F8.fwd_gelu_emit(q_xn3, q_w1, W("mlp.0.bias"), hist.prev(F8.ROWS * i), hist.cur(F8.ROWS * i), save)
                 hact = None
             else:
                 hpre, hact = F8.fwd_gelu(q_xn3, q_w1, W("mlp.0.bias"))
-                q_hact = F8.Q(hact, F8.E4M3, True, save, hist, 6 * i)
+                q_hact = F8.Q(hact, F8.E4M3, True, save, hist, F8.ROWS * i)
             q_w2 = F8.Q(W("mlp.2.weight"), F8.E4M3, True, save)
             y_mlp, X3 = F8.fwd_gate_res(q_hact, q_w2, W("mlp.2.bias"), mod, 8 * D, X2, L)
         else:
@@ -393,6 +410,9 @@ class DiTBlock(nn.Module):
             bs = _Saved()
             bs.mod, bs.X, bs.X1, bs.X2 = mod, X, X1, X2
             bs.xn1, bs.rstd1, bs.qkv, bs.q, bs.k, bs.v, bs.attn, bs.lse1, bs.y_sa = xn1, rstd1, qkv, q, k, v, attn, lse1, y_sa
+            bs.a8, bs.a8_on, bs.q8, bs.k8, bs.v8, bs.deq = a8, a8_on, q8, k8, v8, deq
+            if a8:
+                bs.v = None  # (block 0's bf16 v lives on as v_0; the backward contracts the fp8 copies)
             bs.mix, bs.has_cross = mix, has_cross
             if has_cross:
                 bs.xn2, bs.rstd2, bs.qc, bs.ckv, bs.catt, bs.lse2, bs.y_ca = xn2, rstd2, qc, ckv, catt, lse2, y_ca
@@ -410,7 +430,7 @@ class DiTBlock(nn.Module):
         sv carries cos, sin, v0, ctx2d, cvec.  first: this is the block whose v was handed out as v_0."""
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
         hdp = {64: 64, 72: 96, 128: 128}[hd]
-        fp8_hist, i = fp8 if fp8 is not None else (None, 0)
+        fp8_hist, i, _ = fp8 if fp8 is not None else (None, 0, False)
         W = lambda n: G.w(pre + n)
         Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
         Gr = lambda n: G.g(pre + n)
@@ -426,22 +446,22 @@ class DiTBlock(nn.Module):
         pemit = emit and not _NO_PRODUCER_EMIT
         if pemit:  # the fc2 output gradient leaves gate_bwd as e5m2
             fq, fs = ops.gate_bwd_fp8(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L, F8.E5M2,
-                                    hist.prev(6 * i + 4), hist.part(6 * i + 4, B * L))
+                                    hist.prev(F8.ROWS * i + 4), hist.part(F8.ROWS * i + 4, B * L))
             q_dy = F8.Q.from_rowmajor(fq, fs, True)
             dy = None
         else:
             dy = ops.gate_bwd(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L)
         if bs.f8:
             if not pemit:
-                q_dy = F8.Q(dy, F8.E5M2, True, True, hist, 6 * i + 4)
+                q_dy = F8.Q(dy, F8.E5M2, True, True, hist, F8.ROWS * i + 4)
             F8.wgrad(q_dy, bs.q_hact, Gr("mlp.2.weight"))
             if emit:  # the fc2 input gradient leaves the GEMM as e5m2 (+ transposed, + bias gradient)
                 dh = None
-                q_dh = F8.dgrad_gelu_emit(q_dy, bs.q_w2, bs.hpre, hist.prev(6 * i + 1), hist.cur(6 * i + 1),
+                q_dh = F8.dgrad_gelu_emit(q_dy, bs.q_w2, bs.hpre, hist.prev(F8.ROWS * i + 1), hist.cur(F8.ROWS * i + 1),
                                           Gr("mlp.0.bias"))
             else:
                 dh = F8.dgrad(q_dy, bs.q_w2, pre=bs.hpre)
-                q_dh = F8.Q(dh, F8.E5M2, True, True, hist, 6 * i + 1)
+                q_dh = F8.Q(dh, F8.E5M2, True, True, hist, F8.ROWS * i + 1)
                 ops.colsum(dh, Gr("mlp.0.bias"))
             F8.wgrad(q_dh, bs.q_xn3, Gr("mlp.0.weight"))
             dxn = F8.dgrad(q_dh, bs.q_w1)
@@ -484,17 +504,27 @@ class DiTBlock(nn.Module):
         dq = torch.empty(B, H, L, hdp, dtype=bf16, device=dev)
         dk = torch.empty_like(dq)
         dv = torch.empty_like(dq)
-        delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
-        ops.attn_bwd(bs.q[..., :hd], bs.k[..., :hd], bs.v[..., :hd], ops.heads_view(bs.attn, B, L, H, hd), bs.lse1,
-                     ops.heads_view(dattn, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta,
-                     kv_pad_ones=(hdp - hd) >= 8)
+        if bs.a8:
+            r9 = F8.ROWS * i + F8.ROW_DO
+            if getattr(sv, "doq", None) is None:  # one e5m2 dO buffer per backward pass; its pad bytes stay zero
+                sv.doq = torch.zeros(B, H, L, ops.FP8_ROW, dtype=torch.float8_e5m2, device=dev)
+            stats = ops.attn_fp8_delta(bs.attn, dattn, bs.lse1, sv.doq, fp8_hist.prev(r9), fp8_hist.cur(r9), bs.deq,
+                                       B, H, L, hd)
+            ops.attn_fp8_bwd(bs.q8, bs.k8, bs.v8, sv.doq, stats, bs.deq, dq[..., :hd], dk[..., :hd], dv[..., :hd], hd)
+        else:
+            delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
+            ops.attn_bwd(bs.q[..., :hd], bs.k[..., :hd], bs.v[..., :hd], ops.heads_view(bs.attn, B, L, H, hd), bs.lse1,
+                         ops.heads_view(dattn, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta,
+                         kv_pad_ones=(hdp - hd) >= 8)
+            if bs.a8_on:
+                ops.absmax(dattn, fp8_hist.cur(F8.ROWS * i + F8.ROW_DO))
         rope_args = (dq, dk, dv, sv.cos, sv.sin, bs.qkv if bs.mix else None, sv.v0 if bs.mix else None,
                      W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),
                      Gr("lambda_param") if bs.mix else None, bs.mix, first and dv0 is not None, B, L, H, hd, hdp)
         # the qkv output gradient leaves the RoPE backward as e5m2 (a qkv bias gradient needs the bf16 tensor)
         emit_dqkv = pemit and not G.has(pre + "qkv.bias") and hdp % 8 == 0 and D <= 2048
         if emit_dqkv:
-            fq, fs = ops.qkv_rope_bwd_fp8(*rope_args, F8.E5M2, hist.prev(6 * i + 5), hist.part(6 * i + 5, B * L))
+            fq, fs = ops.qkv_rope_bwd_fp8(*rope_args, F8.E5M2, hist.prev(F8.ROWS * i + 5), hist.part(F8.ROWS * i + 5, B * L))
             q_dqkv = F8.Q.from_rowmajor(fq, fs, True)
         else:
             dqkv = ops.qkv_rope_bwd(*rope_args)
@@ -502,7 +532,7 @@ class DiTBlock(nn.Module):
             ops.colsum(dqkv, Gr("qkv.bias"))
         if bs.f8:
             if not emit_dqkv:
-                q_dqkv = F8.Q(dqkv, F8.E5M2, True, True, fp8_hist, 6 * i + 5)
+                q_dqkv = F8.Q(dqkv, F8.E5M2, True, True, fp8_hist, F8.ROWS * i + 5)
             F8.wgrad(q_dqkv, bs.q_xn1, Gr("qkv.weight"))
             dxn = F8.dgrad(q_dqkv, bs.q_wqkv)
             del q_dqkv
@@ -561,11 +591,14 @@ class DiT(nn.Module):
         self._world, self._rank, self._pg = 1, 0, None
         self._fsdp = None  # set by fsdp.apply_fsdp
         self.fp8 = False   # enable_fp8(): qkv / mlp GEMMs on the fp8 MFMA path (fp8.py; BASELINE config 5)
+        self.fp8_attn = False  # ... and the self-attention products
 
-    def enable_fp8(self, on: bool = True):
+    def enable_fp8(self, on: bool = True, attention: bool = True):
         """Run the qkv and MLP linears of every block in OCP fp8 (e4m3 activations / weights, e5m2 gradients,
-        per-tensor current scaling; fp8.py states the recipe).  The reference has no such mode."""
+        per-tensor scaling) and, with `attention`, the self-attention products on the fp8 MFMA as well (head_dim 72:
+        e4m3 Q / K / V / P, e5m2 dO / dS; fp8.py states the recipe).  The reference has no such mode."""
         self.fp8 = bool(on)
+        self.fp8_attn = bool(on and attention)
         self._fp8_hist = None  # fp8.AmaxHistory: 6 rows per block (gelu(fc1), d fc2-in, xn1, xn3, d mlp-out, d qkv)
         return self
 
@@ -668,7 +701,7 @@ class DiT(nn.Module):
         sv = _Saved() if save else None
         if self.fp8:
             if getattr(self, "_fp8_hist", None) is None or self._fp8_hist.tab.device != dev:
-                self._fp8_hist = F8.AmaxHistory(6 * self.depth, dev)
+                self._fp8_hist = F8.AmaxHistory(F8.ROWS * self.depth, dev)
             if save:
                 self._fp8_hist.ensure_part(B * (t * h * w + N_REG))  # before roll(): see AmaxHistory.ensure_part
                 self._fp8_hist.roll()
@@ -704,7 +737,7 @@ class DiT(nn.Module):
             if fs is not None:
                 fs.pre_forward_block(i)
             X, v, bs = self.blocks[i]._fwd(self.block_group(i), f"blocks.{i}.", X, ctx2d, cvec, v0, cos, sin, B, L, Lc,
-                                           save, (self._fp8_hist, i) if self.fp8 else None,
+                                           save, (self._fp8_hist, i, self.fp8_attn) if self.fp8 else None,
                                            mods[i] if mods is not None else None)
             if v0 is None:
                 v0 = v
@@ -768,7 +801,7 @@ class DiT(nn.Module):
             if fs is not None:
                 fs.pre_backward_block(i)
             dX = self.blocks[i]._bwd(self.block_group(i), f"blocks.{i}.", sv.blocks[i], dX, sv, dc, dv0, B, L, Lc,
-                                     i == 0, (self._fp8_hist, i) if self.fp8 else None,
+                                     i == 0, (self._fp8_hist, i, self.fp8_attn) if self.fp8 else None,
                                      dmods[i] if dmods is not None else None)
             sv.blocks[i] = None
             if fs is not None:

@@ -222,6 +222,67 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta=None, kv_pad_ones: bool = Fa
     check(_lib.load().vds_attn_bwd(C.byref(a), _stream()), f"vds_attn_bwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
 
 
+# ---------------------------------------------------------------------- fp8 attention ----
+FP8_ROW = 128  # bytes of an fp8 head row ([B,H,L,128]: head_dim data bytes + pad)
+
+
+def attn_fp8_supported(hd: int) -> bool:
+    return bool(_lib.load().vds_attn_fp8_supported(int(hd)))
+
+
+def qkv_rope_fwd_fp8(qkv, cos, sin, v0, lam, B, L, H, hd, hdp, amax_prev, amax_cur, amax_stride, deq, want_v=False):
+    """qkv_rope_fwd with e4m3 outputs: -> (q8, k8, v8 [B,H,L,128] float8_e4m3fn, v bf16 [B,H,L,hdp] or None).
+    amax_prev / amax_cur: f32 views whose elements 0, stride, 2*stride are the q, k, v amax of the previous / this
+    step; deq: f32[4], entries 0..2 receive the dequantisation factors."""
+    dev = qkv.device
+    q8 = torch.empty(B, H, L, FP8_ROW, dtype=torch.float8_e4m3fn, device=dev)
+    k8 = torch.empty_like(q8)
+    v8 = torch.empty_like(q8)
+    v = torch.empty(B, H, L, hdp, dtype=bf16, device=dev) if want_v else None
+    check(_lib.load().vds_qkv_rope_fwd_fp8(_p(qkv), _p(cos), _p(sin), _p(v0), _p(lam), _p(q8), _p(k8), _p(v8), _p(v),
+                                           _p(amax_prev), _p(amax_cur), amax_stride, _p(deq), B, L, H, hd, hdp,
+                                           _stream()), "vds_qkv_rope_fwd_fp8")
+    return q8, k8, v8, v
+
+
+def _attn8_args(q8, k8, v8, deq, hd):
+    B, H, Lq, row = q8.shape
+    assert row == FP8_ROW and q8.is_contiguous() and k8.is_contiguous() and v8.is_contiguous()
+    assert deq.dtype == f32 and deq.numel() >= 4 and deq.is_contiguous()
+    a = _lib.Attn8Args()
+    a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, k8.shape[2], hd
+    a.q, a.k, a.v, a.deq = _p(q8), _p(k8), _p(v8), _p(deq)
+    return a
+
+
+def attn_fp8_fwd(q8, k8, v8, deq, o, lse, hd):
+    """fp8 self-attention forward: q8/k8/v8 from qkv_rope_fwd_fp8, o [B,H,Lq,hd] bf16 strided view, lse f32 [B,H,Lq]"""
+    a = _attn8_args(q8, k8, v8, deq, hd)
+    a.o, (a.o_sb, a.o_sh, a.o_sl) = _p(o), _st(o)
+    a.lse = _p(lse)
+    check(_lib.load().vds_attn_fp8_fwd(C.byref(a), _stream()), f"vds_attn_fp8_fwd(B={a.B},H={a.H},Lq={a.Lq},Lk={a.Lk})")
+
+
+def attn_fp8_delta(o2d, do2d, lse, doq, amax_prev, amax_cur, deq, B, H, L, hd):
+    """backward preprocess over the token-major bf16 o / dO [B*L, H*hd]: -> stats f32 [2,B,H,L]; fills doq (e5m2
+    [B,H,L,128], pad bytes untouched: allocate it zeroed once), deq[3]; records dO's amax"""
+    assert o2d.stride(1) == 1 and do2d.stride(1) == 1 and doq.is_contiguous() and doq.shape == (B, H, L, FP8_ROW)
+    stats = torch.empty(2, B, H, L, dtype=f32, device=o2d.device)
+    check(_lib.load().vds_attn_fp8_delta(_p(o2d), L * o2d.stride(0), o2d.stride(0), _p(do2d), L * do2d.stride(0),
+                                         do2d.stride(0), _p(lse), _p(stats), _p(doq), _p(amax_prev), _p(amax_cur),
+                                         _p(deq), B, H, L, hd, _stream()), "vds_attn_fp8_delta")
+    return stats
+
+
+def attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dq, dk, dv, hd):
+    a = _attn8_args(q8, k8, v8, deq, hd)
+    a.d_o, a.stats = _p(doq), _p(stats)
+    a.dq, (a.dq_sb, a.dq_sh, a.dq_sl) = _p(dq), _st(dq)
+    a.dk, (a.dk_sb, a.dk_sh, a.dk_sl) = _p(dk), _st(dk)
+    a.dv, (a.dv_sb, a.dv_sh, a.dv_sl) = _p(dv), _st(dv)
+    check(_lib.load().vds_attn_fp8_bwd(C.byref(a), _stream()), f"vds_attn_fp8_bwd(B={a.B},H={a.H},Lq={a.Lq},Lk={a.Lk})")
+
+
 def attn_set_variant(mask: int) -> int:
     """tests / A-B: which head_dim-72 attention kernels use the 16x16x32 MFMA shape (bit 0 dK/dV, 1 dQ, 2 forward;
     -1 = default); returns the previous mask"""
