@@ -288,7 +288,7 @@ def block_forward(P: Dict[str, Tensor], pre: str, cfg: DiTConfig, x: Tensor,
     x1 = x + y_sa * gate_sa[:, None, :]
     if cap is not None:
         cap.update({pre + "mod": mod, pre + "xn1": xn, pre + "q_rope": qr, pre + "k_rope": kr,
-                    pre + "v": v, pre + "attn": att, pre + "x_sa": x1})
+                    pre + "v": v, pre + "attn": att, pre + "y_sa": y_sa, pre + "x_sa": x1})
 
     # cross attention (model.py:142-160)
     x2 = x1
@@ -300,7 +300,7 @@ def block_forward(P: Dict[str, Tensor], pre: str, cfg: DiTConfig, x: Tensor,
         y_ca = linear(catt, g("cross_proj.weight"))
         x2 = x1 + y_ca * gate_ca[:, None, :]
         if cap is not None:
-            cap.update({pre + "cattn": catt, pre + "x_ca": x2})
+            cap.update({pre + "cattn": catt, pre + "y_ca": y_ca, pre + "x_ca": x2})
 
     # MLP (model.py:163-165)
     xn3 = modulate(rms_norm(x2, g("norm3.weight")), shift_mlp, scale_mlp)
@@ -308,7 +308,7 @@ def block_forward(P: Dict[str, Tensor], pre: str, cfg: DiTConfig, x: Tensor,
     y_mlp = linear(hmid, g("mlp.2.weight"), g("mlp.2.bias"))
     x3 = x2 + y_mlp * gate_mlp[:, None, :]
     if cap is not None:
-        cap.update({pre + "x_out": x3})
+        cap.update({pre + "y_mlp": y_mlp, pre + "x_out": x3})
     return x3, v
 
 

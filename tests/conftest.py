@@ -11,6 +11,17 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: opt-in long GPU checks (minutes of CPU oracle): run with -m \"gpu and slow\"")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`slow` tests are opt-in: they run only when the marker expression names them (-m "gpu and slow")"""
+    if "slow" in (config.getoption("markexpr") or ""):
+        return
+    skip = pytest.mark.skip(reason='opt-in: run with -m "gpu and slow"')
+    for it in items:
+        if "slow" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -3,7 +3,7 @@ import csv, collections, re, sys
 res = collections.defaultdict(dict)
 for f in sys.argv[1:]:
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(attn_\w+|(?:big::|mid::)?gemm_kernel<[\d, ]+>|\w+_kernel)", r["Kernel_Name"])
+        m = re.search(r"(attn8?_\w+|(?:big::|mid::)?gemm_kernel<[\d, ]+>|\w+_kernel)", r["Kernel_Name"])
         if not m:
             continue
         k = m.group(1)

@@ -20,7 +20,8 @@
 // contraction bytes in natural order.
 // Row constants ride in for free: dP accumulates onto C = -delta (scaled), the exponent is one v_fma_f32
 // (score * cs + (8 - lse2)) per element.  P is kept as P * 2^8 (e4m3 tops out at 448): forward <= 2^8.8 relative
-// to the lazily raised running maximum, backward = 256 * the true probability (covers 2^-17 .. 1).
+// to the lazily raised running maximum (and rounded to the e4m3 grid in the log domain: P_BYTE in the forward kernel),
+// backward = 256 * the true probability (covers 2^-17 .. 1).
 // LDS image: row-major 128-B rows, 16-B chunk c of row r stored at chunk c ^ swz8(r), swz8(r) = ((r >> 1) & 3) |
 // ((r >> 3) & 4): conflict-free for the row reads (16 lanes x 16 B over 256 B) and for the transposing reads
 // (2 x 8 rows x 16 B per 32-lane half); applied to the per-lane SOURCE address of the LDS-DMA.
@@ -38,8 +39,9 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr int ROWB = 128;            // bytes of an fp8 row (global memory and LDS)
 constexpr int TILE = 128 * ROWB;     // one streamed tile: 128 rows
 constexpr float P_SHIFT = 8.0f;      // P is held as P * 2^8
-constexpr float P_LIMIT = 8.75f;
-constexpr float SEED_HEADROOM = 4.0f; // forward: the first block's maximum + 4 seeds the running maximum     // forward: raise the running maximum when a score exceeds it by 2^0.75 (e4m3 max 448 = 2^8.8)
+constexpr float LOGDOM_BIAS = 56.0f - 0.344f;  // forward: e4m3 byte of 2^x = round(8 x + LOGDOM_BIAS) (attn8_fwd_kernel, P_BYTE)
+constexpr float BYTE_LIMIT = 126.4f;  // forward: raise the running maximum when a byte would exceed 0x7E (448; 0x7F is NaN)
+constexpr float SEED_HEADROOM = 4.0f; // forward: the first block's maximum + 4 seeds the running maximum
 
 struct Attn8P {
   int B, H, Lq, Lk, hd;
@@ -114,14 +116,18 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+// (the first convert replaces the low half of `w`, the second the high half: `w` needs no initial value -- the empty
+// asm "defines" it without an instruction, which saves the v_mov 0 a zero-initialised temporary costs per dword)
 __device__ __forceinline__ int cvt4_e4m3(const f32x4& x) {
-  int w = 0;
+  int w;
+  asm volatile("" : "=v"(w));
   w = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], w, false);
   w = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w, true);
   return w;
 }
 __device__ __forceinline__ int cvt4_e5m2(const f32x4& x) {
-  int w = 0;
+  int w;
+  asm volatile("" : "=v"(w));
   w = __builtin_amdgcn_cvt_pk_bf8_f32(x[0], x[1], w, false);
   w = __builtin_amdgcn_cvt_pk_bf8_f32(x[2], x[3], w, true);
   return w;
@@ -171,10 +177,10 @@ __device__ __forceinline__ void retire(float f) { asm volatile("" ::"v"(f)); }
 
 // ===================================== forward ==============================================
 // Workgroup = 256 queries (4 waves x 4 column blocks of 16); K / V tiles of 128 keys, double-buffered, one barrier
-// per tile.  Lazy online softmax per 16-key block: the exponent x = score * cs + (8 - m) is checked against
-// P_LIMIT; when some query of the wave exceeds it (wave-uniform, rare after the first tiles) its running maximum
-// m is raised, O (whose row `hd` is the softmax denominator, from V's ones column) is rescaled, and the tile is
-// restarted -- the blocks already packed with the old m have not entered O yet, so they are simply recomputed.
+// per tile.  Lazy online softmax per tile: the exponent x = score * cs + (8 - m) of every key of the tile is packed
+// as its e4m3 byte; when some byte of the wave would exceed 0x7E (wave-uniform, rare after the first tiles) the
+// running maxima m are raised to the tile's, O (whose row `hd` is the softmax denominator, from V's ones column) is
+// rescaled, and the tile's P is recomputed -- it has not entered O yet.
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
   static_assert(HD == 72, "ones column of V at byte 72: row 72 of O^T = block 4, lanes g = 2, register 0");
@@ -200,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) qf[cb] = load_row32(rq, qrow0 + 16 * cb, g);
   const float cs = p.scale * LOG2E * p.deq[0] * p.deq[1];
+  const float cs8 = 8.0f * cs;
   const float sv = p.deq[2];
   Frag8 fr;
   fr.init(lane);
@@ -213,14 +220,14 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
   const int nkt = (p.Lk + 127) / 128;
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) retire(qf[cb]);
-  retire(cs);
+  retire(cs8);
   retire(sv);
   VDS_WAIT_VM(0);
   __syncthreads();
 
   // seed the running maxima from the first 16-key block plus SEED_HEADROOM: the largest P of the first tiles is then
   // ~2^(8 - headroom), 13+ binades above e4m3's smallest value, and the maximum is raised (and a tile recomputed)
-  // only when a later score exceeds the seed by more than headroom + 0.75 in the log2 domain
+  // only when a later score exceeds the seed by more than headroom + 0.84 in the log2 domain
   {
     const i32x8 kf = fr.row<0>(smem);
 #pragma unroll
@@ -234,7 +241,16 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
     }
   }
 
-  // scores -> packed P of one tile with the current maxima; mt: largest exponent per query block.  Software-pipelined by
+  // P_BYTE: the forward pass is bound by the VALU work between its MFMAs (exp2 alone is a quarter-rate instruction), so
+  // P = 2^x is rounded to e4m3 in the LOG domain: an e4m3 byte b >= 8 is the value 2^((b >> 3) - 7) (1 + (b & 7) / 8),
+  // i.e. b is a piecewise-linear function of log2(value) that deviates from 8 x + 56 by g = 8 (2^f - 1 - f) in
+  // [-0.688, 0] (f = frac x).  byte = round(8 x + 56 - 0.344) -- one v_fma_f32 (shared with the score scaling) and one
+  // v_cvt_pk_u8_f32 (round to nearest even, saturating at 0, written straight into its byte) per element instead of
+  // fma + v_exp_f32 + convert -- is the value 2^x within a factor 2^(+-0.043) (+- 3 %) before the rounding to the byte
+  // grid that every e4m3 cast has (+- 0.5 step): 0.35 instead of 0.29 steps rms.  The softmax denominator is the sum of
+  // the SAME bytes (V's ones column), so the weights of a row still sum to one exactly.  Below 2^-6 (bytes < 8, e4m3
+  // subnormals: 14.8 binades under the row maximum) the byte grid is linear and the value is under-estimated.
+  // scores -> packed P of one tile with the current maxima; mt: largest byte value per query block.  Software-pipelined by
   // hand: the S products of block i+1 are issued before the softmax VALU work of block i, and the sched_barrier keeps
   // hipcc from hoisting all 32 independent MFMAs (128 live accumulator registers).  RAGGED (last tile only): keys past
   // Lk -- zero rows -- are kept out of the maximum and of P.
@@ -242,12 +258,14 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
     constexpr bool ragged = decltype(RAG)::value;
     float nm[4];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) { nm[cb] = P_SHIFT - m[cb]; mt[cb] = -INFINITY; }
+    for (int cb = 0; cb < 4; ++cb) { nm[cb] = 8.0f * (P_SHIFT - m[cb]) + LOGDOM_BIAS; mt[cb] = -INFINITY; }
     f32x4 xn[4];
+    i32x8 kfn;  // K fragment of the block whose products are issued in the next iteration (read one iteration ahead)
     {
       const i32x8 kf = fr.row<0>(kt);
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) xn[cb] = mfma8<0, 0>(kf, qf[cb], zero4());
+      kfn = fr.row<1>(kt);
     }
     static_for<8>([&](auto I) {
       constexpr int i = decltype(I)::value;
@@ -255,26 +273,29 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) x[cb] = xn[cb];
       if constexpr (i < 7) {
-        const i32x8 kf = fr.row<i + 1>(kt);
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) xn[cb] = mfma8<0, 0>(kf, qf[cb], zero4());
+        for (int cb = 0; cb < 4; ++cb) xn[cb] = mfma8<0, 0>(kfn, qf[cb], zero4());
       }
+      if constexpr (i < 6) kfn = fr.row<i + 2>(kt);
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
+        // t = 8 * exponent + 56 - 0.344: the e4m3 byte of 2^exponent, rounded in the LOG domain (see P_BYTE below)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[cb][r] = __builtin_fmaf(x[cb][r], cs, nm[cb]);
+        for (int r = 0; r < 4; ++r) x[cb][r] = __builtin_fmaf(x[cb][r], cs8, nm[cb]);
         if constexpr (ragged) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (4 * i + r >= key_lim) x[cb][r] = -INFINITY;
         }
-        mt[cb] = fmaxf(fmaxf(mt[cb], fmaxf(x[cb][0], x[cb][1])), fmaxf(x[cb][2], x[cb][3]));
+        mt[cb] = fmaxf(fmaxf(mt[cb], x[cb][0]), x[cb][1]);  // v_max3_f32
+        mt[cb] = fmaxf(fmaxf(mt[cb], x[cb][2]), x[cb][3]);
+        unsigned w;
+        asm volatile("" : "=v"(w));  // (every byte is written below: no initial value, no v_mov)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[cb][r] = __builtin_amdgcn_exp2f(x[cb][r]);
-        int w = cvt4_e4m3(x[cb]);
-        asm volatile("" : "+v"(w));  // pins exp2 + pack here: LLVM otherwise sinks them below the (rare) raise-the-maximum
+        for (int r = 0; r < 4; ++r) w = __builtin_amdgcn_cvt_pk_u8_f32(x[cb][r], r, w);
+        asm volatile("" : "+v"(w));  // pins the pack here: LLVM otherwise sinks it below the (rare) raise-the-maximum
                                      // branch, which keeps all 128 exponents of the tile live
-        pq[cb][i] = w;
+        pq[cb][i] = (int)w;
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -294,11 +315,12 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
     float mt[4];
     s_phase(kt, pq, mt, key_lim, RAG);
     const float mxa = fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]));
-    if (__builtin_amdgcn_ballot_w64(mxa > P_LIMIT) != 0) {  // wave-uniform, rare after the first tiles
+    if (__builtin_amdgcn_ballot_w64(mxa > BYTE_LIMIT) != 0) {  // wave-uniform, rare after the first tiles
       asm volatile("; raise the running maxima to this tile's, rescale O, recompute the tile's P" ::: "memory");
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
-        const float t = max_over_lane_groups(mt[cb]) - (P_SHIFT - m[cb]);  // largest score of the tile, log2 domain
+        // largest score of the tile, log2 domain: byte value -> exponent -> score
+        const float t = (max_over_lane_groups(mt[cb]) - LOGDOM_BIAS) * 0.125f - (P_SHIFT - m[cb]);
         if (t > m[cb]) {  // (the same decision in the 4 lanes of a query)
           const float alpha = __builtin_amdgcn_exp2f(m[cb] - t);
           m[cb] = t;
@@ -306,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
           for (int db = 0; db < NDB; ++db) o[db][cb] *= alpha;
         }
       }
-      s_phase(kt, pq, mt, key_lim, RAG);  // every exponent of the tile is now <= 8
+      s_phase(kt, pq, mt, key_lim, RAG);  // every exponent of the tile is now <= 8 (byte <= 120)
     }
     static_for<NDB>([&](auto DB) {
       constexpr int db = decltype(DB)::value;
@@ -422,26 +444,54 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
     const char* dot = qt + TILE;
     const float* stl = reinterpret_cast<const float*>(stats + par * 1024);
     i32x8 pq[2], dsq[2];
-    static_for<8>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      const i32x8 aq = fr.row<i>(qt);
-      const i32x8 ad = fr.row<i>(dot);
-      // accumulator register r <-> query 32 g + 4 i + r of the tile
-      const f32x4 nl4 = *reinterpret_cast<const f32x4*>(stl + 32 * g + 4 * i);
-      const f32x4 nd4 = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g + 4 * i);
+    // software pipeline by hand (as in the forward kernel): the S / dP products of block i+1 are issued before the
+    // exp2 / multiply / pack VALU work of block i; accumulator register r <-> query 32 g + 4 i + r of the tile
+    f32x4 sn[2], dpn[2];
+    i32x8 aqn, adn;   // fragments of the block whose products are issued in the NEXT iteration: read one iteration ahead
+    f32x4 ndn;        // of their use, so that no MFMA waits on an LDS round trip
+    {
+      const i32x8 aq = fr.row<0>(qt);
+      const i32x8 ad = fr.row<0>(dot);
+      const f32x4 nd4 = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        const f32x4 s = mfma8<0, 0>(aq, kf[cb], zero4());
-        const f32x4 dp = mfma8<1, 0>(ad, vf[cb], nd4);  // dO (e5m2) V^T - delta, in units of s_do s_v
+        sn[cb] = mfma8<0, 0>(aq, kf[cb], zero4());
+        dpn[cb] = mfma8<1, 0>(ad, vf[cb], nd4);  // dO (e5m2) V^T - delta, in units of s_do s_v
+      }
+      aqn = fr.row<1>(qt);
+      adn = fr.row<1>(dot);
+      ndn = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g + 4);
+    }
+    static_for<8>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      f32x4 s[2], dp[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) { s[cb] = sn[cb]; dp[cb] = dpn[cb]; }
+      const f32x4 nl4 = *reinterpret_cast<const f32x4*>(stl + 32 * g + 4 * i);
+      if constexpr (i < 7) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          sn[cb] = mfma8<0, 0>(aqn, kf[cb], zero4());
+          dpn[cb] = mfma8<1, 0>(adn, vf[cb], ndn);
+        }
+      }
+      if constexpr (i < 6) {
+        aqn = fr.row<i + 2>(qt);
+        adn = fr.row<i + 2>(dot);
+        ndn = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g + 4 * (i + 2));
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
         f32x4 pr, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cs, nl4[r]));  // 256 P
-          ds[r] = pr[r] * dp[r];
+          pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[cb][r], cs, nl4[r]));  // 256 P
+          ds[r] = pr[r] * dp[cb][r];
         }
         pq[cb][i] = cvt4_e4m3(pr);
         dsq[cb][i] = cvt4_e5m2(ds);
       }
+      __builtin_amdgcn_sched_barrier(0);
     });
     static_for<NDB>([&](auto DB) {
       constexpr int db = decltype(DB)::value;
@@ -547,19 +597,43 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
     const char* kt = smem + par * 2 * TILE;
     const char* vt = kt + TILE;
     i32x8 dsq[2];
-    static_for<8>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      const i32x8 ak = fr.row<i>(kt);
-      const i32x8 av = fr.row<i>(vt);
+    f32x4 sn[2], dpn[2];  // software pipeline by hand, as in the other two kernels
+    i32x8 akn, avn;       // fragments read one iteration ahead of the products that consume them
+    {
+      const i32x8 ak = fr.row<0>(kt);
+      const i32x8 av = fr.row<0>(vt);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        const f32x4 s = mfma8<0, 0>(ak, qf[cb], zero4());
-        const f32x4 dp = mfma8<0, 1>(av, dof[cb], nd4[cb]);
+        sn[cb] = mfma8<0, 0>(ak, qf[cb], zero4());
+        dpn[cb] = mfma8<0, 1>(av, dof[cb], nd4[cb]);
+      }
+      akn = fr.row<1>(kt);
+      avn = fr.row<1>(vt);
+    }
+    static_for<8>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      f32x4 s[2], dp[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) { s[cb] = sn[cb]; dp[cb] = dpn[cb]; }
+      if constexpr (i < 7) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          sn[cb] = mfma8<0, 0>(akn, qf[cb], zero4());
+          dpn[cb] = mfma8<0, 1>(avn, dof[cb], nd4[cb]);
+        }
+      }
+      if constexpr (i < 6) {
+        akn = fr.row<i + 2>(kt);
+        avn = fr.row<i + 2>(vt);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
         f32x4 ds;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cs, nl[cb])) * dp[r];
+        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[cb][r], cs, nl[cb])) * dp[cb][r];
         dsq[cb][i] = cvt4_e5m2(ds);
       }
+      __builtin_amdgcn_sched_barrier(0);
     });
     static_for<NDB>([&](auto DB) {
       constexpr int db = decltype(DB)::value;
