@@ -389,7 +389,9 @@ int vds_cast_bf16_f32(const void* src, float* dst, int64_t n, vds_stream_t strea
  * OCP e4m3, dO / dS in e5m2, fp32 accumulation and softmax statistics (csrc/attention_fp8.hip; recipe: fp8.py).  The
  * reference trains in bf16 only.  q, k, v, d_o: fp8 rows [B,H,L,128] (contiguous; bytes [0, head_dim) data, byte
  * head_dim of every V row = 1.0 (0x38), all other pad bytes 0) as written by vds_qkv_rope_fwd_fp8 / vds_attn_fp8_delta;
- * deq: device float[4] = dequantisation factors {s_q, s_k, s_v, s_do} (x = x_q * s), written by the same two producers.
+ * deq: device float[8] = {s_q, s_k, s_v, s_do, E, -, -, -}: dequantisation factors (x = x_q * s) and the exponent E with
+ * s_q s_k log2(e) / sqrt(head_dim) = 2^-E exactly (the kernels' block-scaled MFMAs rely on it), written by the same two
+ * producers.
  * o: bf16, any strides (last dim contiguous); lse f32 [B,H,Lq]; dq, dk, dv: bf16 strided like attention's.
  * stats: the f32 [2,B,H,Lq] workspace vds_attn_fp8_delta filled (vds_attn_fp8_bwd_workspace_bytes).  head_dim 72. */
 typedef struct vds_attn_fp8_args {
@@ -418,7 +420,7 @@ int vds_attn_fp8_bwd(const vds_attn_fp8_args* a, vds_stream_t stream);
 /* vds_qkv_rope_fwd with fp8 outputs (the values quantised are that kernel's bf16 results): q8 / k8 / v8 e4m3 rows
  * [B,H,L,128]; v_out (may be NULL): additionally the bf16 v in the padded head-major layout [B,H,L,hdp]; amax_prev /
  * amax_cur: the q, k, v amax entries at element stride amax_stride (delayed scaling: scale = 448 / previous amax);
- * writes deq[0..2]. */
+ * writes deq[0..2] and deq[4] (q's factor is tied to k's: see deq above). */
 int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const float* sinb, const void* v0, const void* lam,
                          void* q8, void* k8, void* v8, void* v_out, const float* amax_prev, float* amax_cur,
                          int32_t amax_stride, float* deq, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t hdp,

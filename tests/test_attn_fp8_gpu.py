@@ -33,9 +33,10 @@ def cos(a, b):
     return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
 
 
-def quant_rows(x, fmt, amax_target):
-    """[B,H,L,hd] f32 -> (rows uint8 [B,H,L,128] with zero pad, dequantisation factor)"""
-    alpha = amax_target / x.abs().max().item()
+def quant_rows(x, fmt, amax_target=None, alpha=None):
+    """[B,H,L,hd] f32 -> (rows uint8 [B,H,L,128] with zero pad, dequantisation factor, dequantised values)"""
+    if alpha is None:
+        alpha = amax_target / x.abs().max().item()
     q = (x * alpha).to(fmt)
     rows = torch.zeros(*x.shape[:-1], ROW, dtype=torch.uint8, device=x.device)
     rows[..., :x.shape[-1]] = q.view(torch.uint8)
@@ -51,11 +52,15 @@ def make_qkv(B, H, L, seed, dev, spike=None, k_scale=1.0):
         k[:, :, spike] = 0.0
         k[:, :, spike, :8] = 3.0
         q[:, :, 3, :8] = 4.0
-    q8, sq, qd = quant_rows(q, E4, 448.0)
-    k8, sk, kd = quant_rows(k, E4, 448.0)
+    from video_diffusion_speedrun_amd import ops as _ops
+    # the producer's rule: k onto 448, q's factor tied to it so that s_q s_k log2(e) / sqrt(hd) = 2^-E
+    aq, ak, E = _ops.attn_fp8_qk_factors(q.abs().max().item(), k.abs().max().item(), HD)
+    q8, sq, qd = quant_rows(q, E4, alpha=aq)
+    k8, sk, kd = quant_rows(k, E4, alpha=ak)
     v8, sv, vd = quant_rows(v, E4, 448.0)
+    assert 224.0 < q.abs().max().item() * aq <= 448.0
     v8[..., HD] = 0x38  # ones column (1.0 in e4m3)
-    deq = torch.tensor([sq, sk, sv, 0.0], dtype=f32, device=dev)
+    deq = torch.tensor([sq, sk, sv, 0.0, E, 0.0, 0.0, 0.0], dtype=f32, device=dev)
     return (q8.view(E4), k8.view(E4), v8.view(E4)), deq, (qd, kd, vd)
 
 
@@ -117,7 +122,7 @@ def test_attn_fp8_backward_vs_fp32_on_dequantised_operands(ops, parity_log, L):
     assert int(doq.view(torch.uint8)[..., HD:].max()) == 0
     assert amax_cur.item() == amax_prev.item()
     delta_ref = (do_h.double() * o.float().view(B, L, H, HD).permute(0, 2, 1, 3).double()).sum(-1)
-    assert rel(stats[0] * (-(s_do * deq[2].item())), delta_ref) <= 1e-5
+    assert rel(stats[0] * (-(s_do * deq[2].item() * 256.0)), delta_ref) <= 1e-5
     assert (stats[1].double() - (8.0 - lse.double() * math.log2(math.e))).abs().max().item() <= 1e-4
     # gradients of fp32 attention on the dequantised operands (dO as quantised)
     qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (qd, kd, vd))
@@ -155,13 +160,15 @@ def test_qkv_rope_fp8_is_the_bf16_kernel_quantised(ops, mix):
     hist = torch.zeros(3, 2, dtype=f32, device=dev)  # [prev, cur] pairs like fp8.AmaxHistory
     for i, t in enumerate((q, k, v)):
         hist[i, 0] = t[..., :HD].float().abs().max()
-    deq = torch.zeros(4, dtype=f32, device=dev)
+    deq = torch.zeros(8, dtype=f32, device=dev)
     q8, k8, v8, vb = ops.qkv_rope_fwd_fp8(qkv, cs, sn, v0, lam, B, L, H, HD, HDP, hist[:, 0], hist[:, 1], 2, deq,
                                           want_v=True)
     torch.cuda.synchronize()
+    aq, ak, E = ops.attn_fp8_qk_factors(hist[0, 0].item(), hist[1, 0].item(), HD)
+    assert deq[4].item() == E
     for i, (t8, t) in enumerate(((q8, q), (k8, k), (v8, v))):
-        alpha = 448.0 / hist[i, 0].item()
-        assert abs(deq[i].item() * alpha - 1.0) <= 1e-6
+        alpha = (aq, ak, 448.0 / hist[2, 0].item())[i]
+        assert abs(deq[i].item() * alpha - 1.0) <= 1e-5
         want = (t[..., :HD].float() * alpha).to(E4).view(torch.uint8)
         got = t8.view(torch.uint8)
         # (the rotation is evaluated in fp32 in both kernels; hipcc may contract a*b+c*d differently: a value that sits

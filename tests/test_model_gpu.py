@@ -73,16 +73,35 @@ def load_g1(golden_dir, name):
     return fx, cfg, P
 
 
-def check_lambda_vector(named, ref_grads):
-    """lambda_param gradients are scalars made of ~1e5..1e6 cancelling bf16 products: judge them
-    as one vector over the blocks (direction + size), not one by one."""
-    ks = [k for k in ref_grads if k.endswith("lambda_param")]
-    if not ks:
-        return
-    got = torch.stack([named[k].grad.float().cpu().reshape(()) for k in ks])
-    ref = torch.stack([(ref_grads[k]["sample"] if isinstance(ref_grads[k], dict) else ref_grads[k]).float().reshape(())
-                       for k in ks])
-    assert cosine(got, ref) >= 0.98 and rel(got, ref) <= 0.2, (got.tolist(), ref.tolist())
+LAMBDA_ERR = 2e-4  # |got - reference| / sum of |terms|; measured <= 6.3e-5 on the workload tests (test_workloads_gpu.py)
+
+
+def lambda_term_sums(cfg, P, x, ctx, t, start, upstream):
+    """sum_j |dv_j (v_raw_j - v_0_j)| per mixed block, from the fp32 oracle on the fixture's inputs: d loss / d lambda_i
+    is a scalar made of B*L*D signed bf16 products that largely cancel, so its error is judged against the sum of
+    the |products| (v_raw - v_0 = (v_mixed - v_0) / lambda, model.py:129-130).  `upstream(out)` -> scalar to backward."""
+    Pg = {k: w.clone().requires_grad_(True) for k, w in P.items()}
+    cap = {}
+    out = O.dit_forward(Pg, cfg, x.float(), ctx.float(), t.float(), start, cap)
+    mixed = {i: cap[f"blocks.{i}.v"] for i in range(1, cfg.depth)}
+    for vm in mixed.values():
+        vm.retain_grad()
+    upstream(out).backward()
+    v0 = cap["blocks.0.v"].detach()
+    return {f"blocks.{i}.lambda_param": (vm.grad * (vm.detach() - v0) / P[f"blocks.{i}.lambda_param"].item()).abs().sum().item()
+            for i, vm in mixed.items()}
+
+
+def check_lambda(named, ref_grads, l1):
+    """every lambda_param gradient against the REFERENCE's value (fixture), error normalised by the block's term sum"""
+    rows = []
+    for k in ref_grads:
+        if not k.endswith("lambda_param") or k not in l1:
+            continue
+        ref = ref_grads[k]["sample"] if isinstance(ref_grads[k], dict) else ref_grads[k]
+        got, want = named[k].grad.float().cpu().reshape(()).item(), ref.float().reshape(()).item()
+        rows.append((k, got, want, abs(got - want) / l1[k]))
+    assert rows and all(r[3] <= LAMBDA_ERR for r in rows), rows
 
 
 def check_grad(name, got, ref, report):
@@ -118,7 +137,9 @@ def test_g1_golden_forward_backward(vds, golden_dir, name):
         if not check_grad(k, p.grad, g, report):
             bad.append(report[-1])
     assert not bad, f"gradient mismatches (name, cosine, rel): {bad}"
-    check_lambda_vector(named, fx["fp32"]["grads"])
+    l1 = lambda_term_sums(cfg, P, fx["x"].to(bf16), fx["context"].to(bf16), fx["t"].to(bf16), tuple(fx["rope_start"]),
+                          lambda o: (o * fx["dout"]).sum())
+    check_lambda(named, fx["fp32"]["grads"], l1)
 
 
 def test_g2_dit_s_config1(vds, golden_dir):
@@ -145,7 +166,9 @@ def test_g2_dit_s_config1(vds, golden_dir):
         if not check_grad(k, named[k].grad, d, report):
             bad.append(report[-1])
     assert not bad, f"gradient mismatches (name, cosine, rel): {bad}"
-    check_lambda_vector(named, fx["grad_digest"])
+    l1 = lambda_term_sums(cfg, P, x.to(bf16), ctx.to(bf16), t.to(bf16), tuple(fx["rope_start"]),
+                          lambda o: O.flow_loss(v.to(bf16), o)[0])
+    check_lambda(named, fx["grad_digest"], l1)
 
 
 def test_g3_harness(vds, golden_dir):
@@ -208,7 +231,8 @@ def test_oracle_parity_random(vds, hd, H, train_bias):
         if not (c >= GRAD_COS and e <= GRAD_REL):
             bad.append((k, c, e))
     assert not bad, bad
-    check_lambda_vector(dict(m.named_parameters()), {k: v.grad for k, v in Pg.items() if v.grad is not None})
+    l1 = lambda_term_sums(cfg, P, x, ctx, t, start, lambda o: O.flow_loss(v, o)[0])
+    check_lambda(dict(m.named_parameters()), {k: w.grad for k, w in Pg.items() if w.grad is not None}, l1)
 
 
 def test_muadamw_matches_reference(vds, golden_dir):
@@ -530,6 +554,43 @@ def test_graph_replay_rejects_other_shapes(vds):
         gs.step({"latent": torch.randn(2, 16, 4, 8, 16).cuda(), "context": torch.randn(2, 16, 64).cuda()})
 
 
+@pytest.mark.parametrize("D,H", [(128, 4), (512, 16), (192, 2)], ids=["hd32", "hd32_reference_smoke_width", "hd96"])
+def test_head_dim_32_and_96_vs_oracle(vds, D, H):
+    """head_dim 32 (the reference's own smoke test builds width 512 with its default 16 heads, model.py:545-565) and
+    head_dim 96 (no padding at all): forward, loss and every gradient against the fp32 oracle"""
+    cfg = O.DiTConfig(in_channels=16, hidden_size=D, depth=2, num_heads=H, cross_attn_input_size=64,
+                      residual_v=True, train_bias_and_rms=True)
+    P = O.init_params(cfg, seed=41, randomize_zero_init=True, init_std_factor=1.0)
+    g = torch.Generator().manual_seed(42)
+    lat = (2, 16, 4, 16, 16)
+    x = torch.randn(*lat, generator=g).to(bf16)
+    ctx = torch.randn(lat[0], 24, 64, generator=g).to(bf16)
+    t = torch.tensor([0.25, 0.7]).to(bf16)
+    v = torch.randn(*lat, generator=g).to(bf16)
+    start = (3, 1, 2)
+    Pg = {k: w.clone().requires_grad_(True) for k, w in P.items()}
+    o_ref = O.dit_forward(Pg, cfg, x.float(), ctx.float(), t.float(), start)
+    l_ref, _ = O.flow_loss(v, o_ref)
+    l_ref.backward()
+    m = build(vds, cfg, P)
+    out = m(x.cuda(), ctx.cuda(), t.cuda(), rope_start=start)
+    loss, _ = vds["train"].flow_loss(out, v.cuda())
+    loss.backward()
+    assert rel(out, o_ref) <= 2.5e-2, rel(out, o_ref)
+    assert abs(loss.item() - l_ref.item()) / l_ref.item() <= 1e-2
+    bad = []
+    for k, p in m.named_parameters():
+        if Pg[k].grad is None or k.endswith("lambda_param") or float(Pg[k].grad.abs().max()) == 0:
+            continue
+        c, e = cosine(p.grad, Pg[k].grad), rel(p.grad, Pg[k].grad)
+        _track(f"hd{D // H}:" + k, c, e)
+        if not (c >= GRAD_COS and e <= GRAD_REL):
+            bad.append((k, c, e))
+    assert not bad, bad
+    with pytest.raises(ValueError, match="no attention kernel instance"):
+        vds["model"].DiT(in_channels=16, hidden_size=160, depth=1, num_heads=4)  # head_dim 40: stated, not silent
+
+
 @pytest.mark.parametrize("D,H,lat", [(144, 2, (2, 16, 4, 8, 8)), (256, 4, (2, 16, 4, 16, 16))])
 def test_fp8_step_close_to_oracle(vds, D, H, lat):
     """BASELINE config 5 (no reference counterpart): DiT.enable_fp8() runs the qkv / MLP GEMMs of every block in
@@ -558,7 +619,7 @@ def test_fp8_step_close_to_oracle(vds, D, H, lat):
     loss.backward()
     stats = ops.prof_collect()
     ops.prof_enable(0)
-    assert stats["gemm_fp8"]["launches"] == 9 * cfg.depth  # 3 linears x (fwd, dgrad, wgrad) per block ran in fp8
+    assert stats["gemm_fp8"]["launches"] == 21 * cfg.depth  # all 7 linears x (fwd, dgrad, wgrad) per block ran in fp8
     assert rel(out, o_ref) <= 2.5e-2, rel(out, o_ref)
     assert abs(loss.item() - l_ref.item()) / l_ref.item() <= 1e-2
     bad = []

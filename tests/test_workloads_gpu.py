@@ -101,7 +101,9 @@ def sublayer_errors(m, out, subs, B, L):
     return {n: rel(got[n], subs[n]) for n in got if n in subs}
 
 
-def check_step(vds, m, x, ctx, t, v, start, ref, cos_min, rel_max, out_tol=2.5e-2, sub_tol=SUB_REL):
+def check_step(vds, m, x, ctx, t, v, start, ref, cos_min, rel_max, out_tol=2.5e-2, sub_tol=SUB_REL, lam_tol=None,
+               log=None):
+    """log = (parity_log, name): the measured figures are recorded BEFORE the assertions (a failing run keeps them)"""
     o_ref, l_ref, g_ref, subs = ref
     out = m(x.cuda(), ctx.cuda(), t.cuda(), rope_start=start)
     e_out = rel(out, o_ref)
@@ -128,12 +130,14 @@ def check_step(vds, m, x, ctx, t, v, start, ref, cos_min, rel_max, out_tol=2.5e-
             per_block[b] = max(per_block.get(b, 0.0), e)
     figures = dict(out_rel=e_out, loss_rel=e_loss, worst_cos=worst_cos, worst_rel=worst_rel, lambda_param=lam,
                    sublayers=sub_err, worst_rel_per_block=[round(per_block[b], 5) for b in sorted(per_block)])
+    if log is not None:
+        log[0](log[1], **figures)
     assert e_out <= out_tol, figures
     assert sub_err and all(e <= sub_tol for e in sub_err.values()), sub_err
     assert e_loss <= 1e-2, figures
     bad = [r for r in rows if not (r[1] >= cos_min and r[2] <= rel_max)]
     assert not bad, bad
-    assert all(r[3] <= LAMBDA_ERR for r in lam), lam
+    assert all(r[3] <= (lam_tol or LAMBDA_ERR) for r in lam), [r for r in lam if r[3] > (lam_tol or LAMBDA_ERR)]
     return figures
 
 
@@ -214,7 +218,7 @@ def test_headline_shape_block_vs_oracle(vds, headline, parity_log, fp8):
     if fp8:
         stats = vds["ops"].prof_collect()
         vds["ops"].prof_enable(0)
-        assert stats["gemm_fp8"]["launches"] == 9  # qkv, fc1, fc2 x (fwd, dgrad, wgrad) really ran in fp8
+        assert stats["gemm_fp8"]["launches"] == 21  # the 7 linears of the block x (fwd, dgrad, wgrad) really ran in fp8
         # ... and so did the three self-attention kernels; no bf16 self-attention launch is left
         assert [stats[k]["launches"] for k in ("attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq")] == [1, 1, 1]
         assert "attn_fwd" not in stats and "attn_bwd_dkv" not in stats and "attn_bwd_dq" not in stats
@@ -241,6 +245,7 @@ def test_dit_xl_depth6_vs_oracle(vds, parity_log):
 # Error grows with depth (the residual-V and conditioning gradients fan in over all blocks, model.py:379-384): the
 # full DiT-XL depth is checked at a short sequence in the default suite and at the headline sequence on request.
 GRAD_COS_28, GRAD_REL_28 = 0.999, 4e-2  # measured: parity_report.jsonl "dit_xl_depth28_*" (bounds ~2x the worst block)
+LAMBDA_ERR_28 = 4e-4  # lambda_param gradients at depth 28 (see LAMBDA_ERR; the upstream dv carries 28 blocks of bf16 error)
 
 
 def _depth28(vds, parity_log, lat, Lc, name, seed):
@@ -250,8 +255,8 @@ def _depth28(vds, parity_log, lat, Lc, name, seed):
     x, ctx, t, v = make_inputs(lat, Lc, 4096, seed + 1, 0.4)
     start = (7, 40, 19)
     ref = oracle_step(cfg, P, x, ctx, t, v, start)
-    fig = check_step(vds, build(vds, cfg, P), x, ctx, t, v, start, ref, GRAD_COS_28, GRAD_REL_28)
-    parity_log(name, **fig)
+    fig = check_step(vds, build(vds, cfg, P), x, ctx, t, v, start, ref, GRAD_COS_28, GRAD_REL_28,
+                     lam_tol=LAMBDA_ERR_28, log=(parity_log, name))
     assert len(fig["lambda_param"]) == 27 and len(fig["worst_rel_per_block"]) == 28
     return fig
 

@@ -71,12 +71,13 @@ for hd, H, hdp in SHAPES:
             r = torch.zeros(B, H, Lq, 128, dtype=torch.uint8, device=dev)
             r[..., :hd] = (x[..., :hd].float() * a).to(fmt).view(torch.uint8)
             return r, 1.0 / a
-        q8, sq = rows(q, E4, 448.0)
+        aq, ak, E = ops.attn_fp8_qk_factors(q[..., :hd].float().abs().max().item(), k[..., :hd].float().abs().max().item(), hd)
+        q8, sq = rows(q, E4, aq * q[..., :hd].float().abs().max().item())
         k8, sk = rows(k, E4, 448.0)
         v8, sv = rows(v, E4, 448.0)
         v8[..., hd] = 0x38
         q8, k8, v8 = q8.view(E4), k8.view(E4), v8.view(E4)
-        deq = torch.tensor([sq, sk, sv, 0.0], dtype=f32, device=dev)
+        deq = torch.tensor([sq, sk, sv, 0.0, E, 0.0, 0.0, 0.0], dtype=f32, device=dev)
         t = timeit(lambda: ops.attn_fp8_fwd(q8, k8, v8, deq, ov, lse, hd))
         print(f"{tag} fp8 fwd hd{hd}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TF/s")
         doq = torch.zeros(B, H, Lq, 128, dtype=E5, device=dev)

@@ -10,20 +10,22 @@ B, H, hd, Lq = int(os.environ.get("B", 6)), 16, 72, 8208
 g = torch.Generator(device=dev).manual_seed(0)
 
 
-def rows(fmt, target):
-    x = torch.randn(B, H, Lq, hd, device=dev, generator=g)
+def rows(fmt, target, x=None):
+    x = torch.randn(B, H, Lq, hd, device=dev, generator=g) if x is None else x
     a = target / x.abs().max().item()
     r = torch.zeros(B, H, Lq, 128, dtype=torch.uint8, device=dev)
     r[..., :hd] = (x * a).to(fmt).view(torch.uint8)
     return r, 1.0 / a
 
 
-q8, sq = rows(E4, 448.0)
-k8, sk = rows(E4, 448.0)
+xq, xk = (torch.randn(B, H, Lq, hd, device=dev, generator=g) for _ in range(2))
+aq, ak, E = ops.attn_fp8_qk_factors(xq.abs().max().item(), xk.abs().max().item(), hd)
+q8, sq = rows(E4, aq * xq.abs().max().item(), xq)
+k8, sk = rows(E4, 448.0, xk)
 v8, sv = rows(E4, 448.0)
 v8[..., hd] = 0x38
 q8, k8, v8 = q8.view(E4), k8.view(E4), v8.view(E4)
-deq = torch.tensor([sq, sk, sv, 0.0], dtype=f32, device=dev)
+deq = torch.tensor([sq, sk, sv, 0.0, E, 0.0, 0.0, 0.0], dtype=f32, device=dev)
 o = torch.empty(B * Lq, H * hd, dtype=bf16, device=dev)
 lse = torch.empty(B, H, Lq, dtype=f32, device=dev)
 ov = ops.heads_view(o, B, Lq, H, hd)

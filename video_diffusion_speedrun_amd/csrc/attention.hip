@@ -1,5 +1,5 @@
 // Flash-style full (non-causal) attention for gfx950, forward and backward, bf16 in /
-// fp32 softmax, head_dim 64 / 72 / 128 (72 = DiT-XL, padded to 80 for the QK contraction and
+// fp32 softmax, head_dim 32 / 64 / 72 / 96 / 128 (72 = DiT-XL, padded to 80 for the QK contraction and
 // to 96 for the 32-wide output blocks).  Replaces F.scaled_dot_product_attention at
 // model.py:136 (self, L x L) and model.py:157 (cross, L x 512) and its autograd backward.
 //
@@ -1464,8 +1464,8 @@ int run_fwd(AttnP p, hipStream_t s) {
   if (!once) {
     set_lds(attn_fwd_kernel<HDP, HDQ, 2, true>, LDS);
     if constexpr (HDP <= 96) set_lds(attn_fwd_wide_kernel<HDP, HDQ, false>, LDS);
-    if constexpr (HDP == 96) set_lds(attn_fwd_wide_kernel<HDP, HDQ, true>, LDS);
-    if constexpr (HDP == 96) set_lds(attn_fwd16_kernel<HDP>, LDS);
+    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_fwd_wide_kernel<HDP, HDQ, true>, LDS);
+    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_fwd16_kernel<HDP>, LDS);
     once = true;
   }
   static int wide = -1;  // VDS_ATTN_FWD_WIDE=0/1 forces (experiments); default: head_dim 64 / 72, long query sequences
@@ -1479,7 +1479,7 @@ int run_fwd(AttnP p, hipStream_t s) {
   p.n_rt = cdiv(p.Lq, use_wide ? 256 : 128);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
-  const bool ones_fwd = HDP == 96 && use_wide && p.kv_pad_ones && p.hd == 72;
+  const bool ones_fwd = HDP == 96 && HDQ == 80 && use_wide && p.kv_pad_ones && p.hd == 72;
   vdsprof::Scope ps(ones_fwd ? VDS_PROF_ATTN_FWD : VDS_PROF_ATTN_FWD_PLAIN, s, fl,
                     2.0 * p.B * p.H * p.hd * (2.0 * p.Lq + 2.0 * p.Lk));
   if constexpr (HDP == 64) {
@@ -1490,12 +1490,15 @@ int run_fwd(AttnP p, hipStream_t s) {
   }
   if constexpr (HDP == 96) {
     if (use_wide) {
-      if (p.kv_pad_ones && p.hd == 72 && (attn_variant() & 4))
-        hipLaunchKernelGGL((attn_fwd16_kernel<HDP>), dim3(grid), dim3(256), LDS, s, p);
-      else if (p.kv_pad_ones && p.hd == 72)
-        hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS, s, p);
-      else
-        hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS, s, p);
+      bool done = false;
+      if constexpr (HDQ == 80) {
+        if (p.kv_pad_ones && p.hd == 72) {
+          if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd16_kernel<HDP>), dim3(grid), dim3(256), LDS, s, p);
+          else hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS, s, p);
+          done = true;
+        }
+      }
+      if (!done) hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS, s, p);
       return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
     }
   }
@@ -1510,11 +1513,11 @@ int run_bwd(AttnP p, hipStream_t s) {
   static bool once = false;
   if (!once) {
     set_lds(attn_bwd_dq_kernel<HDP, HDQ, false>, LDS_DQ);
-    if constexpr (HDP == 96) set_lds(attn_bwd_dq_kernel<HDP, HDQ, true>, LDS_DQ);
+    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dq_kernel<HDP, HDQ, true>, LDS_DQ);
     set_lds(attn_bwd_dkv_kernel<HDP, HDQ, false>, LDS_DKV);
-    if constexpr (HDP == 96) set_lds(attn_bwd_dkv_kernel<HDP, HDQ, true>, LDS_DKV);
-    if constexpr (HDP == 96) set_lds(attn_bwd_dkv16_kernel<HDP>, LDS_DKV);
-    if constexpr (HDP == 96) set_lds(attn_bwd_dq16_kernel<HDP>, LDS_DQ);
+    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv_kernel<HDP, HDQ, true>, LDS_DKV);
+    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv16_kernel<HDP>, LDS_DKV);
+    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dq16_kernel<HDP>, LDS_DQ);
     once = true;
   }
   const long rows = (long)p.B * p.H * p.Lq;
@@ -1538,9 +1541,9 @@ int run_bwd(AttnP p, hipStream_t s) {
   int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     bool ones_kv = false;
-    if constexpr (HDP == 96) ones_kv = p.kv_pad_ones && p.hd == 72;
+    if constexpr (HDP == 96 && HDQ == 80) ones_kv = p.kv_pad_ones && p.hd == 72;
     vdsprof::Scope ps(ones_kv ? VDS_PROF_ATTN_BWD_DKV : VDS_PROF_ATTN_BWD_DKV_PLAIN, s, 2.0 * prod, 2.0 * qb + 4.0 * kb);
-    if constexpr (HDP == 96) {
+    if constexpr (HDP == 96 && HDQ == 80) {
       if (ones_kv && (attn_variant() & 1))
         hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP>), dim3(grid), dim3(256), LDS_DKV, s, p);
       else if (ones_kv)
@@ -1552,9 +1555,9 @@ int run_bwd(AttnP p, hipStream_t s) {
   grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     bool ones = false;
-    if constexpr (HDP == 96) ones = p.kv_pad_ones && p.hd == 72;
+    if constexpr (HDP == 96 && HDQ == 80) ones = p.kv_pad_ones && p.hd == 72;
     vdsprof::Scope ps(ones ? VDS_PROF_ATTN_BWD_DQ : VDS_PROF_ATTN_BWD_DQ_PLAIN, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
-    if constexpr (HDP == 96) {
+    if constexpr (HDP == 96 && HDQ == 80) {
       if (ones && (attn_variant() & 2))
         hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP>), dim3(grid), dim3(256), LDS_DQ, s, p);
       else if (ones)
@@ -1580,8 +1583,10 @@ extern "C" int vds_attn_fwd(const vds_attn_args* a, vds_stream_t stream) {
   AttnP p = to_p(a);
   hipStream_t s = (hipStream_t)stream;
   switch (a->head_dim) {
+    case 32: return run_fwd<32, 32>(p, s);  // (the reference's own smoke test: width 512 / 16 heads, model.py:545-565)
     case 64: return run_fwd<64, 64>(p, s);
     case 72: return run_fwd<96, 80>(p, s);
+    case 96: return run_fwd<96, 96>(p, s);
     case 128: return run_fwd<128, 128>(p, s);
     default: return VDS_ERR_UNSUPPORTED;
   }
@@ -1599,8 +1604,10 @@ extern "C" int vds_attn_bwd(const vds_attn_args* a, vds_stream_t stream) {
   AttnP p = to_p(a);
   hipStream_t s = (hipStream_t)stream;
   switch (a->head_dim) {
+    case 32: return run_bwd<32, 32>(p, s);
     case 64: return run_bwd<64, 64>(p, s);
     case 72: return run_bwd<96, 80>(p, s);
+    case 96: return run_bwd<96, 96>(p, s);
     case 128: return run_bwd<128, 128>(p, s);
     default: return VDS_ERR_UNSUPPORTED;
   }

@@ -18,8 +18,13 @@
 // so that a 16-row block i of a tile uses the tile rows 32 (m >> 2) + 4 i + (m & 3) as its MFMA rows m = 0..15:
 // accumulator register r of lane (c, g) is then tile row 32 g + 4 i + r, and the eight blocks fill the lane's 32
 // contraction bytes in natural order.
-// Row constants ride in for free: dP accumulates onto C = -delta (scaled), the exponent is one v_fma_f32
-// (score * cs + (8 - lse2)) per element.  P is kept as P * 2^8 (e4m3 tops out at 448): forward <= 2^8.8 relative
+// Row constants and scale factors ride in for free.  The producer quantises q with a factor chosen so that
+// s_q s_k / sqrt(hd) * log2(e) is a power of two, 2^-E (its top binade is still fully used); every S-type product is
+// the block-scaled form of the instruction (v_mfma_scale_f32_16x16x128_f8f6f4, one E8M0 byte per operand: same issue
+// rate, tools/probe_mfma_scale.hip) with scale 2^-E, so its accumulator IS the log2-domain exponent, and it starts
+// from C = the row constant (8 - lse2 backward; 8 (8 - m) + bias per query forward): no multiply-add per element.
+// dP accumulates onto C = -delta with scale 2^-8, which keeps dS = 256 P * dP / 256 below the e5m2 maximum for ANY
+// data (|dO_q| <= 2^-4, |V_q| <= 448: |dS_q| <= 2 * 72 * 28 = 4032) -- no clamp.  P is kept as P * 2^8 (e4m3 tops out at 448): forward <= 2^8.8 relative
 // to the lazily raised running maximum (and rounded to the e4m3 grid in the log domain: P_BYTE in the forward kernel),
 // backward = 256 * the true probability (covers 2^-17 .. 1).
 // LDS image: row-major 128-B rows, 16-B chunk c of row r stored at chunk c ^ swz8(r), swz8(r) = ((r >> 1) & 3) |
@@ -29,6 +34,7 @@
 #include <type_traits>
 #include "prof.h"
 #include "../../include/vds.h"
+#include <cstdlib>
 
 namespace {
 
@@ -51,8 +57,8 @@ struct Attn8P {
   bf16_t* dq; long dq_sb, dq_sh, dq_sl;
   bf16_t* dk; long dk_sb, dk_sh, dk_sl;
   bf16_t* dv; long dv_sb, dv_sh, dv_sl;
-  const float* stats;                    // backward: [2][B,H,Lq]: -delta / (s_do s_v), then 8 - lse log2(e)
-  const float* deq;                      // dequantisation factors {s_q, s_k, s_v, s_do}: x = x_q * s
+  const float* stats;                    // backward: [2][B,H,Lq]: -delta / (256 s_do s_v), then 8 - lse log2(e)
+  const float* deq;                      // {s_q, s_k, s_v, s_do, E}: x = x_q * s; s_q s_k log2(e) / sqrt(hd) = 2^-E
   float scale;
   int n_rt;
 };
@@ -114,6 +120,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<N - 1>(f);
     f(std::integral_constant<int, N - 1>{});
   }
+}
+// block-scaled form: D = C + 2^(sa - 127) 2^(sb - 127) A B (byte 0 of the scale registers, the same for every lane)
+template <int FA, int FB>
+__device__ __forceinline__ f32x4 mfma8s(const i32x8& a, const i32x8& b, f32x4 c, int sa, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, FA, FB, 0, sa, 0, sb);
 }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 // (the first convert replaces the low half of `w`, the second the high half: `w` needs no initial value -- the empty
@@ -205,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
   i32x8 qf[4];
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) qf[cb] = load_row32(rq, qrow0 + 16 * cb, g);
-  const float cs = p.scale * LOG2E * p.deq[0] * p.deq[1];
-  const float cs8 = 8.0f * cs;
+  // S-type products come out as 8 x (log2-domain score): scale 2^(3 - E) (see the file header)
+  const int sc_t = __builtin_amdgcn_readfirstlane(127 + 3 - (int)p.deq[4]);
   const float sv = p.deq[2];
   Frag8 fr;
   fr.init(lane);
@@ -220,7 +231,6 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
   const int nkt = (p.Lk + 127) / 128;
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) retire(qf[cb]);
-  retire(cs8);
   retire(sv);
   VDS_WAIT_VM(0);
   __syncthreads();
@@ -232,12 +242,12 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
     const i32x8 kf = fr.row<0>(smem);
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-      const f32x4 s0 = mfma8<0, 0>(kf, qf[cb], zero4());
+      const f32x4 s0 = mfma8s<0, 0>(kf, qf[cb], zero4(), sc_t, 127);
       float t = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (32 * g + r < p.Lk) t = fmaxf(t, s0[r]);
-      m[cb] = max_over_lane_groups(t) * cs + SEED_HEADROOM;
+      m[cb] = max_over_lane_groups(t) * 0.125f + SEED_HEADROOM;
     }
   }
 
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
   // i.e. b is a piecewise-linear function of log2(value) that deviates from 8 x + 56 by g = 8 (2^f - 1 - f) in
   // [-0.688, 0] (f = frac x).  byte = round(8 x + 56 - 0.344) -- one v_fma_f32 (shared with the score scaling) and one
   // v_cvt_pk_u8_f32 (round to nearest even, saturating at 0, written straight into its byte) per element instead of
-  // fma + v_exp_f32 + convert -- is the value 2^x within a factor 2^(+-0.043) (+- 3 %) before the rounding to the byte
+  // fma + v_exp_f32 + convert (and the fma is folded into the block-scaled MFMA) -- is the value 2^x within a factor 2^(+-0.043) (+- 3 %) before the rounding to the byte
   // grid that every e4m3 cast has (+- 0.5 step): 0.35 instead of 0.29 steps rms.  The softmax denominator is the sum of
   // the SAME bytes (V's ones column), so the weights of a row still sum to one exactly.  Below 2^-6 (bytes < 8, e4m3
   // subnormals: 14.8 binades under the row maximum) the byte grid is linear and the value is under-estimated.
@@ -256,15 +266,20 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
   // Lk -- zero rows -- are kept out of the maximum and of P.
   auto s_phase = [&](const char* kt, i32x8 (&pq)[4], float (&mt)[4], int key_lim, auto RAG) {
     constexpr bool ragged = decltype(RAG)::value;
-    float nm[4];
+    // the accumulators start at the query's constant 8 (8 - m) + bias: t = 8 * exponent + 56 - 0.344 leaves the MFMA
+    f32x4 nm[4];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) { nm[cb] = 8.0f * (P_SHIFT - m[cb]) + LOGDOM_BIAS; mt[cb] = -INFINITY; }
+    for (int cb = 0; cb < 4; ++cb) {
+      const float c0 = 8.0f * (P_SHIFT - m[cb]) + LOGDOM_BIAS;
+      nm[cb] = f32x4{c0, c0, c0, c0};
+      mt[cb] = -INFINITY;
+    }
     f32x4 xn[4];
     i32x8 kfn;  // K fragment of the block whose products are issued in the next iteration (read one iteration ahead)
     {
       const i32x8 kf = fr.row<0>(kt);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) xn[cb] = mfma8<0, 0>(kf, qf[cb], zero4());
+      for (int cb = 0; cb < 4; ++cb) xn[cb] = mfma8s<0, 0>(kf, qf[cb], nm[cb], sc_t, 127);
       kfn = fr.row<1>(kt);
     }
     static_for<8>([&](auto I) {
@@ -274,14 +289,12 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
       for (int cb = 0; cb < 4; ++cb) x[cb] = xn[cb];
       if constexpr (i < 7) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) xn[cb] = mfma8<0, 0>(kfn, qf[cb], zero4());
+        for (int cb = 0; cb < 4; ++cb) xn[cb] = mfma8s<0, 0>(kfn, qf[cb], nm[cb], sc_t, 127);
       }
       if constexpr (i < 6) kfn = fr.row<i + 2>(kt);
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
-        // t = 8 * exponent + 56 - 0.344: the e4m3 byte of 2^exponent, rounded in the LOG domain (see P_BYTE below)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[cb][r] = __builtin_fmaf(x[cb][r], cs8, nm[cb]);
+        // x = the e4m3 byte of 2^exponent before rounding (log-domain rounding: see P_BYTE above)
         if constexpr (ragged) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
         // largest score of the tile, log2 domain: byte value -> exponent -> score
-        const float t = (max_over_lane_groups(mt[cb]) - LOGDOM_BIAS) * 0.125f - (P_SHIFT - m[cb]);
+        const float t = (max_over_lane_groups(mt[cb]) - LOGDOM_BIAS) * 0.125f - (P_SHIFT - m[cb]);  // (mt includes 8 (8 - m) + bias)
         if (t > m[cb]) {  // (the same decision in the 4 lanes of a query)
           const float alpha = __builtin_amdgcn_exp2f(m[cb] - t);
           m[cb] = t;
@@ -330,11 +343,18 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
       }
       s_phase(kt, pq, mt, key_lim, RAG);  // every exponent of the tile is now <= 8 (byte <= 120)
     }
+    // O^T += V^T P^T: the transposed V fragments are double-buffered by hand -- block db+1 is read while the four
+    // products of block db run (hipcc otherwise re-uses one register set and exposes an LDS round trip per block)
+    i32x8 vfa = fr.trans<0>(vt), vfb;
     static_for<NDB>([&](auto DB) {
       constexpr int db = decltype(DB)::value;
-      const i32x8 vf = fr.trans<db>(vt);
+      if constexpr (db + 1 < NDB) {
+        if constexpr (db & 1) vfa = fr.trans<db + 1>(vt);
+        else vfb = fr.trans<db + 1>(vt);
+      }
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) o[db][cb] = mfma8<0, 0>(vf, pq[cb], o[db][cb]);
+      for (int cb = 0; cb < 4; ++cb) o[db][cb] = mfma8<0, 0>((db & 1) ? vfb : vfa, pq[cb], o[db][cb]);
+      __builtin_amdgcn_sched_barrier(0);
     });
     VDS_WAIT_VM(0);
     __syncthreads();
@@ -420,8 +440,9 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
     kf[cb] = load_row32(rk, key0 + 16 * cb, g);
     vf[cb] = load_row32(rv, key0 + 16 * cb, g);
   }
-  const float s_q = p.deq[0], s_k = p.deq[1], s_v = p.deq[2], s_do = p.deq[3];
-  const float cs = p.scale * LOG2E * s_q * s_k;
+  const float s_q = p.deq[0], s_v = p.deq[2], s_do = p.deq[3];
+  const int sc_s = __builtin_amdgcn_readfirstlane(127 - (int)p.deq[4]);  // S products: log2-domain exponents
+  constexpr int SC_DP = 127 - 8;                                          // dP products: x 2^-8
   Frag8 fr;
   fr.init(lane);
 
@@ -433,7 +454,6 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
   const int nqt = (p.Lq + 127) / 128;
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) { retire(kf[cb]); retire(vf[cb]); }
-  retire(cs);
   VDS_WAIT_VM(0);
   __syncthreads();
 
@@ -448,18 +468,20 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
     // exp2 / multiply / pack VALU work of block i; accumulator register r <-> query 32 g + 4 i + r of the tile
     f32x4 sn[2], dpn[2];
     i32x8 aqn, adn;   // fragments of the block whose products are issued in the NEXT iteration: read one iteration ahead
-    f32x4 ndn;        // of their use, so that no MFMA waits on an LDS round trip
+    f32x4 nln, ndn;   // of their use (with their rows' constants), so that no MFMA waits on an LDS round trip
     {
       const i32x8 aq = fr.row<0>(qt);
       const i32x8 ad = fr.row<0>(dot);
+      const f32x4 nl4 = *reinterpret_cast<const f32x4*>(stl + 32 * g);
       const f32x4 nd4 = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        sn[cb] = mfma8<0, 0>(aq, kf[cb], zero4());
-        dpn[cb] = mfma8<1, 0>(ad, vf[cb], nd4);  // dO (e5m2) V^T - delta, in units of s_do s_v
+        sn[cb] = mfma8s<0, 0>(aq, kf[cb], nl4, sc_s, 127);     // 8 - lse2 + log2-domain score
+        dpn[cb] = mfma8s<1, 0>(ad, vf[cb], nd4, SC_DP, 127);   // (dO V^T - delta) / (256 s_do s_v)
       }
       aqn = fr.row<1>(qt);
       adn = fr.row<1>(dot);
+      nln = *reinterpret_cast<const f32x4*>(stl + 32 * g + 4);
       ndn = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g + 4);
     }
     static_for<8>([&](auto I) {
@@ -467,17 +489,17 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
       f32x4 s[2], dp[2];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) { s[cb] = sn[cb]; dp[cb] = dpn[cb]; }
-      const f32x4 nl4 = *reinterpret_cast<const f32x4*>(stl + 32 * g + 4 * i);
       if constexpr (i < 7) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          sn[cb] = mfma8<0, 0>(aqn, kf[cb], zero4());
-          dpn[cb] = mfma8<1, 0>(adn, vf[cb], ndn);
+          sn[cb] = mfma8s<0, 0>(aqn, kf[cb], nln, sc_s, 127);
+          dpn[cb] = mfma8s<1, 0>(adn, vf[cb], ndn, SC_DP, 127);
         }
       }
       if constexpr (i < 6) {
         aqn = fr.row<i + 2>(qt);
         adn = fr.row<i + 2>(dot);
+        nln = *reinterpret_cast<const f32x4*>(stl + 32 * g + 4 * (i + 2));
         ndn = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g + 4 * (i + 2));
       }
 #pragma unroll
@@ -485,23 +507,28 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
         f32x4 pr, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[cb][r], cs, nl4[r]));  // 256 P
-          ds[r] = pr[r] * dp[cb][r];
+          pr[r] = __builtin_amdgcn_exp2f(s[cb][r]);  // 256 P
+          ds[r] = pr[r] * dp[cb][r];                 // P (dP - delta) / (s_do s_v): |.| <= 4032 (file header)
         }
         pq[cb][i] = cvt4_e4m3(pr);
         dsq[cb][i] = cvt4_e5m2(ds);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+    // dV^T += dO^T P, dK^T += Q^T dS: transposed fragments double-buffered by hand (see the forward kernel)
+    i32x8 doa = fr.trans<0>(dot), qta = fr.trans<0>(qt), dob, qtb;
     static_for<NDB>([&](auto DB) {
       constexpr int db = decltype(DB)::value;
-      const i32x8 ado = fr.trans<db>(dot);
-      const i32x8 aqt = fr.trans<db>(qt);
+      if constexpr (db + 1 < NDB) {
+        if constexpr (db & 1) { doa = fr.trans<db + 1>(dot); qta = fr.trans<db + 1>(qt); }
+        else { dob = fr.trans<db + 1>(dot); qtb = fr.trans<db + 1>(qt); }
+      }
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        dv[db][cb] = mfma8<1, 0>(ado, pq[cb], dv[db][cb]);
-        dk[db][cb] = mfma8<0, 1>(aqt, dsq[cb], dk[db][cb]);
+        dv[db][cb] = mfma8<1, 0>((db & 1) ? dob : doa, pq[cb], dv[db][cb]);
+        dk[db][cb] = mfma8<0, 1>((db & 1) ? qtb : qta, dsq[cb], dk[db][cb]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     });
     VDS_WAIT_VM(0);
     __syncthreads();
@@ -510,8 +537,8 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
     q_tile(j, std::integral_constant<int, 0>{});
     if (j + 1 < nqt) q_tile(j + 1, std::integral_constant<int, 1>{});
   }
-  const float fk = p.scale * s_do * s_v * s_q * (1.0f / 256.0f);  // dS_q = 256 dS / (s_do s_v)
-  const float fv = s_do * (1.0f / 256.0f);
+  const float fk = p.scale * s_do * s_v * s_q;  // dS_q = dS / (s_do s_v)
+  const float fv = s_do * (1.0f / 256.0f);      // P_q = 256 P
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int krow = key0 + 16 * cb;
@@ -534,8 +561,11 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
 // Workgroup = 128 queries (4 waves x 2 column blocks of 16), Q / dO rows as B operands in registers, the query's
 // 8 - lse2 as the exponent's addend and -delta' as the dP accumulator's start; K / V tiles of 128 keys by LDS-DMA.
 // Keys past Lk are zero rows of K: whatever dS they get multiplies a zero column of K^T.
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
+// NW = 6 (192 queries per workgroup, VDS_ATTN8_DQ_WAVES=6): the kernel needs <= 168 registers, so three waves fit on a
+// SIMD with two workgroups of six waves.  Measured SLOWER than NW = 4 (2.7 vs 2.0 ms at B=6, L=8208): kept as an
+// experiment only.
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kernel(Attn8P p) {
   static_assert(HD == 72, "5 output blocks of 16");
   constexpr int NDB = 5;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -544,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qrow0 = qt * 128 + wave * 32 + (lane & 15);
+  const int qrow0 = qt * (32 * NW) + wave * 32 + (lane & 15);
   const long head = (long)b * p.H + hh;
   const long nrows = (long)p.B * p.H * p.Lq;
 
@@ -552,14 +582,15 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
   const __amdgpu_buffer_rsrc_t rdo = make_rsrc(p.d_o + head * p.Lq * ROWB, (unsigned)(p.Lq * ROWB));
   const srd_t rk = make_srd(p.k + head * p.Lk * ROWB, (unsigned)(p.Lk * ROWB));
   const srd_t rv = make_srd(p.v + head * p.Lk * ROWB, (unsigned)(p.Lk * ROWB));
-  Stage8 st;
-  st.init(wave, lane);
-  st.issue(rk, smem, 0, wave);
-  st.issue(rv, smem + TILE, 0, wave);
+  Stage8 st;  // the tiles are staged by waves 0-3 (4 pieces of each tile per wave)
+  st.init(wave & 3, lane);
+  if (wave < 4) {
+    st.issue(rk, smem, 0, wave);
+    st.issue(rv, smem + TILE, 0, wave);
+  }
 
   i32x8 qf[2], dof[2];
-  float nl[2];
-  f32x4 nd4[2];
+  f32x4 nl4[2], nd4[2];  // the query's constants as accumulator start values
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int qrow = qrow0 + 16 * cb;
@@ -567,11 +598,13 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
     dof[cb] = load_row32(rdo, qrow, g);
     const long srow = head * p.Lq + min(qrow, p.Lq - 1);
     const float nd = p.stats[srow];
-    nl[cb] = p.stats[nrows + srow];
+    const float nl = p.stats[nrows + srow];
     nd4[cb] = f32x4{nd, nd, nd, nd};
+    nl4[cb] = f32x4{nl, nl, nl, nl};
   }
-  const float s_q = p.deq[0], s_k = p.deq[1], s_v = p.deq[2], s_do = p.deq[3];
-  const float cs = p.scale * LOG2E * s_q * s_k;
+  const float s_k = p.deq[1], s_v = p.deq[2], s_do = p.deq[3];
+  const int sc_s = __builtin_amdgcn_readfirstlane(127 - (int)p.deq[4]);
+  constexpr int SC_DP = 127 - 8;
   Frag8 fr;
   fr.init(lane);
 
@@ -582,14 +615,13 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
     for (int cb = 0; cb < 2; ++cb) dq[db][cb] = zero4();
   const int nkt = (p.Lk + 127) / 128;
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) { retire(qf[cb]); retire(dof[cb]); retire(nl[cb]); retire(nd4[cb][0]); }
-  retire(cs);
+  for (int cb = 0; cb < 2; ++cb) { retire(qf[cb]); retire(dof[cb]); retire(nl4[cb][0]); retire(nd4[cb][0]); }
   VDS_WAIT_VM(0);
   __syncthreads();
 
   auto kv_tile = [&](int j, auto PAR) {
     constexpr int par = decltype(PAR)::value;
-    if (j + 1 < nkt) {
+    if (j + 1 < nkt && wave < 4) {
       char* nk = smem + (par ^ 1) * 2 * TILE;
       st.issue(rk, nk, (unsigned)(j + 1) * TILE, wave);
       st.issue(rv, nk + TILE, (unsigned)(j + 1) * TILE, wave);
@@ -604,8 +636,8 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
       const i32x8 av = fr.row<0>(vt);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        sn[cb] = mfma8<0, 0>(ak, qf[cb], zero4());
-        dpn[cb] = mfma8<0, 1>(av, dof[cb], nd4[cb]);
+        sn[cb] = mfma8s<0, 0>(ak, qf[cb], nl4[cb], sc_s, 127);
+        dpn[cb] = mfma8s<0, 1>(av, dof[cb], nd4[cb], SC_DP, 127);
       }
       akn = fr.row<1>(kt);
       avn = fr.row<1>(vt);
@@ -618,8 +650,8 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
       if constexpr (i < 7) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          sn[cb] = mfma8<0, 0>(akn, qf[cb], zero4());
-          dpn[cb] = mfma8<0, 1>(avn, dof[cb], nd4[cb]);
+          sn[cb] = mfma8s<0, 0>(akn, qf[cb], nl4[cb], sc_s, 127);
+          dpn[cb] = mfma8s<0, 1>(avn, dof[cb], nd4[cb], SC_DP, 127);
         }
       }
       if constexpr (i < 6) {
@@ -630,16 +662,22 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
       for (int cb = 0; cb < 2; ++cb) {
         f32x4 ds;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[cb][r], cs, nl[cb])) * dp[cb][r];
+        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(s[cb][r]) * dp[cb][r];  // P (dP - delta) / (s_do s_v)
         dsq[cb][i] = cvt4_e5m2(ds);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+    // dQ^T += K^T dS^T: transposed K fragments double-buffered by hand (see the forward kernel)
+    i32x8 kta = fr.trans<0>(kt), ktb;
     static_for<NDB>([&](auto DB) {
       constexpr int db = decltype(DB)::value;
-      const i32x8 akt = fr.trans<db>(kt);
+      if constexpr (db + 1 < NDB) {
+        if constexpr (db & 1) kta = fr.trans<db + 1>(kt);
+        else ktb = fr.trans<db + 1>(kt);
+      }
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) dq[db][cb] = mfma8<0, 1>(akt, dsq[cb], dq[db][cb]);
+      for (int cb = 0; cb < 2; ++cb) dq[db][cb] = mfma8<0, 1>((db & 1) ? ktb : kta, dsq[cb], dq[db][cb]);
+      __builtin_amdgcn_sched_barrier(0);
     });
     VDS_WAIT_VM(0);
     __syncthreads();
@@ -648,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
     kv_tile(j, std::integral_constant<int, 0>{});
     if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
   }
-  const float fq = p.scale * s_do * s_v * s_k * (1.0f / 256.0f);
+  const float fq = p.scale * s_do * s_v * s_k;
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int qrow = qrow0 + 16 * cb;
@@ -666,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dq_kernel(Attn8P p) {
 
 // ===================================== preprocess ===========================================
 // delta preprocess of the fp8 backward: one wave per token of the token-major O / dO ([B*Lq, H*hd] bf16, what the
-// model passes).  Per head:  stats[0][b,h,q] = -rowsum(dO o O) / (s_do s_v),  stats[1][b,h,q] = 8 - lse log2(e);
+// model passes).  Per head:  stats[0][b,h,q] = -rowsum(dO o O) / (256 s_do s_v),  stats[1][b,h,q] = 8 - lse log2(e);
 // dO leaves as e5m2 rows [B,H,Lq,128] (bytes [hd,128) are never written: the buffer is zeroed once by its owner),
 // scaled so that the previous step's amax lands on DO_TARGET; the current amax is recorded (delayed scaling).
 constexpr float DO_TARGET = 0.0625f;  // dO_q in [2^-16, 2^-4]: dS_q = 256 P dP' then stays below the e5m2 maximum
@@ -706,8 +744,14 @@ __global__ __launch_bounds__(256) void attn8_delta_kernel(const bf16_t* o, long 
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         int x = 0;
-        x = __builtin_amdgcn_cvt_pk_bf8_f32(f[4 * e] * alpha, f[4 * e + 1] * alpha, x, false);
-        x = __builtin_amdgcn_cvt_pk_bf8_f32(f[4 * e + 2] * alpha, f[4 * e + 3] * alpha, x, true);
+        // saturating: an element that outgrew the previous step's amax is clipped at DO_TARGET -- the bound the
+        // backward kernels' dS range rests on (delayed scaling; the cast itself does not saturate)
+        const float g0 = __builtin_amdgcn_fmed3f(f[4 * e] * alpha, -DO_TARGET, DO_TARGET);
+        const float g1 = __builtin_amdgcn_fmed3f(f[4 * e + 1] * alpha, -DO_TARGET, DO_TARGET);
+        const float g2 = __builtin_amdgcn_fmed3f(f[4 * e + 2] * alpha, -DO_TARGET, DO_TARGET);
+        const float g3 = __builtin_amdgcn_fmed3f(f[4 * e + 3] * alpha, -DO_TARGET, DO_TARGET);
+        x = __builtin_amdgcn_cvt_pk_bf8_f32(g0, g1, x, false);
+        x = __builtin_amdgcn_cvt_pk_bf8_f32(g2, g3, x, true);
         w[e] = (unsigned)x;
       }
 #pragma unroll
@@ -723,7 +767,7 @@ __global__ __launch_bounds__(256) void attn8_delta_kernel(const bf16_t* o, long 
     for (int i = 0; i < cph; ++i) acc += part[wave][lane * cph + i];
     const long rows = (long)B * H * Lq;
     const long row = ((long)b * H + lane) * Lq + q;
-    stats[row] = -acc / (s_do * deq[2]);
+    stats[row] = -acc / (s_do * deq[2] * 256.0f);
     stats[rows + row] = P_SHIFT - lse[row] * LOG2E;
   }
   amax = wave_max(amax);
@@ -731,11 +775,23 @@ __global__ __launch_bounds__(256) void attn8_delta_kernel(const bf16_t* o, long 
 }
 
 // qkv head split + 3-D RoPE + residual-V mix (model.py:125-134,266-275) with fp8 outputs: q, k, v leave as e4m3 rows
-// [B,H,L,128] (bytes [hd,128) zero, V byte hd = 1.0: the softmax denominator's ones column), each scaled so that the
-// previous step's amax of the tensor lands on 448; the current amax is recorded.  The values quantised are the bf16
-// results of the bf16 kernel (vds_qkv_rope_fwd), rounding points included.  v_out (optional): the bf16 v in the
-// padded head-major layout -- block 0's v feeds the residual-V mix of the later blocks.
-// One thread = one 16-byte output chunk (16 head-dim columns) of one (tensor, token, head); blockIdx.y = tensor.
+// [B,H,L,128] (bytes [hd,128) zero, V byte hd = 1.0: the softmax denominator's ones column), scaled with the previous
+// step's amax (delayed scaling, saturating): k and v so that it lands on 448; q so that s_q s_k log2(e) / sqrt(hd) is
+// a power of two 2^-E with its amax in (224, 448] (the attention kernels fold 2^-E into their block-scaled MFMAs).
+// The current amax of each tensor is recorded.  The values quantised are the bf16 results of the bf16 kernel
+// (vds_qkv_rope_fwd), rounding points included.  v_out (optional): the bf16 v in the padded head-major layout -- block
+// 0's v feeds the residual-V mix of the later blocks.
+// One thread = one 16-byte output chunk (16 head-dim columns) of one (tensor, token, head); blockIdx.y = tensor.  All
+// loads are 16 / 8 bytes wide: the 4-column groups never straddle the rotation halves (hd / 2 is a multiple of 4).
+__device__ __forceinline__ void qk_scales(const float* amax_prev, int stride, int hd, float& alpha_q, float& alpha_k, float& E) {
+  const float aq = amax_prev[0], ak = amax_prev[stride];
+  alpha_k = ak > 0.f ? 448.0f / ak : 1.0f;
+  const float cl = LOG2E / sqrtf((float)hd);
+  int e = 1;
+  if (aq > 0.f) (void)frexpf(448.0f * alpha_k / (cl * aq), &e);  // x = f 2^e, f in [0.5, 1): floor(log2 x) = e - 1
+  E = (float)(e - 1);
+  alpha_q = cl * exp2f(E) / alpha_k;
+}
 __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_kernel(const bf16_t* qkv, const float* cosb, const float* sinb,
                                                                const bf16_t* v0, const bf16_t* lamp, unsigned char* q8,
                                                                unsigned char* k8, unsigned char* v8, bf16_t* v_out,
@@ -744,73 +800,100 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_kernel(const bf16_t* qkv
   const int which = blockIdx.y;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long n = (long)B * H * L * 8;
-  const float ap = amax_prev[which * amax_stride];
-  const float alpha = ap > 0.f ? 448.0f / ap : 1.0f;
-  if (gid == 0) deq[which] = 1.0f / alpha;
+  float alpha;
+  {
+    float aq, ak, E;
+    qk_scales(amax_prev, amax_stride, hd, aq, ak, E);
+    const float av = amax_prev[2 * amax_stride];
+    alpha = which == 0 ? aq : which == 1 ? ak : (av > 0.f ? 448.0f / av : 1.0f);
+    if (gid == 0) {
+      deq[which] = 1.0f / alpha;
+      if (which == 0) deq[4] = E;
+    }
+  }
   float amax = 0.f;
   if (gid < n) {
+    // thread order (token, head, chunk): a wave reads 8 consecutive heads of one token (contiguous in the qkv row)
+    // and writes 8 complete 128-byte head rows
     const int c = (int)(gid & 7);
-    const long row = gid >> 3;  // (b*H + h)*L + l
-    const int l = (int)(row % L);
-    const long bhx = row / L;
-    const int hh = (int)(bhx % H), b = (int)(bhx / H);
+    const int hh = (int)((gid >> 3) % H);
+    const long tok = gid / (8 * H);
+    const int l = (int)(tok % L), b = (int)(tok / L);
+    const long row = ((long)b * H + hh) * L + l;
     const int half = hd >> 1, D = H * hd;
-    const bf16_t* src = qkv + ((long)b * L + l) * 3 * D + which * D + hh * hd;
+    const bf16_t* src = qkv + tok * 3 * D + which * D + hh * hd;
     unsigned char* dst = (which == 0 ? q8 : which == 1 ? k8 : v8) + row * ROWB + 16 * c;
+    const int d0 = 16 * c;
     float y[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) y[e] = 0.f;
-    const int d0 = 16 * c;
     if (d0 < hd) {
-      if (which < 2) {
-        const float* cr = cosb + (long)l * half;
-        const float* sr = sinb + (long)l * half;
+      // own 16 columns (those past hd: the next head's / tensor's first columns, masked below), 4 groups of 4
+      u32x2 own[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int d = d0 + e;
+      for (int j = 0; j < 4; ++j) own[j] = d0 + 4 * j < hd ? *reinterpret_cast<const u32x2*>(src + d0 + 4 * j) : u32x2{0u, 0u};
+      if (which < 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int d = d0 + 4 * j;
           if (d < hd) {
             const bool lo = d < half;
-            const int j = lo ? d : d - half;
-            const float x = bf2f(src[d]), pt = bf2f(src[lo ? d + half : d - half]);
-            const float v = lo ? x * cr[j] + pt * sr[j] : x * cr[j] - pt * sr[j];
-            y[e] = bf2f(f2bf(v));
+            const int jj = lo ? d : d - half;
+            const u32x2 pt = *reinterpret_cast<const u32x2*>(src + (lo ? d + half : d - half));
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosb + (long)l * half + jj);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinb + (long)l * half + jj);
+            const float x[4] = {bflo(own[j][0]), bfhi(own[j][0]), bflo(own[j][1]), bfhi(own[j][1])};
+            const float pp[4] = {bflo(pt[0]), bfhi(pt[0]), bflo(pt[1]), bfhi(pt[1])};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = lo ? x[e] * c4[e] + pp[e] * s4[e] : x[e] * c4[e] - pp[e] * s4[e];
+              y[4 * j + e] = bf2f(f2bf(v));
+            }
           }
         }
       } else {
         float lam = 0.f, oml = 0.f;
-        const bf16_t* v0r = nullptr;
         if (v0) {
           lam = bf2f(*lamp);
           oml = bf2f(f2bf(1.0f - lam));
-          v0r = v0 + row * hdp;
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int d = d0 + e;
+        for (int j = 0; j < 4; ++j) {
+          const int d = d0 + 4 * j;
           if (d < hd) {
-            float x = bf2f(src[d]);
-            if (v0) x = bf2f(f2bf(bf2f(f2bf(lam * x)) + bf2f(f2bf(oml * bf2f(v0r[d])))));
-            y[e] = x;
-          }
-        }
-        if (v_out) {
-          bf16_t* vo = v_out + row * hdp;
+            float x[4] = {bflo(own[j][0]), bfhi(own[j][0]), bflo(own[j][1]), bfhi(own[j][1])};
+            if (v0) {
+              const u32x2 a = *reinterpret_cast<const u32x2*>(v0 + row * hdp + d);
+              const float z[4] = {bflo(a[0]), bfhi(a[0]), bflo(a[1]), bfhi(a[1])};
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if (d0 + e < hdp) vo[d0 + e] = d0 + e < hd ? f2bf(y[e]) : (bf16_t)(((hdp - hd) >= 8 && (d0 + e == hd || d0 + e == hd + 4)) ? 0x3f80 : 0);
+              for (int e = 0; e < 4; ++e) x[e] = bf2f(f2bf(bf2f(f2bf(lam * x[e])) + bf2f(f2bf(oml * z[e]))));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[4 * j + e] = x[e];
+          }
         }
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(y[e]));
-    } else if (which == 2 && v_out) {
-      bf16_t* vo = v_out + row * hdp;
+    }
+    if (which == 2 && v_out && d0 < hdp) {  // bf16 v with the bf16 kernels' pad (ones at hd, hd+4 when the pad is >= 8 wide)
+      bf16_t* vo = v_out + row * hdp + d0;
+      const bool ones = (hdp - hd) >= 8;
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (d0 + e < hdp) vo[d0 + e] = 0;
+      for (int j = 0; j < 4; ++j) {
+        const int d = d0 + 4 * j;
+        if (d < hdp) {
+          u32x2 w = {pack_bf2(y[4 * j], y[4 * j + 1]), pack_bf2(y[4 * j + 2], y[4 * j + 3])};
+          if (d >= hd) w = (ones && (d == hd || d == hd + 4)) ? u32x2{0x3f80u, 0u} : u32x2{0u, 0u};
+          *reinterpret_cast<u32x2*>(vo + 4 * j) = w;
+        }
+      }
     }
     u32x4 w;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = fp8_cvt4<0>(y[4 * e] * alpha, y[4 * e + 1] * alpha, y[4 * e + 2] * alpha, y[4 * e + 3] * alpha);
+    for (int e = 0; e < 16; ++e) y[e] = __builtin_amdgcn_fmed3f(y[e] * alpha, -448.0f, 448.0f);  // saturating cast
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = fp8_cvt4<0>(y[4 * e], y[4 * e + 1], y[4 * e + 2], y[4 * e + 3]);
     if (which == 2 && hd >= d0 && hd < d0 + 16) {  // ones column: byte hd of every V row = 1.0 (e4m3 0x38)
       const int e = hd - d0;
       w[e >> 2] = (w[e >> 2] & ~(0xffu << (8 * (e & 3)))) | (0x38u << (8 * (e & 3)));
@@ -903,7 +986,8 @@ extern "C" int vds_attn_fp8_bwd(const vds_attn_fp8_args* a, vds_stream_t stream)
   static bool once = false;
   if (!once) {
     set_lds(attn8_bwd_dkv_kernel<72>, LDS_DKV);
-    set_lds(attn8_bwd_dq_kernel<72>, LDS_DQ);
+    set_lds(attn8_bwd_dq_kernel<72, 4>, LDS_DQ);
+    set_lds(attn8_bwd_dq_kernel<72, 6>, LDS_DQ);
     once = true;
   }
   Attn8P p = to_p(a);
@@ -916,11 +1000,17 @@ extern "C" int vds_attn_fp8_bwd(const vds_attn_fp8_args* a, vds_stream_t stream)
     vdsprof::Scope ps(VDS_PROF_ATTN_FP8_DKV, s, 2.0 * prod, bytes + 4.0 * p.B * p.H * p.hd * (double)p.Lk);
     hipLaunchKernelGGL((attn8_bwd_dkv_kernel<72>), dim3(grid), dim3(256), LDS_DKV, s, p);
   }
-  p.n_rt = cdiv(p.Lq, 128);
+  static int dq_waves = 0;  // VDS_ATTN8_DQ_WAVES=4|6 (experiments)
+  if (!dq_waves) {
+    const char* e = getenv("VDS_ATTN8_DQ_WAVES");
+    dq_waves = (e && atoi(e) == 6) ? 6 : 4;  // measured (B=6, L=8208): 2.0 ms with 4 waves, 2.7 ms with 6
+  }
+  p.n_rt = cdiv(p.Lq, 32 * dq_waves);
   grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     vdsprof::Scope ps(VDS_PROF_ATTN_FP8_DQ, s, 2.0 * prod, bytes + 2.0 * p.B * p.H * p.hd * (double)p.Lq);
-    hipLaunchKernelGGL((attn8_bwd_dq_kernel<72>), dim3(grid), dim3(256), LDS_DQ, s, p);
+    if (dq_waves == 6) hipLaunchKernelGGL((attn8_bwd_dq_kernel<72, 6>), dim3(grid), dim3(384), LDS_DQ, s, p);
+    else hipLaunchKernelGGL((attn8_bwd_dq_kernel<72, 4>), dim3(grid), dim3(256), LDS_DQ, s, p);
   }
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
@@ -934,6 +1024,7 @@ extern "C" int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const fl
       hdp < hd)
     return VDS_ERR_ARG;
   if (v0 && !lam) return VDS_ERR_ARG;
+  if ((hd & 7) || (hdp & 3) || ((H * hd) & 7)) return VDS_ERR_ARG;  // 8-byte groups of 4 columns; hd / 2 % 4 == 0
   const long n = (long)B * H * L * 8;
   hipStream_t s = (hipStream_t)stream;
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, s, 0.0, (double)B * L * H * (6.0 * hd + 3.0 * ROWB + (v0 ? 2.0 * hd : 0.0)));

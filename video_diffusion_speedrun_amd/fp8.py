@@ -2,10 +2,12 @@
 
 The reference trains in bf16 only (model.py:516-518), so the recipe is this build's own and is stated here:
 
-  * the three large token GEMMs of a block -- qkv, mlp.0 (fc1), mlp.2 (fc2), 11 of its 14 linear-layer FLOP
-    units -- run on `vds_gemm_fp8` (v_mfma_f32_16x16x128_f8f6f4, 2x the bf16 MFMA rate) in forward, input
-    gradient and weight gradient; attention, the K=N=1152 projections (whose quantisation passes would cost more
-    than the faster GEMM returns), norms, modulation, residuals, loss and the optimizer stay as in the bf16 path;
+  * every linear layer of a block -- qkv, mlp.0 (fc1), mlp.2 (fc2), and (round 3, `all_linears`) attn_proj, q_cross,
+    context_kv, cross_proj -- runs on `vds_gemm_fp8` (v_mfma_f32_16x16x128_f8f6f4, 2x the bf16 MFMA rate) in forward,
+    input gradient and weight gradient; the self-attention products run on the same instruction
+    (csrc/attention_fp8.hip, `attention`: e4m3 Q / K / V / P, e5m2 dO / dS, fp32 softmax statistics; P is rounded to
+    the e4m3 grid in the log domain in the forward pass, see P_BYTE there); cross-attention (L x 512), norms,
+    modulation, residuals, loss and the optimizer stay as in the bf16 path;
   * OCP e4m3fn for activations and weights, e5m2 for gradients, fp32 accumulation, bf16 / fp32 outputs;
   * per-tensor scaling with saturating casts.  Weights are scaled by their current amax.  Activations and
     gradients use delayed scaling in training: the scale comes from the amax the previous step recorded
@@ -35,8 +37,12 @@ bf16, f32 = torch.bfloat16, torch.float32
 E4M3, E5M2 = ops.FP8_E4M3, ops.FP8_E5M2
 # rows of the delayed-scaling table per DiT block: 0 gelu(fc1), 1 d(fc2 input), 2 xn1 (qkv input), 3 xn3 (fc1 input),
 # 4 d(mlp output), 5 d(qkv output); fp8 attention: 6 q, 7 k, 8 v (post-RoPE / lambda-mix), 9 d(attention output)
-ROWS = 10
+# the four 1152^2-class linears (`enable_fp8(all_linears=True)`): 10 attention output (attn_proj input), 11 cross-attention
+# output (cross_proj input), 12 xn2 (q_cross input), 13 d(q_cross output), 14 d(context_kv output), 15 d(attn_proj
+# output), 16 d(cross_proj output); one more row after the blocks' rows: the text context (context_kv input, shared)
+ROWS = 17
 ROW_Q, ROW_DO = 6, 9
+ROW_ATTN, ROW_CATT, ROW_XN2, ROW_DQC, ROW_DCKV, ROW_DY_AP, ROW_DY_CP = 10, 11, 12, 13, 14, 15, 16
 
 
 class Q:

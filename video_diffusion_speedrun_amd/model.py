@@ -40,6 +40,10 @@ _NO_PRODUCER_EMIT = os.environ.get("VDS_FP8_PRODUCER_EMIT") == "0"  # experiment
 
 bf16, f32 = torch.bfloat16, torch.float32
 N_REG = 16  # register tokens (model.py:316,362,386)
+# head_dim -> row length of the head-major q / k / v buffers (the attention kernels' LDS images are multiples of 32
+# columns; 72 -> 96 leaves room for the ones columns of the DiT-XL kernels).  The reference accepts any head_dim
+# (hidden_size // num_heads); other values raise in DiT.__init__ with the list below.
+HDP_OF = {32: 32, 64: 64, 72: 96, 96: 96, 128: 128}
 
 
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
@@ -315,12 +319,13 @@ class DiTBlock(nn.Module):
         parameters under the name prefix `pre`; cvec f32 [B, D]; v0: block 0's v in the padded head-major layout
         or None; cos / sin f32 [L, hd/2]; fp8 = (AmaxHistory | None, block index) when the fp8 linears are on."""
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
-        hdp = {64: 64, 72: 96, 128: 128}[hd]
+        hdp = HDP_OF[hd]
         use_fp8 = fp8 is not None
-        fp8_hist, i, fp8_attn = fp8 if use_fp8 else (None, 0, False)
+        fp8_hist, i, fp8_attn, fp8_lin, q_ctx = fp8 if use_fp8 else (None, 0, False, False, None)
         W = lambda n: G.w(pre + n)
         Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
         dev = X.device
+        R0 = F8.ROWS * i
         if mod is None:  # (DiT.forward computes the modulation of all blocks in one batched launch and passes it in)
             mod = ops.small_linear_fwd(cvec, W("adaLN_modulation.1.weight"), W("adaLN_modulation.1.bias"), 1)
         # --- self attention (model.py:122-139)
@@ -355,7 +360,7 @@ class DiTBlock(nn.Module):
         q = k = q8 = k8 = v8 = deq = None
         if a8:
             r0 = F8.ROWS * i + F8.ROW_Q
-            deq = torch.empty(4, dtype=f32, device=dev)
+            deq = torch.empty(8, dtype=f32, device=dev)  # {s_q, s_k, s_v, s_do, E}: include/vds.h, vds_attn_fp8_args
             cur = fp8_hist.tab[r0:r0 + 3, 1] if save else fp8_hist.scratch(3)  # (no-grad forwards record nothing)
             q8, k8, v8, v = ops.qkv_rope_fwd_fp8(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None,
                                                  B, L, H, hd, hdp, fp8_hist.tab[r0:r0 + 3, 0], cur, 2, deq,
@@ -369,20 +374,50 @@ class DiTBlock(nn.Module):
             if a8_on and save:  # first steps: record the amax the next step quantises with
                 for j, t in enumerate((q, k, v)):
                     ops.absmax(t.view(B * H * L, hdp)[:, :hd], fp8_hist.cur(F8.ROWS * i + F8.ROW_Q + j))
-        y_sa, X1 = ops.linear_fwd_gate_res(attn, W("attn_proj.weight"), None, mod, 2 * D, X, L)
+        f8l = f8 and fp8_lin  # the 1152^2-class linears in fp8 too
+        q_attn = q_wap = q_xn2 = q_wqc = q_wkv = q_catt = q_wcp = None
+        if f8l:
+            q_attn = F8.Q(attn, F8.E4M3, True, save, hist, R0 + F8.ROW_ATTN)
+            q_wap = F8.Q(W("attn_proj.weight"), F8.E4M3, True, save)
+            y_sa, X1 = F8.fwd_gate_res(q_attn, q_wap, None, mod, 2 * D, X, L)
+        else:
+            y_sa, X1 = ops.linear_fwd_gate_res(attn, W("attn_proj.weight"), None, mod, 2 * D, X, L)
         # --- cross attention (model.py:142-160)
         has_cross = G.has(pre + "q_cross.weight")
         if has_cross:
-            xn2, rstd2 = ops.rmsnorm_mod_fwd(X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, B, L)
-            qc = ops.linear_fwd(xn2, W("q_cross.weight"), Wo("q_cross.bias"))
-            ckv = ops.linear_fwd(ctx2d, W("context_kv.weight"), Wo("context_kv.bias"))
+            f8c = f8l and q_ctx is not None and F8.supported(B * Lc, 2 * D, ctx2d.shape[1])
+            xn2 = None
+            if f8c and pemit:
+                fq, fs, rstd2 = ops.rmsnorm_mod_fwd_fp8(X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, B, L, F8.E4M3,
+                                                      hist.prev(R0 + F8.ROW_XN2), hist.part(R0 + F8.ROW_XN2, B * L))
+                q_xn2 = F8.Q.from_rowmajor(fq, fs, save)
+            else:
+                xn2, rstd2 = ops.rmsnorm_mod_fwd(X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, B, L)
+            if f8c:
+                if q_xn2 is None:
+                    q_xn2 = F8.Q(xn2, F8.E4M3, True, save, hist, R0 + F8.ROW_XN2)
+                q_wqc = F8.Q(W("q_cross.weight"), F8.E4M3, True, save)
+                qc = torch.empty(B * L, D, dtype=bf16, device=dev)
+                F8.fwd(q_xn2, q_wqc, qc, Wo("q_cross.bias"))
+                q_wkv = F8.Q(W("context_kv.weight"), F8.E4M3, True, save)
+                ckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
+                F8.fwd(q_ctx, q_wkv, ckv, Wo("context_kv.bias"))
+            else:
+                qc = ops.linear_fwd(xn2, W("q_cross.weight"), Wo("q_cross.bias"))
+                ckv = ops.linear_fwd(ctx2d, W("context_kv.weight"), Wo("context_kv.bias"))
             catt = torch.empty(B * L, D, dtype=bf16, device=dev)
             lse2 = torch.empty(B, H, L, dtype=f32, device=dev)
             ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), ops.heads_view(ckv, B, Lc, H, hd, 0),
                          ops.heads_view(ckv, B, Lc, H, hd, D), ops.heads_view(catt, B, L, H, hd), lse2)
-            y_ca, X2 = ops.linear_fwd_gate_res(catt, W("cross_proj.weight"), None, mod, 5 * D, X1, L)
+            if f8c:
+                q_catt = F8.Q(catt, F8.E4M3, True, save, hist, R0 + F8.ROW_CATT)
+                q_wcp = F8.Q(W("cross_proj.weight"), F8.E4M3, True, save)
+                y_ca, X2 = F8.fwd_gate_res(q_catt, q_wcp, None, mod, 5 * D, X1, L)
+            else:
+                y_ca, X2 = ops.linear_fwd_gate_res(catt, W("cross_proj.weight"), None, mod, 5 * D, X1, L)
         else:
             X2 = X1
+            f8c = False
         # --- MLP (model.py:163-165)
         if pemit:
             fq, fs, rstd3 = ops.rmsnorm_mod_fwd_fp8(X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, B, L, F8.E4M3,
@@ -417,10 +452,17 @@ class DiTBlock(nn.Module):
             if has_cross:
                 bs.xn2, bs.rstd2, bs.qc, bs.ckv, bs.catt, bs.lse2, bs.y_ca = xn2, rstd2, qc, ckv, catt, lse2, y_ca
             bs.xn3, bs.rstd3, bs.hpre, bs.hact, bs.y_mlp = xn3, rstd3, hpre, hact, y_mlp
-            bs.f8 = f8
+            bs.f8, bs.f8l, bs.f8c = f8, f8l, f8c
             if f8:  # the backward contracts the fp8 copies: the bf16 GEMM inputs need not be kept
                 bs.q_xn1, bs.q_wqkv, bs.q_xn3, bs.q_w1, bs.q_hact, bs.q_w2 = q_xn1, q_wqkv, q_xn3, q_w1, q_hact, q_w2
                 bs.xn1 = bs.xn3 = bs.hact = None
+            if f8l:
+                bs.q_attn, bs.q_wap = q_attn, q_wap
+                q_attn.q = None  # (the weight gradient contracts the transposed copy only)
+            if f8c:
+                bs.q_xn2, bs.q_wqc, bs.q_wkv, bs.q_catt, bs.q_wcp = q_xn2, q_wqc, q_wkv, q_catt, q_wcp
+                q_catt.q = q_xn2.q = None
+                bs.xn2 = None
         return X3, v, bs
 
 
@@ -429,8 +471,9 @@ class DiTBlock(nn.Module):
         buffer; dc (f32 [B, D]) and dv0 (f32 [B,H,L,hdp]) accumulate the conditioning / residual-V gradients.
         sv carries cos, sin, v0, ctx2d, cvec.  first: this is the block whose v was handed out as v_0."""
         D, H, hd = self.hidden_size, self.num_heads, self.head_dim
-        hdp = {64: 64, 72: 96, 128: 128}[hd]
-        fp8_hist, i, _ = fp8 if fp8 is not None else (None, 0, False)
+        hdp = HDP_OF[hd]
+        fp8_hist, i, _, _, q_ctx = fp8 if fp8 is not None else (None, 0, False, False, None)
+        R0 = F8.ROWS * i
         W = lambda n: G.w(pre + n)
         Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
         Gr = lambda n: G.g(pre + n)
@@ -475,10 +518,23 @@ class DiTBlock(nn.Module):
         dX2 = ops.rmsnorm_mod_bwd(dxn, bs.X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, bs.rstd3, dX, dmod,
                                   Go("norm3.weight"), B, L)
         # --- cross attention
+        def gate_bwd_q(dXo, y, col, row):
+            """the gradient w.r.t. a gated projection's output as an fp8 operand (e5m2, row-major + transposed)"""
+            if pemit:
+                fq, fs = ops.gate_bwd_fp8(dXo, y, mod, col, dmod, None, B, L, F8.E5M2, hist.prev(row), hist.part(row, B * L))
+                return F8.Q.from_rowmajor(fq, fs, True)
+            return F8.Q(ops.gate_bwd(dXo, y, mod, col, dmod, None, B, L), F8.E5M2, True, True, hist, row)
+
         if bs.has_cross:
-            dy = ops.gate_bwd(dX2, bs.y_ca, mod, 5 * D, dmod, None, B, L)
-            ops.linear_wgrad(dy, bs.catt, Gr("cross_proj.weight"))
-            dcatt = ops.linear_dgrad(dy, W("cross_proj.weight"))
+            if bs.f8c:
+                q_dy = gate_bwd_q(dX2, bs.y_ca, 5 * D, R0 + F8.ROW_DY_CP)
+                F8.wgrad(q_dy, bs.q_catt, Gr("cross_proj.weight"))
+                dcatt = F8.dgrad(q_dy, bs.q_wcp)
+                del q_dy
+            else:
+                dy = ops.gate_bwd(dX2, bs.y_ca, mod, 5 * D, dmod, None, B, L)
+                ops.linear_wgrad(dy, bs.catt, Gr("cross_proj.weight"))
+                dcatt = ops.linear_dgrad(dy, W("cross_proj.weight"))
             dqc = torch.empty(B * L, D, dtype=bf16, device=dev)
             dckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
             delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
@@ -486,21 +542,35 @@ class DiTBlock(nn.Module):
                          ops.heads_view(bs.ckv, B, Lc, H, hd, D), ops.heads_view(bs.catt, B, L, H, hd), bs.lse2,
                          ops.heads_view(dcatt, B, L, H, hd), ops.heads_view(dqc, B, L, H, hd),
                          ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), delta)
-            ops.linear_wgrad(dckv, sv.ctx2d, Gr("context_kv.weight"))
             if G.has(pre + "context_kv.bias"):
                 ops.colsum(dckv, Gr("context_kv.bias"))
-            ops.linear_wgrad(dqc, bs.xn2, Gr("q_cross.weight"))
             if G.has(pre + "q_cross.bias"):
                 ops.colsum(dqc, Gr("q_cross.bias"))
-            dxn = ops.linear_dgrad(dqc, W("q_cross.weight"))
+            if bs.f8c:
+                q_dckv = F8.Q(dckv, F8.E5M2, False, True, hist, R0 + F8.ROW_DCKV)
+                F8.wgrad(q_dckv, q_ctx, Gr("context_kv.weight"))
+                q_dqc = F8.Q(dqc, F8.E5M2, True, True, hist, R0 + F8.ROW_DQC)
+                F8.wgrad(q_dqc, bs.q_xn2, Gr("q_cross.weight"))
+                dxn = F8.dgrad(q_dqc, bs.q_wqc)
+                del q_dckv, q_dqc
+            else:
+                ops.linear_wgrad(dckv, sv.ctx2d, Gr("context_kv.weight"))
+                ops.linear_wgrad(dqc, bs.xn2, Gr("q_cross.weight"))
+                dxn = ops.linear_dgrad(dqc, W("q_cross.weight"))
             dX1 = ops.rmsnorm_mod_bwd(dxn, bs.X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, bs.rstd2, dX2, dmod,
                                       Go("norm2.weight"), B, L)
         else:
             dX1 = dX2
         # --- self attention
-        dy = ops.gate_bwd(dX1, bs.y_sa, mod, 2 * D, dmod, None, B, L)
-        ops.linear_wgrad(dy, bs.attn, Gr("attn_proj.weight"))
-        dattn = ops.linear_dgrad(dy, W("attn_proj.weight"))
+        if bs.f8l:
+            q_dy = gate_bwd_q(dX1, bs.y_sa, 2 * D, R0 + F8.ROW_DY_AP)
+            F8.wgrad(q_dy, bs.q_attn, Gr("attn_proj.weight"))
+            dattn = F8.dgrad(q_dy, bs.q_wap)
+            del q_dy
+        else:
+            dy = ops.gate_bwd(dX1, bs.y_sa, mod, 2 * D, dmod, None, B, L)
+            ops.linear_wgrad(dy, bs.attn, Gr("attn_proj.weight"))
+            dattn = ops.linear_dgrad(dy, W("attn_proj.weight"))
         dq = torch.empty(B, H, L, hdp, dtype=bf16, device=dev)
         dk = torch.empty_like(dq)
         dv = torch.empty_like(dq)
@@ -565,8 +635,10 @@ class DiT(nn.Module):
         self.residual_v = residual_v
         self.cross_attn_input_size = cross_attn_input_size
         self.head_dim = hidden_size // num_heads
-        if self.head_dim not in (64, 72, 128):
-            raise ValueError(f"head_dim {self.head_dim} not supported by the attention kernels (64, 72, 128)")
+        if self.head_dim not in HDP_OF:
+            raise ValueError(f"head_dim {self.head_dim} = hidden_size / num_heads has no attention kernel instance "
+                             f"({sorted(HDP_OF)}: DiT-S/B = 64, DiT-XL = 72, the reference's sweep = 128, its smoke "
+                             "test = 32); the kernels are templates on the padded head dim, see csrc/attention.hip")
         self.patch_embed = PatchEmbed(patch_size, in_channels, hidden_size, time_patch_size)
         self.rope = ThreeDimRotary(hidden_size // (2 * num_heads), h=128, w=128, t=128)
         self.register_tokens = nn.Parameter(torch.randn(1, N_REG, hidden_size))
@@ -592,13 +664,15 @@ class DiT(nn.Module):
         self._fsdp = None  # set by fsdp.apply_fsdp
         self.fp8 = False   # enable_fp8(): qkv / mlp GEMMs on the fp8 MFMA path (fp8.py; BASELINE config 5)
         self.fp8_attn = False  # ... and the self-attention products
+        self.fp8_lin = False   # ... and the four remaining linears of a block
 
-    def enable_fp8(self, on: bool = True, attention: bool = True):
+    def enable_fp8(self, on: bool = True, attention: bool = True, all_linears: bool = True):
         """Run the qkv and MLP linears of every block in OCP fp8 (e4m3 activations / weights, e5m2 gradients,
         per-tensor scaling) and, with `attention`, the self-attention products on the fp8 MFMA as well (head_dim 72:
         e4m3 Q / K / V / P, e5m2 dO / dS; fp8.py states the recipe).  The reference has no such mode."""
         self.fp8 = bool(on)
         self.fp8_attn = bool(on and attention)
+        self.fp8_lin = bool(on and all_linears)  # attn_proj, q_cross, context_kv, cross_proj too (qkv / MLP always)
         self._fp8_hist = None  # fp8.AmaxHistory: 6 rows per block (gelu(fc1), d fc2-in, xn1, xn3, d mlp-out, d qkv)
         return self
 
@@ -701,10 +775,16 @@ class DiT(nn.Module):
         sv = _Saved() if save else None
         if self.fp8:
             if getattr(self, "_fp8_hist", None) is None or self._fp8_hist.tab.device != dev:
-                self._fp8_hist = F8.AmaxHistory(F8.ROWS * self.depth, dev)
+                self._fp8_hist = F8.AmaxHistory(F8.ROWS * self.depth + 1, dev)
             if save:
                 self._fp8_hist.ensure_part(B * (t * h * w + N_REG))  # before roll(): see AmaxHistory.ensure_part
                 self._fp8_hist.roll()
+            # the text context is the same operand for every block's context_kv: quantised once per step
+            q_ctx = None
+            if self.fp8_lin and self.cross_attn_input_size is not None and F8.supported(B * Lc, 2 * D, Cc):
+                q_ctx = F8.Q(ctx2d, F8.E4M3, True, save, self._fp8_hist if save else None, F8.ROWS * self.depth)
+            if save:
+                sv.q_ctx = q_ctx
 
         # patch embed + register tokens -> token buffer X [B*L, D]   (model.py:360-362).  ONE GEMM over all B*L rows:
         # the patches are laid out as rows of the token buffer (16 zero rows in front of every sample, whose outputs --
@@ -737,7 +817,7 @@ class DiT(nn.Module):
             if fs is not None:
                 fs.pre_forward_block(i)
             X, v, bs = self.blocks[i]._fwd(self.block_group(i), f"blocks.{i}.", X, ctx2d, cvec, v0, cos, sin, B, L, Lc,
-                                           save, (self._fp8_hist, i, self.fp8_attn) if self.fp8 else None,
+                                           save, (self._fp8_hist, i, self.fp8_attn, self.fp8_lin, q_ctx) if self.fp8 else None,
                                            mods[i] if mods is not None else None)
             if v0 is None:
                 v0 = v
@@ -794,14 +874,14 @@ class DiT(nn.Module):
         dc = torch.zeros(B, D, dtype=f32, device=dev)
         ops.small_linear_bwd(dfmod, sv.cvec, R.w("final_modulation.1.weight"), R.g("final_modulation.1.weight"),
                              R.g("final_modulation.1.bias"), dc, 1)
-        hdp = {64: 64, 72: 96, 128: 128}[hd]
+        hdp = HDP_OF[hd]
         dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev) if (self.residual_v and self.depth > 1) else None
         dmods = torch.zeros(self.depth, B, 9 * D, dtype=f32, device=dev) if sv.batched_adaln else None
         for i in reversed(range(self.depth)):
             if fs is not None:
                 fs.pre_backward_block(i)
             dX = self.blocks[i]._bwd(self.block_group(i), f"blocks.{i}.", sv.blocks[i], dX, sv, dc, dv0, B, L, Lc,
-                                     i == 0, (self._fp8_hist, i, self.fp8_attn) if self.fp8 else None,
+                                     i == 0, (self._fp8_hist, i, self.fp8_attn, self.fp8_lin, sv.q_ctx) if self.fp8 else None,
                                      dmods[i] if dmods is not None else None)
             sv.blocks[i] = None
             if fs is not None:
@@ -890,7 +970,7 @@ class _BlockFunction(torch.autograd.Function):
     def forward(ctx, block, need, x, context, c, v_0, cos, sin, *params):
         B, L, D = x.shape
         H, hd = block.num_heads, block.head_dim
-        hdp = {64: 64, 72: 96, 128: 128}[hd]
+        hdp = HDP_OF[hd]
         dev = x.device
         if (context is None) != (block.q_cross is None):
             raise ValueError("DiTBlock: `context` must be given exactly when the block has cross-attention")

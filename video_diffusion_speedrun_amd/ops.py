@@ -233,7 +233,8 @@ def attn_fp8_supported(hd: int) -> bool:
 def qkv_rope_fwd_fp8(qkv, cos, sin, v0, lam, B, L, H, hd, hdp, amax_prev, amax_cur, amax_stride, deq, want_v=False):
     """qkv_rope_fwd with e4m3 outputs: -> (q8, k8, v8 [B,H,L,128] float8_e4m3fn, v bf16 [B,H,L,hdp] or None).
     amax_prev / amax_cur: f32 views whose elements 0, stride, 2*stride are the q, k, v amax of the previous / this
-    step; deq: f32[4], entries 0..2 receive the dequantisation factors."""
+    step; deq: f32[8], entries 0..2 receive the dequantisation factors, entry 4 the exponent E that ties q's factor
+    to k's (s_q s_k log2(e) / sqrt(hd) = 2^-E: include/vds.h)."""
     dev = qkv.device
     q8 = torch.empty(B, H, L, FP8_ROW, dtype=torch.float8_e4m3fn, device=dev)
     k8 = torch.empty_like(q8)
@@ -248,7 +249,7 @@ def qkv_rope_fwd_fp8(qkv, cos, sin, v0, lam, B, L, H, hd, hdp, amax_prev, amax_c
 def _attn8_args(q8, k8, v8, deq, hd):
     B, H, Lq, row = q8.shape
     assert row == FP8_ROW and q8.is_contiguous() and k8.is_contiguous() and v8.is_contiguous()
-    assert deq.dtype == f32 and deq.numel() >= 4 and deq.is_contiguous()
+    assert deq.dtype == f32 and deq.numel() >= 5 and deq.is_contiguous()
     a = _lib.Attn8Args()
     a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, k8.shape[2], hd
     a.q, a.k, a.v, a.deq = _p(q8), _p(k8), _p(v8), _p(deq)
@@ -281,6 +282,17 @@ def attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dq, dk, dv, hd):
     a.dk, (a.dk_sb, a.dk_sh, a.dk_sl) = _p(dk), _st(dk)
     a.dv, (a.dv_sb, a.dv_sh, a.dv_sl) = _p(dv), _st(dv)
     check(_lib.load().vds_attn_fp8_bwd(C.byref(a), _stream()), f"vds_attn_fp8_bwd(B={a.B},H={a.H},Lq={a.Lq},Lk={a.Lk})")
+
+
+def attn_fp8_qk_factors(amax_q: float, amax_k: float, hd: int):
+    """(alpha_q, alpha_k, E) the fp8 RoPE producer derives from the two amax values: k onto 448, q so that
+    log2(e) / sqrt(hd) / (alpha_q alpha_k) = 2^-E with its amax in (224, 448].  For tests and tools that build fp8
+    operands by hand; the product path gets them from vds_qkv_rope_fwd_fp8."""
+    import math
+    alpha_k = 448.0 / amax_k
+    cl = math.log2(math.e) / math.sqrt(hd)
+    E = math.floor(math.log2(448.0 * alpha_k / (cl * amax_q)))
+    return cl * 2.0 ** E / alpha_k, alpha_k, float(E)
 
 
 def attn_set_variant(mask: int) -> int:
