@@ -19,7 +19,13 @@ optimizer's descriptor tables and the allocator pool the capture then reuses); t
 captures and from then on every call is a replay.  Large configurations are device-bound and gain
 little; launch-bound ones (C1-size models, small batches) gain the most -- DESIGN.md 7e.
 
-Single-GPU (world_size 1) only: the sharded runtime's RCCL collectives are not captured.
+Sharded models (fsdp.ShardRuntime; the reference compiles the FSDP-wrapped model too, train.py:323-329 and
+run_debug.sh:12-25): the capture covers the runtime's whole choreography -- the communication stream forks from the
+capturing stream (`comm.wait_stream(compute)`), the per-group bf16 all-gathers and fp32 reduce-scatters are RCCL calls
+on that stream (RCCL collectives are capturable), the compute stream joins on the per-group events, and the final
+`wait_stream` closes the fork before the capture ends.  Every rank captures and replays the same sequence.  The
+exposed-communication measurement (timing events) is off inside a capture.  Proven on one GPU with the runtime
+forced on over a 1-rank RCCL group (tests/test_model_gpu.py::test_graph_replay_with_the_sharding_runtime).
 """
 from __future__ import annotations
 
@@ -36,8 +42,6 @@ class GraphedTrainStep:
     """`step(batch) -> loss` with the semantics of `train.train_step` (train.py:412-434)."""
 
     def __init__(self, dit_model, optimizer, lr_scheduler, device, eager_steps: int = 2):
-        if getattr(dit_model, "_fsdp", None) is not None:
-            raise RuntimeError("GraphedTrainStep: the sharded (multi-GPU) runtime is not capturable; use the eager step")
         if eager_steps < 1:
             raise ValueError("at least one eager step is needed before the capture (descriptor tables, shadows)")
         self.model, self.opt, self.sched = dit_model, optimizer, lr_scheduler
@@ -81,10 +85,18 @@ class GraphedTrainStep:
 
     def _capture(self):
         step0 = self.opt._step
+        fs = getattr(self.model, "_fsdp", None)
+        measure = fs.measure if fs is not None else False
+        if fs is not None:
+            fs.measure = False  # timing events cannot be recorded into a graph
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
-        with torch.cuda.graph(g):
-            loss = self._body(self.rope_dev)
+        try:
+            with torch.cuda.graph(g):
+                loss = self._body(self.rope_dev)
+        finally:
+            if fs is not None:
+                fs.measure = measure
         self.opt._step = step0  # the capture launched nothing: `advance()` counts the step at replay time
         self.graph, self.loss = g, loss
 
@@ -110,6 +122,10 @@ class GraphedTrainStep:
             from . import ops
             for g in self.model._groups:
                 g.refresh_shadow(ops.cast_f32_bf16)
+            fs = getattr(self.model, "_fsdp", None)
+            if fs is not None:  # the counters a capture cannot bump: one all-gather and one reduce-scatter per group
+                fs.n_all_gather += len(self.model._groups)
+                fs.n_reduce_scatter += len(self.model._groups)
             self.graph.replay()
             self.n_replays += 1
             loss = self.loss.detach()
