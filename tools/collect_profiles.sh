@@ -3,7 +3,7 @@
 #     bash tools/collect_profiles.sh r02        (writes gpurun_out/prof_r02/..., summaries are then copied into profiles/)
 # Counter passes are separate runs (--pmc with --kernel-trace only), as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -27,9 +27,26 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
   B=6 REPS=2 rocprofv3 --kernel-trace --pmc $set -d "$OUT/sq_attn_$i" -o x --output-format csv -- $PY tools/prof_attn.py > "$OUT/sq_attn_$i.log" 2>&1
   rocprofv3 --kernel-trace --pmc $set -d "$OUT/sq_gemm_$i" -o x --output-format csv -- $PY tools/prof_gemm.py > "$OUT/sq_gemm_$i.log" 2>&1
 done
+# 4. (round 3) the fp8 configuration: kernel stats of the C5 bench, HBM bytes (B = 12) and SQ counters (B = 6) of the
+#    fp8 attention kernels
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_c5" -o c5 --output-format csv -- $PY bench.py --workload c5 --steps 3 --warmup 3 --no-cpu-baseline > "$OUT/c5_bench_under_rocprof.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  B=12 REPS=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc8_$c" -o x --output-format csv -- $PY tools/prof_attn_fp8.py > "$OUT/pmc8_$c.log" 2>&1
+done
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
+  i=$((i + 1))
+  B=6 REPS=2 rocprofv3 --kernel-trace --pmc $set -d "$OUT/sq_attn8_$i" -o x --output-format csv -- $PY tools/prof_attn_fp8.py > "$OUT/sq_attn8_$i.log" 2>&1
+done
+$PY tools/pmc_summary.py $(find "$OUT" -path "*pmc8_*" -name "*counter_collection.csv") > "$OUT/attn_fp8_hbm_traffic_pmc.txt" 2>&1
+$PY tools/pmc_summary.py $(find "$OUT" -path "*sq_attn8_*" -name "*counter_collection.csv") > "$OUT/attn_fp8_sq_counters.txt" 2>&1
+find "$OUT/stats_c5" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c5_kernel_stats.csv"
 $PY tools/pmc_summary.py $(find "$OUT" -path "*pmc_*" -name "*counter_collection.csv") > "$OUT/attn_hbm_traffic_pmc.txt" 2>&1
 $PY tools/pmc_summary.py $(find "$OUT" -path "*pmcg_*" -name "*counter_collection.csv") > "$OUT/gemm_hbm_traffic_pmc.txt" 2>&1
 $PY tools/pmc_summary.py $(find "$OUT" -path "*sq_attn_*" -name "*counter_collection.csv") > "$OUT/attn_sq_counters.txt" 2>&1
 $PY tools/pmc_summary.py $(find "$OUT" -path "*sq_gemm_*" -name "*counter_collection.csv") > "$OUT/gemm_sq_counters.txt" 2>&1
-find "$OUT" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c3b_kernel_stats.csv"
+find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c3b_kernel_stats.csv"
 tail -c 600 "$OUT/bench_under_rocprof.log"; echo; cat "$OUT/attn_hbm_traffic_pmc.txt" | head -20

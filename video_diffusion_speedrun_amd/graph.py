@@ -89,6 +89,7 @@ class GraphedTrainStep:
         measure = fs.measure if fs is not None else False
         if fs is not None:
             fs.measure = False  # timing events cannot be recorded into a graph
+            counts = (fs.n_all_gather, fs.n_reduce_scatter)
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         try:
@@ -97,6 +98,7 @@ class GraphedTrainStep:
         finally:
             if fs is not None:
                 fs.measure = measure
+                fs.n_all_gather, fs.n_reduce_scatter = counts  # the capture launched nothing: replays count
         self.opt._step = step0  # the capture launched nothing: `advance()` counts the step at replay time
         self.graph, self.loss = g, loss
 
