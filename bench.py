@@ -444,7 +444,8 @@ def main():
             traffic, traffic_src = None, None
             try:
                 tj = json.load(open(os.path.join(REPO, "profiles", TRAFFIC_JSON)))
-                if tj["workload"] == args.workload and tj["per_gpu_batch"] == B and dominant in tj["kernels"]:
+                # (the file holds the self-attention kernels at the C3b / C5 shape, bf16 and fp8)
+                if args.workload in (tj["workload"], "c5") and tj["per_gpu_batch"] == B and dominant in tj["kernels"]:
                     k = tj["kernels"][dominant]
                     traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
                     traffic_src = f"profiles/{TRAFFIC_JSON}: rocprofv3 PMC pass of {k['symbol']} at commit {tj['commit']}"
