@@ -31,6 +31,7 @@
 // ((r >> 3) & 4): conflict-free for the row reads (16 lanes x 16 B over 256 B) and for the transposing reads
 // (2 x 8 rows x 16 B per 32-lane half); applied to the per-lane SOURCE address of the LDS-DMA.
 #include "common.h"
+#include "rope_stage.h"
 #include <type_traits>
 #include "prof.h"
 #include "../../include/vds.h"
@@ -905,6 +906,122 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_kernel(const bf16_t* qkv
   if ((threadIdx.x & 63) == 0 && amax > *ac) atomicMax(reinterpret_cast<int*>(ac), __float_as_int(amax));
 }
 
+// Token-tile form of the producer above (rope_stage.h): T consecutive tokens per workgroup, qkv rows copied to LDS by
+// LDS-DMA, q / k rotated in place there (bf16, the rounding points of the bf16 kernel), then one lane = one 16-byte
+// chunk of a 128-byte fp8 row: every global access is 16 bytes wide and a (tensor, head) leaves the workgroup as a run
+// of T complete rows.  Same values, scales and recorded amax as the element-wise kernel.
+template <int HD, int HDP, int T>
+__global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_tile_kernel(const bf16_t* qkv, const float* cosb, const float* sinb,
+                                                                    const bf16_t* v0, const bf16_t* lamp,
+                                                                    unsigned char* q8, unsigned char* k8,
+                                                                    unsigned char* v8, bf16_t* v_out,
+                                                                    const float* amax_prev, float* amax_cur,
+                                                                    int amax_stride, float* deq, long ntok, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD, row_b = 6 * D;
+  const long tok0 = (long)blockIdx.x * T;
+  const int nt = (int)min((long)T, ntok - tok0);
+  ropestage::issue_rows(qkv + tok0 * 3 * D, smem, nt, row_b, wave, lane);
+  float alpha[3];
+  {
+    float E;
+    qk_scales(amax_prev, amax_stride, HD, alpha[0], alpha[1], E);
+    const float av = amax_prev[2 * amax_stride];
+    alpha[2] = av > 0.f ? 448.0f / av : 1.0f;
+    if (blockIdx.x == 0 && tid == 0) {
+      deq[0] = 1.0f / alpha[0];
+      deq[1] = 1.0f / alpha[1];
+      deq[2] = 1.0f / alpha[2];
+      deq[4] = E;
+    }
+  }
+  float lam = 0.f, oml = 0.f;
+  if (v0) {
+    lam = bf2f(*lamp);
+    oml = bf2f(f2bf(1.0f - lam));
+  }
+  VDS_WAIT_VM(0);
+  __syncthreads();
+  ropestage::rotate_rows<HD>(smem, cosb, sinb, tok0, nt, L, H, row_b, tid);
+  __syncthreads();
+  const ropestage::Div by_nt((unsigned)nt), by_h((unsigned)H);
+  const int b0 = (int)(tok0 / L), l0 = (int)(tok0 % L);
+  float am[3] = {0.f, 0.f, 0.f};
+  const int nch = nt * 3 * H * 8;
+  for (int u = tid; u < nch; u += 256) {
+    const int c = u & 7;
+    unsigned t, hh;
+    const unsigned r = by_nt.div((unsigned)(u >> 3), t);
+    const unsigned tensor = by_h.div(r, hh);
+    int l = l0 + (int)t, b = b0;
+    if (l >= L) { l -= L; ++b; }
+    const long row = ((long)b * H + hh) * L + l;
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (16 * c < HD) {
+      const char* src = smem + t * row_b + ((tensor * H + hh) * HD + 16 * c) * 2;
+      u32x4 x[2];
+      x[0] = *reinterpret_cast<const u32x4*>(src);
+      x[1] = (16 * c + 8 < HD) ? *reinterpret_cast<const u32x4*>(src + 16) : u32x4{0u, 0u, 0u, 0u};
+      if (tensor == 2 && v0) {
+        const bf16_t* z = v0 + row * HDP + 16 * c;
+        x[0] = ropestage::mix_v(x[0], *reinterpret_cast<const u32x4*>(z), lam, oml);
+        if (16 * c + 8 < HD) x[1] = ropestage::mix_v(x[1], *reinterpret_cast<const u32x4*>(z + 8), lam, oml);
+      }
+      const float a = tensor == 0 ? alpha[0] : tensor == 1 ? alpha[1] : alpha[2];
+      float y[16], m = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[2 * e] = bflo(x[0][e]); y[2 * e + 1] = bfhi(x[0][e]);
+        y[8 + 2 * e] = bflo(x[1][e]); y[8 + 2 * e + 1] = bfhi(x[1][e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        m = fmaxf(m, fabsf(y[e]));
+        y[e] = __builtin_amdgcn_fmed3f(y[e] * a, -448.0f, 448.0f);  // saturating cast
+      }
+      if (tensor == 0) am[0] = fmaxf(am[0], m);
+      else if (tensor == 1) am[1] = fmaxf(am[1], m);
+      else am[2] = fmaxf(am[2], m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = fp8_cvt4<0>(y[4 * e], y[4 * e + 1], y[4 * e + 2], y[4 * e + 3]);
+    }
+    if (tensor == 2 && c == HD / 16) {  // ones column: byte hd of every V row = 1.0 (e4m3 0x38)
+      constexpr int e = HD % 16;
+      w[e >> 2] = (w[e >> 2] & ~(0xffu << (8 * (e & 3)))) | (0x38u << (8 * (e & 3)));
+    }
+    *reinterpret_cast<u32x4*>((tensor == 0 ? q8 : tensor == 1 ? k8 : v8) + row * ROWB + 16 * c) = w;
+  }
+  if (v_out) {  // bf16 v in the padded head-major layout of the bf16 kernels (ones at hd, hd+4 when the pad is >= 8 wide)
+    constexpr int CPR = HDP >> 3, DCH = HD >> 3;
+    constexpr bool ONES = (HDP - HD) >= 8;
+    const int nv = nt * H * CPR;
+    for (int u = tid; u < nv; u += 256) {
+      const int c = u % CPR;
+      unsigned t;
+      const unsigned hh = by_nt.div((unsigned)(u / CPR), t);
+      int l = l0 + (int)t, b = b0;
+      if (l >= L) { l -= L; ++b; }
+      const long dst = (((long)b * H + hh) * L + l) * HDP + 8 * c;
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if (c < DCH) {
+        w = *reinterpret_cast<const u32x4*>(smem + t * row_b + ((2 * H + hh) * HD + 8 * c) * 2);
+        if (v0) w = ropestage::mix_v(w, *reinterpret_cast<const u32x4*>(v0 + dst), lam, oml);
+      } else if (ONES && c == DCH) {
+        w[0] = 0x3f80u; w[2] = 0x3f80u;
+      }
+      *reinterpret_cast<u32x4*>(v_out + dst) = w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float m = wave_max(am[i]);
+    float* ac = amax_cur + i * amax_stride;
+    if (lane == 0 && m > *ac) atomicMax(reinterpret_cast<int*>(ac), __float_as_int(m));
+  }
+}
+
 template <typename K>
 void set_lds(K kern, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1028,6 +1145,32 @@ extern "C" int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const fl
   const long n = (long)B * H * L * 8;
   hipStream_t s = (hipStream_t)stream;
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, s, 0.0, (double)B * L * H * (6.0 * hd + 3.0 * ROWB + (v0 ? 2.0 * hd : 0.0)));
+  // token-tile kernel (rope_stage.h) for the model's head size; VDS_ROPE_TILE=0 keeps the element-wise kernel (A/B)
+  static int tile = -1;
+  if (tile < 0) {
+    const char* e = getenv("VDS_ROPE_TILE");
+    tile = e ? atoi(e) : 4;
+  }
+  if (tile > 0 && hd == 72 && hdp == 96 && H <= 256 && L >= 8) {
+    const long ntok = (long)B * L;
+#define ROPE8_TILE(T)                                                                                               \
+  do {                                                                                                              \
+    static bool attr = false;                                                                                       \
+    if (!attr) {                                                                                                    \
+      set_lds(qkv_rope_fwd_fp8_tile_kernel<72, 96, T>, 160 * 1024);                                                 \
+      attr = true;                                                                                                  \
+    }                                                                                                               \
+    hipLaunchKernelGGL((qkv_rope_fwd_fp8_tile_kernel<72, 96, T>), dim3((unsigned)((ntok + T - 1) / T)), dim3(256),  \
+                       ropestage::lds_bytes(T, H * 72), s, (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0,       \
+                       (const bf16_t*)lam, (unsigned char*)q8, (unsigned char*)k8, (unsigned char*)v8,              \
+                       (bf16_t*)v_out, amax_prev, amax_cur, amax_stride, deq, ntok, L, H);                          \
+    return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;                                               \
+  } while (0)
+    if (tile == 2) ROPE8_TILE(2);
+    else if (tile == 8) ROPE8_TILE(8);
+    else ROPE8_TILE(4);
+#undef ROPE8_TILE
+  }
   hipLaunchKernelGGL(qkv_rope_fwd_fp8_kernel, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, s, (const bf16_t*)qkv,
                      cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (unsigned char*)q8, (unsigned char*)k8,
                      (unsigned char*)v8, (bf16_t*)v_out, amax_prev, amax_cur, amax_stride, deq, B, L, H, hd, hdp);

@@ -5,6 +5,7 @@
 // Reference call sites are cited per kernel (file:line of the reference repo).
 #include <cstdlib>
 #include "common.h"
+#include "rope_stage.h"
 #include "prof.h"
 #include "../../include/vds.h"
 
@@ -424,6 +425,55 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_kernel(const bf16_t* qkv, co
     *reinterpret_cast<u32x2*>(q + pd) = z;
     *reinterpret_cast<u32x2*>(k + pd) = (ones && i == 0) ? one2 : z;
     *reinterpret_cast<u32x2*>(v + pd) = (ones && i < 2) ? one : z;
+  }
+}
+
+// Token-tile form of the kernel above (rope_stage.h): T consecutive tokens per workgroup, qkv rows copied to LDS by
+// LDS-DMA, q / k rotated in place there, every global access 16 bytes wide and every (tensor, head) written as a run of T
+// complete head rows.  Same arithmetic and rounding points.
+template <int HD, int HDP, int T>
+__global__ __launch_bounds__(256) void qkv_rope_fwd_tile_kernel(const bf16_t* qkv, const float* cosb, const float* sinb,
+                                                                const bf16_t* v0, const bf16_t* lamp, bf16_t* q,
+                                                                bf16_t* k, bf16_t* v, long ntok, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD, row_b = 6 * D;
+  const long tok0 = (long)blockIdx.x * T;
+  const int nt = (int)min((long)T, ntok - tok0);
+  ropestage::issue_rows(qkv + tok0 * 3 * D, smem, nt, row_b, wave, lane);
+  float lam = 0.f, oml = 0.f;
+  if (v0) {
+    lam = bf2f(*lamp);
+    oml = bf2f(f2bf(1.0f - lam));
+  }
+  VDS_WAIT_VM(0);
+  __syncthreads();
+  ropestage::rotate_rows<HD>(smem, cosb, sinb, tok0, nt, L, H, row_b, tid);
+  __syncthreads();
+  constexpr int CPR = HDP >> 3, DCH = HD >> 3;
+  constexpr bool ONES = (HDP - HD) >= 8;
+  const ropestage::Div by_nt((unsigned)nt), by_h((unsigned)H);
+  const int b0 = (int)(tok0 / L), l0 = (int)(tok0 % L);
+  const int nch = nt * 3 * H * CPR;
+  for (int u = tid; u < nch; u += 256) {
+    const int c = u % CPR;
+    unsigned t, hh;
+    const unsigned r = by_nt.div((unsigned)(u / CPR), t);
+    const unsigned tensor = by_h.div(r, hh);
+    int l = l0 + (int)t, b = b0;
+    if (l >= L) { l -= L; ++b; }
+    const long dst = (((long)b * H + hh) * L + l) * HDP + 8 * c;
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (c < DCH) {
+      w = *reinterpret_cast<const u32x4*>(smem + t * row_b + ((tensor * H + hh) * HD + 8 * c) * 2);
+      if (tensor == 2 && v0) w = ropestage::mix_v(w, *reinterpret_cast<const u32x4*>(v0 + dst), lam, oml);
+    } else if (ONES && c == DCH) {
+      // K[hd] = K[hd+1] = 1.0, V[hd] = V[hd+4] = 1.0 (see the pad comment of the kernel above)
+      if (tensor == 1) w[0] = 0x3f803f80u;
+      if (tensor == 2) { w[0] = 0x3f80u; w[2] = 0x3f80u; }
+    }
+    *reinterpret_cast<u32x4*>((tensor == 0 ? q : tensor == 1 ? k : v) + dst) = w;
   }
 }
 
@@ -1210,6 +1260,43 @@ extern "C" int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float*
   if (((hdp - hd) >> 2) > (hd >> 3)) return VDS_ERR_UNSUPPORTED;
   const long n = (long)B * L * H * (hd >> 3);
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, (hipStream_t)stream, 0.0, (v0 ? 14.0 : 12.0) * B * L * H * hd);
+  // token-tile kernel (16-byte accesses, LDS staging) for the head sizes the model builds; VDS_ROPE_TILE=0 keeps the
+  // element-wise kernel (A/B), VDS_ROPE_TILE=2|4|8 picks the tokens per workgroup
+  static int tile = -1;
+  if (tile < 0) {
+    const char* e = getenv("VDS_ROPE_TILE");
+    tile = e ? atoi(e) : 4;
+  }
+  if (tile > 0 && H * hd <= 2048 && H <= 256 && L >= 8) {
+    const long ntok = (long)B * L;
+#define ROPE_TILE(HD, HDP, T)                                                                                      \
+  do {                                                                                                             \
+    const int lds = ropestage::lds_bytes(T, H * HD);                                                               \
+    static bool attr = false;                                                                                      \
+    if (!attr) {                                                                                                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_rope_fwd_tile_kernel<HD, HDP, T>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
+      attr = true;                                                                                                 \
+    }                                                                                                              \
+    hipLaunchKernelGGL((qkv_rope_fwd_tile_kernel<HD, HDP, T>), dim3((unsigned)((ntok + T - 1) / T)), dim3(256), lds, \
+                       (hipStream_t)stream, (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam,  \
+                       (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, ntok, L, H);                                             \
+    return ok();                                                                                                   \
+  } while (0)
+#define ROPE_TILE_T(HD, HDP)                       \
+  do {                                             \
+    if (tile == 2) ROPE_TILE(HD, HDP, 2);          \
+    else if (tile == 8) ROPE_TILE(HD, HDP, 8);     \
+    else ROPE_TILE(HD, HDP, 4);                    \
+  } while (0)
+    if (hd == 72 && hdp == 96) ROPE_TILE_T(72, 96);
+    if (hd == 64 && hdp == 64) ROPE_TILE_T(64, 64);
+    if (hd == 128 && hdp == 128) ROPE_TILE_T(128, 128);
+    if (hd == 96 && hdp == 96) ROPE_TILE_T(96, 96);
+    if (hd == 32 && hdp == 32) ROPE_TILE_T(32, 32);
+#undef ROPE_TILE_T
+#undef ROPE_TILE
+  }
   hipLaunchKernelGGL(qkv_rope_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (bf16_t*)q, (bf16_t*)k,
                      (bf16_t*)v, B, L, H, hd, hdp);
