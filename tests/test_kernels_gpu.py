@@ -154,6 +154,37 @@ def test_gemm_nn_dgelu(ops, tile):
     close("dgelu", dx, p.grad, 5e-3)
 
 
+def test_gemm_gelu_table_over_the_bf16_range(ops):
+    """256^2 kernel: gelu / gelu' come from a table indexed by the bf16 bits of the pre-activation (gemm.hip,
+    g_gelu_lut).  With an identity weight the pre-activation IS the input, so every binade from 2^-20 to 2^6, both
+    signs, zero, the clamped ends and interior + ragged tiles are checked against float64 erf math: the result must
+    be the bf16 rounding of the exact value up to the table's stated error (1e-4 of the 0.5 plateau below 2^-13)."""
+    M, N = 600, 256  # 2 full row tiles of 256 + a ragged one
+    g = torch.Generator().manual_seed(5)
+    mag = torch.exp2(torch.rand(M, N, generator=g) * 26.0 - 20.0)
+    x = (mag * (torch.randint(0, 2, (M, N), generator=g) * 2 - 1)).to(bf16)
+    x[0, :8] = torch.tensor([0.0, -0.0, 7.96875, -7.96875, 8.0, -8.0, 100.0, -100.0]).to(bf16)
+    eye = torch.eye(N).to(bf16)
+    xd = x.double()
+    cdf = 0.5 * torch.erfc(-xd / math.sqrt(2.0))
+    pdf = torch.exp(-0.5 * xd * xd) / math.sqrt(2.0 * math.pi)
+    ops.gemm_force_tile(256)
+    try:
+        pre, act = ops.linear_fwd_gelu(x.cuda(), eye.cuda(), None)
+        dx = ops.linear_dgrad(torch.ones(M, N).to(bf16).cuda(), eye.cuda(), x.cuda())
+    finally:
+        ops.gemm_force_tile(0)
+    assert torch.equal(pre.cpu(), x)
+    for name, got, want in (("gelu", act, xd * cdf), ("gelu'", dx, cdf + xd * pdf)):
+        got = got.cpu().double()
+        err = (got - want).abs()
+        tol = want.abs() * 2.0 ** -8 + 1.5e-4 * xd.abs().clamp(max=1.0) + 1e-30  # one bf16 rounding + the table's clamp
+        if name == "gelu'":
+            tol = want.abs() * 2.0 ** -8 + 1.5e-4
+        bad = err > tol
+        assert not bad.any(), (name, int(bad.sum()), x[bad][:4], got[bad][:4], want[bad][:4])
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 384, 1152), (4112, 1152, 384), (8208, 128, 768),
                                    (77, 64, 128)])
 def test_gemm_tn_wgrad(ops, tile, M, N, K):

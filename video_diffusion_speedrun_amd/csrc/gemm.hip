@@ -20,7 +20,10 @@
 #include "common.h"
 #include "prof.h"
 #include "../../include/vds.h"
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -129,6 +132,61 @@ __device__ __forceinline__ i32x8 frag_kc8(const char* tile, int row0, int lane) 
   return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// ---- erf-GELU by table (256^2 kernel) ---------------------------------------------------------------------
+// The argument of gelu / gelu' in the fc1 / fc2-dgrad epilogues is a bf16 number (the stored pre-activation:
+// model.py:84-85 applies nn.GELU to the bf16 output of fc1), so Phi(x) and gelu'(x) = Phi(x) + x phi(x) are functions
+// of 16 bits.  A 4096-entry fp32 table -- sign | 16 binades 2^-13 .. 2^3 | 7 mantissa bits, magnitudes outside clamped
+// to the nearest entry (|error| <= 1e-4 relative to 0.5 below 2^-13, < 1e-15 above 8) -- holds the correctly rounded
+// values; it lives in the 24 KiB of LDS the 256^2 kernel does not use and replaces one v_rcp, one v_exp and ~16 more
+// VALU instructions per element by 4 (two elements share the packed 16-bit index arithmetic) + one ds_read_b32: the
+// epilogues of these two GEMMs were VALU-bound (47 instructions per element in the fp8 dgrad, 26 of its 46 us per
+// tile).
+constexpr int LUT_N = 4096, LUT_BYTES = LUT_N * 4, LUT_E0 = 114;  // exponent field of 2^-13
+__device__ float g_gelu_lut[2][LUT_N];                             // [0] Phi, [1] gelu'
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+
+// table values of the two bf16 numbers in `w`
+// (byte offsets are formed inside the 16-bit halves: magnitude index * 4 <= 8188, sign -> bit 13; the table sits at
+// LDS address 0, so a half IS the ds_read address)
+__device__ __forceinline__ f32x2 lut_pair(const char* lut, unsigned w) {
+  u16x2 m = __builtin_bit_cast(u16x2, w & 0x7fff7fffu);
+  m = __builtin_elementwise_sub_sat(m, u16x2{LUT_E0 << 7, LUT_E0 << 7});
+  m = __builtin_elementwise_min(m, u16x2{2047, 2047});
+  m = m << u16x2{2, 2};
+  const unsigned off = __builtin_bit_cast(unsigned, m) | ((w >> 2) & 0x20002000u);
+  f32x2 t;
+  t[0] = *reinterpret_cast<const float*>(lut + (off & 0xffffu));
+  t[1] = *reinterpret_cast<const float*>(lut + (off >> 16));
+  return t;
+}
+__device__ __forceinline__ f32x2 bf2_to_f2(unsigned w) { return f32x2{bflo(w), bfhi(w)}; }
+__device__ __forceinline__ unsigned f2_to_bf2(f32x2 v) { return pack_bf2(v[0], v[1]); }
+
+// host: fill the table of the current device on first use (double-precision erfc, rounded once to fp32)
+bool ensure_gelu_lut() {
+  static std::mutex mu;
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done[dev]) return true;
+  static float host[2][LUT_N];
+  for (int i = 0; i < LUT_N; ++i) {
+    const unsigned bits = (unsigned)(((i & 2047) + (LUT_E0 << 7)) | ((i >> 11) << 15)) << 16;
+    float xf;
+    memcpy(&xf, &bits, 4);
+    const double x = xf;
+    const double cdf = 0.5 * erfc(-x * 0.70710678118654752440);
+    const double pdf = 0.39894228040143267794 * exp(-0.5 * x * x);
+    host[0][i] = (float)cdf;
+    host[1][i] = (float)(cdf + x * pdf);
+  }
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_gelu_lut), host, sizeof(host)) != hipSuccess) return false;
+  done[dev] = true;
+  return true;
+}
+
 // Shared epilogue: a wave's staged 64x64 fp32 sub-tile (stg, EPI_LD floats per row) -> global memory
 // with the fused elementwise work.  (row0, col0) = global coordinates of the sub-tile.
 __device__ __forceinline__ unsigned cvt4_fp8(int fmt, float a, float b, float c, float d) {
@@ -165,9 +223,10 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmP& p, int row0, int 
   }
 }
 
-template <int EPI, bool EMIT = false>
+template <int EPI, bool EMIT = false, bool LUT = false>
 __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int row0, int col0, int lane,
-                                               float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8]) {
+                                               float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8],
+                                               const char* lut = nullptr) {
   if constexpr (EPI == VDS_EPI_F32) {
     if (p.atomic) {
       // split-K / accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256
@@ -230,7 +289,8 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
       for (int e = 0; e < 4; ++e) {
         float a = v[2 * e] + bias8[2 * e], b = v[2 * e + 1] + bias8[2 * e + 1];
         o[e] = pack_bf2(a, b);
-        o2[e] = pack_bf2(gelu_f(a), gelu_f(b));
+        if constexpr (LUT) o2[e] = f2_to_bf2(bf2_to_f2(o[e]) * lut_pair(lut, o[e]));  // as epilogue_full
+        else o2[e] = pack_bf2(gelu_f(a), gelu_f(b));
       }
       *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
       if (p.C2) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + grow * p.ldc2 + gcol) = o2;
@@ -255,8 +315,10 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
       const u32x4 pr = auxr[it];
       u32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        o[e] = pack_bf2(v[2 * e] * dgelu_f(bflo(pr[e])), v[2 * e + 1] * dgelu_f(bfhi(pr[e])));
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (LUT) o[e] = f2_to_bf2(f32x2{v[2 * e], v[2 * e + 1]} * lut_pair(lut, pr[e]));  // as epilogue_full
+        else o[e] = pack_bf2(v[2 * e] * dgelu_f(bflo(pr[e])), v[2 * e + 1] * dgelu_f(bfhi(pr[e])));
+      }
       if (p.C) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + grow * p.ldc + gcol) = o;
       if constexpr (EMIT) ev = o;
     }
@@ -289,6 +351,147 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
       }
     }
   }
+}
+
+// Epilogue of a 64x64 sub-tile that lies completely inside the matrix (and, GATE_RES, inside one sample): no row /
+// column predicates, row pointers advanced instead of recomputed, pair-wise (v_pk_*) arithmetic, table GELU.  Which
+// outputs exist is a template parameter (C1 / C2: the bf16 results, EQ: fp8 copy + its amax, CS: column sums), so the
+// eight rows are ONE basic block: the LDS reads and table look-ups of the next rows are scheduled under the arithmetic
+// and the stores of the current one (with a branch per output the rows serialise on their LDS latencies).  Same
+// results as epilogue_64x64<.., LUT = true>.  e_max: running |max| of the emitted values (the caller folds it).
+// The bf16 results leave with non-temporal stores: each is 0.2-0.9 GB written once and read by a later kernel from HBM
+// anyway, and keeping it out of the way of the operands in L2 / MALL measured -4.5 ms (bf16) / -6.5 ms (fp8) per step.
+template <int EPI, int EFMT, bool C1, bool C2, bool EQ, bool CS>
+__device__ __forceinline__ void epilogue_full(const GemmP& p, const float* stg, const char* lut, int row0, int col0, int lane,
+                                              float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8], float e_scale,
+                                              float& e_max) {
+  const int c8 = lane & 7, rin = lane >> 3;
+  const int gcol = col0 + c8 * 8;
+  const long grow0 = row0 + rin;
+  f32x2 bias[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bias[e] = f32x2{0.f, 0.f};
+  if constexpr (EPI == VDS_EPI_STORE || EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_GATE_RES) {
+    if (p.bias) {
+      const u32x4 bv = *reinterpret_cast<const u32x4*>(p.bias + gcol);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias[e] = bf2_to_f2(bv[e]);
+    }
+  }
+  [[maybe_unused]] f32x2 g[4];
+  if constexpr (EPI == VDS_EPI_GATE_RES) {
+    const float* gp = p.gate + (long)(row0 / p.rows_per_batch) * p.ldgate + gcol;
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+    g[0] = f32x2{g0[0], g0[1]}; g[1] = f32x2{g0[2], g0[3]}; g[2] = f32x2{g1[0], g1[1]}; g[3] = f32x2{g1[2], g1[3]};
+  }
+  [[maybe_unused]] bf16_t* c1 = reinterpret_cast<bf16_t*>(p.C) + grow0 * p.ldc + gcol;
+  [[maybe_unused]] bf16_t* c2 = reinterpret_cast<bf16_t*>(p.C2) + grow0 * p.ldc2 + gcol;
+  [[maybe_unused]] unsigned char* eq = p.e_q + grow0 * p.e_ldq + gcol;
+  const long s1 = 8 * p.ldc, s2 = 8 * p.ldc2, sq = 8 * p.e_ldq;
+  constexpr float FMAX = EFMT == 0 ? 448.0f : 57344.0f;
+  const float* sp = stg + rin * EPI_LD + c8 * 8;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(sp + it * 8 * EPI_LD);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(sp + it * 8 * EPI_LD + 4);
+    const f32x2 v[4] = {f32x2{lo[0], lo[1]}, f32x2{lo[2], lo[3]}, f32x2{hi[0], hi[1]}, f32x2{hi[2], hi[3]}};
+    [[maybe_unused]] u32x4 ev;
+    if constexpr (EPI == VDS_EPI_STORE) {
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2_to_bf2(v[e] + bias[e]);
+      __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(c1 + it * s1));
+    } else if constexpr (EPI == VDS_EPI_BIAS_GELU) {
+      u32x4 o, o2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = f2_to_bf2(v[e] + bias[e]);
+        o2[e] = f2_to_bf2(bf2_to_f2(o[e]) * lut_pair(lut, o[e]));
+      }
+      if constexpr (C1) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(c1 + it * s1));
+      if constexpr (C2) __builtin_nontemporal_store(o2, reinterpret_cast<u32x4*>(c2 + it * s2));
+      ev = o2;
+    } else if constexpr (EPI == VDS_EPI_GATE_RES) {
+      const u32x4 xr = auxr[it];
+      u32x4 o, o2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 a = v[e] + bias[e];
+        o[e] = f2_to_bf2(a);
+        o2[e] = f2_to_bf2(bf2_to_f2(xr[e]) + a * g[e]);
+      }
+      if constexpr (C1) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(c1 + it * s1));
+      __builtin_nontemporal_store(o2, reinterpret_cast<u32x4*>(c2 + it * s2));
+    } else if constexpr (EPI == VDS_EPI_DGELU) {
+      const u32x4 pr = auxr[it];
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2_to_bf2(v[e] * lut_pair(lut, pr[e]));
+      if constexpr (C1) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(c1 + it * s1));
+      ev = o;
+    }
+    if constexpr (EQ || CS) {
+      f32x2 f[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[e] = bf2_to_f2(ev[e]);
+      if constexpr (CS)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[2 * e] += f[e][0]; cs[2 * e + 1] += f[e][1]; }
+      if constexpr (EQ) {
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          e_max = fmaxf(fmaxf(e_max, fabsf(f[e][0])), fabsf(f[e][1]));
+          const f32x2 sc = f[e] * e_scale;
+          q[2 * e] = __builtin_amdgcn_fmed3f(sc[0], -FMAX, FMAX);
+          q[2 * e + 1] = __builtin_amdgcn_fmed3f(sc[1], -FMAX, FMAX);
+        }
+        const u32x2 w = {fp8_cvt4<EFMT>(q[0], q[1], q[2], q[3]), fp8_cvt4<EFMT>(q[4], q[5], q[6], q[7])};
+        ew[it] = w;
+        *reinterpret_cast<u32x2*>(eq + it * sq) = w;
+      }
+    }
+  }
+}
+
+// picks the specialisation for the outputs this launch has; false = not covered (the caller takes epilogue_64x64)
+template <int EPI, bool EMIT>
+__device__ __forceinline__ bool epilogue_full_dispatch(const GemmP& p, const float* stg, const char* lut, int row0, int col0,
+                                                       int lane, float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8],
+                                                       float e_scale, float& e_max) {
+  const bool c1 = p.C != nullptr, c2 = p.C2 != nullptr;
+  [[maybe_unused]] bool eq = false, eany = false, csum = false;
+  if constexpr (EMIT) {
+    eq = p.e_q != nullptr;
+    eany = p.e_q || p.e_qt;
+    csum = p.e_colsum != nullptr;
+  }
+#define VDS_FULL(E, F, A, B, Q, S) epilogue_full<E, F, A, B, Q, S>(p, stg, lut, row0, col0, lane, cs, ew, auxr, e_scale, e_max)
+  if constexpr (EPI == VDS_EPI_STORE) {
+    VDS_FULL(EPI, 0, true, false, false, false);
+    return true;
+  } else if constexpr (EPI == VDS_EPI_GATE_RES) {
+    if (c1) VDS_FULL(EPI, 0, true, true, false, false);
+    else VDS_FULL(EPI, 0, false, true, false, false);
+    return true;
+  } else if constexpr (EPI == VDS_EPI_BIAS_GELU) {
+    if (c1 && c2 && !eany) { VDS_FULL(EPI, 0, true, true, false, false); return true; }
+    if constexpr (EMIT) {
+      if (c1 && !c2 && eq && !csum && p.e_fmt == 0) { VDS_FULL(EPI, 0, true, false, true, false); return true; }
+    }
+    return false;
+  } else if constexpr (EPI == VDS_EPI_DGELU) {
+    if (c1 && !eany && !csum) { VDS_FULL(EPI, 0, true, false, false, false); return true; }
+    if constexpr (EMIT) {
+      if (c1 && !eany && csum) { VDS_FULL(EPI, 0, true, false, false, true); return true; }
+      if (!c1 && eq && csum && p.e_fmt == 1) { VDS_FULL(EPI, 1, false, false, true, true); return true; }
+      if (!c1 && eq && !csum && p.e_fmt == 1) { VDS_FULL(EPI, 1, false, false, true, false); return true; }
+    }
+    return false;
+  } else {
+    return false;
+  }
+#undef VDS_FULL
 }
 
 template <int LAYOUT, int EPI>
@@ -504,6 +707,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
 
   const srd_t ra = make_srd(p.A, p.a_bytes);
   const srd_t rb = make_srd(p.B, p.b_bytes);
+  constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
+  char* const ring = smem + (USE_LUT ? LUT_BYTES : 0);  // stage ring / epilogue staging area
+  if constexpr (USE_LUT) {
+    // the GELU table (16 KiB) sits at LDS address 0, in front of the ring: two 1-KiB pieces per wave, older than
+    // every operand DMA, so the counted waits of the main loop cover them
+    const srd_t rl = make_srd(g_gelu_lut[EPI == VDS_EPI_DGELU ? 1 : 0], LUT_BYTES);
+    const unsigned lb = lds_addr_of(smem) + wave * 2048;
+    lds_dma16(rl, lb, (unsigned)(wave * 2048 + lane * 16));
+    lds_dma16(rl, lb + 1024, (unsigned)(wave * 2048 + 1024 + lane * 16));
+  }
   unsigned va[2][2], vb[2][2];
   int ca[2][2], cb[2][2];
 #pragma unroll
@@ -518,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   // (= (T - kt_begin) & 1, passed as a compile-time constant so that every LDS address is base + immediate)
   auto issue = [&](int T, int which, int par) {
     const int krem = (T < kt_end) ? p.K - T * BK : 0;
-    char* buf = smem + par * BUF;
+    char* buf = ring + par * BUF;
     if (which == 0) issue_half<A_KM>(ra, buf + SLOT_A0, va[0], ca[0], (unsigned)T * a_step, krem, wave);
     else if (which == 3) issue_half<A_KM>(ra, buf + SLOT_A1, va[1], ca[1], (unsigned)T * a_step, krem, wave);
     else if (which == 1) issue_half<B_KM>(rb, buf + SLOT_B0, vb[0], cb[0], (unsigned)T * b_step, krem, wave);
@@ -579,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   // one K tile = 4 phases; unrolled by two so that the buffer parity is a compile-time constant
   auto k_tile = [&](int T, auto PAR) {
     constexpr int par = decltype(PAR)::value;
-    const char* buf = smem + par * BUF;
+    const char* buf = ring + par * BUF;
     // ---- phase 0: quadrant (0,0) <- A0, B0 ----
     read_a(buf + SLOT_A0);
     read_b(buf + SLOT_B0, fb0);
@@ -621,7 +834,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   __builtin_amdgcn_s_barrier();
 
   // ---- epilogue: two 64-row quadrant rows per wave through the wave's private staging area ----
-  float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
+  float* stg = reinterpret_cast<float*>(ring) + wave * 64 * EPI_LD;
   float dq = 1.0f;
   if constexpr (FMT != 0) dq = (p.sa ? *p.sa : 1.0f) * (p.sb ? *p.sb : 1.0f);
   // EMIT also serves the bf16 DGELU GEMM: no fp8 copies there (e_q / e_qt are null), only the column sums of its
@@ -631,10 +844,19 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   u32x2 ew[2][8];  // EMIT: the fp8 bytes of both quadrant rows (for the transposed copy)
 #pragma unroll
   for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+  [[maybe_unused]] float e_scale = 1.0f, e_max = 0.f;
+  if constexpr (EMIT) {
+    const float fmax = p.e_fmt == 0 ? 448.0f : 57344.0f;
+    const float ain = ((p.e_q || p.e_qt) && p.e_amax_in) ? *p.e_amax_in : 0.f;
+    e_scale = ain > 0.f ? fmax / ain : 1.0f;
+    if ((p.e_q || p.e_qt) && p.e_dq_out && m0 == 0 && n0 == 0 && tid == 0) *p.e_dq_out = ain > 0.f ? ain / fmax : 1.0f;
+  }
+  const char* lut = smem;
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa) {
     u32x4 auxr[8];
-    epilogue_prefetch<EPI>(p, m0 + wr * 128 + qa * 64, n0 + wc * 64, lane, auxr);
+    const int row0 = m0 + wr * 128 + qa * 64, col0 = n0 + wc * 64;
+    epilogue_prefetch<EPI>(p, row0, col0, lane, auxr);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -645,8 +867,22 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
               FMT != 0 ? acc[qa * 4 + i][j][r] * dq : acc[qa * 4 + i][j][r];
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_wave_barrier();
-    epilogue_64x64<EPI, EMIT>(p, stg, m0 + wr * 128 + qa * 64, n0 + wc * 64, lane, cs, ew[qa], auxr);
+    // sub-tiles completely inside the matrix (all but the last row / column of tiles) take the lean path
+    bool full = row0 + 64 <= p.M && col0 + 64 <= p.N;
+    if constexpr (EPI == VDS_EPI_GATE_RES) full = full && (row0 % p.rows_per_batch) + 64 <= p.rows_per_batch;
+    if constexpr (EPI == VDS_EPI_F32) full = false;
+    bool done = false;
+    if (full) done = epilogue_full_dispatch<EPI, EMIT>(p, stg, lut, row0, col0, lane, cs, ew[qa], auxr, e_scale, e_max);
+    if (!done) epilogue_64x64<EPI, EMIT, USE_LUT>(p, stg, row0, col0, lane, cs, ew[qa], auxr, lut);
     __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
+  }
+  if constexpr (EMIT) {
+    if ((p.e_q || p.e_qt) && p.e_amax_out) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) e_max = fmaxf(e_max, __shfl_xor(e_max, o));
+      unsigned* a = reinterpret_cast<unsigned*>(p.e_amax_out);
+      if (lane == 0 && __float_as_uint(e_max) > __atomic_load_n(a, __ATOMIC_RELAXED)) atomicMax(a, __float_as_uint(e_max));
+    }
   }
   if constexpr (EMIT) {
     if (p.e_qt) {
@@ -701,7 +937,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
         for (int e = 0; e < 8; ++e) stg[lane * 8 + e] = cs[e];
       __syncthreads();
       if (wr == 0 && lane < 8) {
-        const float* other = reinterpret_cast<const float*>(smem) + (wave + 4) * 64 * EPI_LD;
+        const float* other = reinterpret_cast<const float*>(ring) + (wave + 4) * 64 * EPI_LD;
         const int gcol = n0 + wc * 64 + lane * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -713,18 +949,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
 
 template <int LAYOUT, int EPI, int FMT = 0>
 int launch(const GemmP& p, hipStream_t s) {
+  constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
+  constexpr int LDS_TOTAL = LDS_BYTES + (USE_LUT ? LUT_BYTES : 0);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI, FMT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     attr_set = true;
+  }
+  if constexpr (USE_LUT) {
+    if (!ensure_gelu_lut()) return VDS_ERR_LAUNCH;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.split_k > 1 ? p.split_k : 1, 1);
   const double k = FMT != 0 ? p.prof_k : (double)p.K;
   vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : LAYOUT == VDS_NN ? VDS_PROF_GEMM_NN
                                                                                                        : VDS_PROF_GEMM_TN,
                     s, 2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
-  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT>), grid, dim3(512), LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT>), grid, dim3(512), LDS_TOTAL, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 }  // namespace big
