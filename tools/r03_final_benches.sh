@@ -15,3 +15,9 @@ python tools/bench_sampler.py > gpurun_out/r03final/sampler.log 2>&1; tail -3 gp
 for f in final_c1_graph_bench c5_without_fp8_attention_bench final_c3b_shard_runtime_w1_bench; do python -c "
 import json
 d=json.loads(open('gpurun_out/r03final/$f.log').read()); print('$f', round(d['value'],3), round(d['ms_per_step'],1))"; done
+for b in 1 2 4; do
+  python bench.py --batch $b --steps 8 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/r03final/c3b_b${b}_bench.log
+  python -c "
+import json
+d=json.loads(open('gpurun_out/r03final/c3b_b${b}_bench.log').read()); print('c3b B=$b', round(d['value'],3), round(d['ms_per_step'],1), round(d['mfma_util_step'],4))"
+done
