@@ -1,7 +1,5 @@
-mkdir -p gpurun_out/r03b
-python -m pytest tests/test_fp8_gpu.py -x -q -m gpu > gpurun_out/r03b/fp8_tests.log 2>&1
-tail -3 gpurun_out/r03b/fp8_tests.log
+python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -x -q -m gpu -k "gemm or linear or emit" 2>&1 | tail -2
 for i in 1 2; do
-echo "== old"; VDS_LIB_PATH=$PWD/video_diffusion_speedrun_amd/libvds_hip_old.so python tools/bench_fp8_producers.py 2>&1 | grep -i "transpose\|quant"
-echo "== new"; python tools/bench_fp8_producers.py 2>&1 | grep -i "transpose\|quant"
+echo "== base"; VDS_LIB_PATH=$PWD/video_diffusion_speedrun_amd/libvds_hip_old.so python tools/bench_gemm_epi.py 2>&1 | grep -v amdgpu
+echo "== pipelined halves"; python tools/bench_gemm_epi.py 2>&1 | grep -v amdgpu
 done
