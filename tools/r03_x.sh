@@ -1,5 +1,4 @@
-python -m pytest tests/test_kernels_gpu.py tests/test_fp8_gpu.py -x -q -m gpu -k "gemm or linear or emit" 2>&1 | tail -2
-for i in 1 2; do
-echo "== base"; VDS_LIB_PATH=$PWD/video_diffusion_speedrun_amd/libvds_hip_old.so python tools/bench_gemm_epi.py 2>&1 | grep -v amdgpu
-echo "== pipelined halves"; python tools/bench_gemm_epi.py 2>&1 | grep -v amdgpu
-done
+mkdir -p gpurun_out/r03b
+python -m pytest tests/test_workloads_gpu.py -x -q -m "gpu and slow" -s > gpurun_out/r03b/slow_depth28_headline.log 2>&1
+tail -15 gpurun_out/r03b/slow_depth28_headline.log
+tail -3 gpurun_out/parity_report.jsonl
