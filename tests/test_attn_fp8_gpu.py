@@ -142,10 +142,11 @@ def test_attn_fp8_backward_vs_fp32_on_dequantised_operands(ops, parity_log, L):
     assert figs["dk_rel"] <= 1.2e-1 and figs["dk_cos"] >= 0.993, figs
 
 
+@pytest.mark.parametrize("L", [200, 203], ids=["L200", "L203_tiles_straddle_samples"])
 @pytest.mark.parametrize("mix", [False, True], ids=["block0", "mixed"])
-def test_qkv_rope_fp8_is_the_bf16_kernel_quantised(ops, mix):
+def test_qkv_rope_fp8_is_the_bf16_kernel_quantised(ops, mix, L):
     dev = torch.device("cuda")
-    B, L, H = 2, 200, 4
+    B, H = 3, 4  # L = 203: 609 tokens -- 4-token tiles cross the sample boundaries and the last tile holds one token
     D = H * HD
     g = torch.Generator().manual_seed(3)
     qkv = torch.randn(B * L, 3 * D, generator=g).to(bf16).to(dev)

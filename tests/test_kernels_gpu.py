@@ -373,6 +373,37 @@ def test_gate_bwd_and_colsum(ops):
 
 
 # ----------------------------------------------------------------- qkv / rope / res-V ----
+@pytest.mark.parametrize("hd,hdp", [(72, 96), (32, 32), (96, 96)])
+def test_qkv_rope_fwd_ragged_token_tiles(ops, hd, hdp):
+    """the forward producer works on tiles of 4 consecutive tokens (csrc/rope_stage.h): L = 25 and B = 3 make tiles
+    straddle the sample boundaries and leave a 3-token last tile; every head size the tile kernel is instantiated for"""
+    B, H, thw = 3, 3, (1, 3, 3)
+    L = thw[0] * thw[1] * thw[2] + 16
+    D = H * hd
+    cos, sin = O.rope_cos_sin(hd, thw, (3, 7, 11))
+    qkv = gen(B * L, 3 * D, seed=75)
+    v0 = gen(B, H, L, hdp, seed=76)
+    v0[..., hd:] = 0
+    lam = torch.tensor([0.37]).to(bf16)
+    q, k, v = O.split_heads(qkv.reshape(B, L, 3 * D), 3, H)
+    qr, kr = O.apply_rotary(q, cos, sin), O.apply_rotary(k, cos, sin)
+    for mix in (False, True):
+        qd, kd, vd = ops.qkv_rope_fwd(qkv.cuda(), cos.cuda(), sin.cuda(), v0.cuda() if mix else None,
+                                      lam.cuda() if mix else None, B, L, H, hd, hdp)
+        close("rope.q", qd[..., :hd], qr, 1e-3)
+        close("rope.k", kd[..., :hd], kr, 1e-3)
+        if mix:
+            close("rope.v", vd[..., :hd], lam * v + (1 - lam) * v0[..., :hd], 4e-3)
+        else:
+            assert torch.equal(vd[..., :hd].cpu(), v.contiguous())
+        if hdp > hd:
+            assert qd[..., hd:].abs().max().item() == 0
+            want_k = torch.zeros(hdp - hd); want_v = torch.zeros(hdp - hd)
+            want_k[0] = 1; want_k[1] = 1; want_v[0] = 1; want_v[4] = 1
+            assert torch.equal(kd[..., hd:].float().cpu(), want_k.expand(B, H, L, -1))
+            assert torch.equal(vd[..., hd:].float().cpu(), want_v.expand(B, H, L, -1))
+
+
 @pytest.mark.parametrize("hd,hdp", [(64, 64), (72, 96), (128, 128)])
 def test_qkv_rope_fwd_bwd(ops, hd, hdp):
     B, H, thw = 2, 2, (2, 4, 5)
