@@ -1024,12 +1024,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
   VDS_WAIT_VM(0);
   __syncthreads();  // tile 0 landed
 
-  auto q_tile = [&](int j, auto PAR) {
+  // NKB: 16-key blocks of this wave that hold keys (2 except in the head's last workgroup, which owns the 16 register
+  // tokens at L = 8208: its other waves only stage and synchronise; see attn_fwd16_kernel)
+  auto q_tile = [&](int j, auto PAR, auto NKBT) {
     constexpr int par = decltype(PAR)::value;
+    constexpr int NKB = decltype(NKBT)::value;
     if (j + 1 < nqt) issue_tile(j + 1, par ^ 1);
     const char* qt = qbuf + par * 2 * Q_TILE;
     const char* dot = qt + Q_TILE;
     const float* stl = reinterpret_cast<const float*>(stats + par * 512);
+    if constexpr (NKB > 0)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x4 s[2][2], dp[2][2];
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
       for (int rb = 0; rb < 2; ++rb) {
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qb * 32 + rb * 16 + 4 * g);  // -delta of rows 4g..
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) { s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[rb][cb] = d4; }
+        for (int cb = 0; cb < NKB; ++cb) { s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[rb][cb] = d4; }
       }
       PRIO_HI();
 #pragma unroll
@@ -1047,7 +1051,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
           const bf16x8 aq = frag16_row<HDP>(qt, qb * 32 + rb * 16, ks, lane);
           const bf16x8 ad = frag16_row<HDP>(dot, qb * 32 + rb * 16, ks, lane);
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
+          for (int cb = 0; cb < NKB; ++cb) {
             s[rb][cb] = mfma16(aq, kf[cb][ks], s[rb][cb]);
             dp[rb][cb] = mfma16(ad, vf[cb][ks], dp[rb][cb]);
           }
@@ -1056,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NKB; ++cb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pr = __builtin_amdgcn_exp2f(s[rb][cb][r]);  // S came out of the MFMA as log2 P
@@ -1065,7 +1069,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
           }
       bf16x8 pf[2], df[2];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < NKB; ++cb) {
         pf[cb] = pack2(s[0][cb], s[1][cb]);
         df[cb] = pack2(dp[0][cb], dp[1][cb]);
       }
@@ -1075,7 +1079,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
         const bf16x8 ado = frag16_tr<HDP>(dot, qb * 32, db * 16, lane);
         const bf16x8 aqt = frag16_tr<HDP>(qt, qb * 32, db * 16, lane);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < NKB; ++cb) {
           dv[db][cb] = mfma16(ado, pf[cb], dv[db][cb]);
           dk[db][cb] = mfma16(aqt, df[cb], dk[db][cb]);
         }
@@ -1085,10 +1089,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
     VDS_WAIT_VM(0);
     __syncthreads();
   };
-  for (int j = 0; j < nqt; j += 2) {
-    q_tile(j, std::integral_constant<int, 0>{});
-    if (j + 1 < nqt) q_tile(j + 1, std::integral_constant<int, 1>{});
-  }
+  auto run = [&](auto NKBT) {
+    for (int j = 0; j < nqt; j += 2) {
+      q_tile(j, std::integral_constant<int, 0>{}, NKBT);
+      if (j + 1 < nqt) q_tile(j + 1, std::integral_constant<int, 1>{}, NKBT);
+    }
+  };
+  const int nkb = min(2, max(0, (p.Lk - key0 + 15) >> 4));  // wave-uniform
+  if (nkb == 2) run(std::integral_constant<int, 2>{});
+  else if (nkb == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int krow = key0 + cb * 16 + (lane & 15);
@@ -1172,8 +1182,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
   VDS_WAIT_VM(0);
   __syncthreads();
 
-  auto kv_tile = [&](int j, auto PAR) {
+  // NCB: query blocks of this wave that hold queries: 4 except in a head's last workgroup (16 of its 256 queries are
+  // real at L = 8208), whose other waves only stage and synchronise -- that workgroup then runs at the pace of the one
+  // wave that has a block instead of occupying a CU slot for the time of a full one.  Invisible at B = 12 (12.4 rounds
+  // of workgroups either way), but at B = 2 the 33rd workgroup of every head opens a third round.
+  auto kv_tile = [&](int j, auto PAR, auto NCBT) {
     constexpr int par = decltype(PAR)::value;
+    constexpr int NCB = decltype(NCBT)::value;
     if (j + 1 < nkt) {
       char* nk = smem + (par ^ 1) * 2 * TILE;
       dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
@@ -1181,13 +1196,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
     }
     const char* kt = smem + par * 2 * TILE;
     const char* vt = kt + TILE;
+    if constexpr (NCB > 0)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x4 s[2][4];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < NCB; ++cb) s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
       PRIO_HI();
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -1195,7 +1211,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
         for (int rb = 0; rb < 2; ++rb) {
           const bf16x8 ak = frag16_row<HDP>(kt, kb * 32 + rb * 16, ks, lane);
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb) s[rb][cb] = mfma16(ak, qf[cb][ks], s[rb][cb]);
+          for (int cb = 0; cb < NCB; ++cb) s[rb][cb] = mfma16(ak, qf[cb][ks], s[rb][cb]);
         }
       PRIO_LO();
       // keys past Lk need no mask: their zero-filled V rows (ones columns included) add nothing to the numerators or
@@ -1203,15 +1219,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
       const bool first = (j == 0) && (kb == 0);
       float mx[4];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
+      for (int cb = 0; cb < NCB; ++cb) {
         mx[cb] = fmaxf(fmaxf(fmaxf(s[0][cb][0], s[0][cb][1]), fmaxf(s[0][cb][2], s[0][cb][3])),
                        fmaxf(fmaxf(s[1][cb][0], s[1][cb][1]), fmaxf(s[1][cb][2], s[1][cb][3])));
       }
-      const float mxa = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+      float mxa = mx[0];
+#pragma unroll
+      for (int cb = 1; cb < NCB; ++cb) mxa = fmaxf(mxa, mx[cb]);
       if (first || __builtin_amdgcn_ballot_w64(mxa > LAZY_THR) != 0) {  // wave-uniform, rare after the first tile
         asm volatile("; rescale" ::: "memory");  // keeps this a real branch (no if-conversion of the O multiplies)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
           const float mxf = max_over_lane_groups(mx[cb]);  // all four lanes of a query agree
           const float m_new = bf2f(f2bf(m[cb] + (first ? mxf : fmaxf(mxf, 0.f))));
           const float delta = m_new - m[cb];
@@ -1228,7 +1246,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
       }
       bf16x8 pf[4];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
+      for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -1240,17 +1258,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
       for (int db = 0; db < NDB; ++db) {
         const bf16x8 av = frag16_tr<HDP>(vt, kb * 32, db * 16, lane);
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) o[db][cb] = mfma16(av, pf[cb], o[db][cb]);
+        for (int cb = 0; cb < NCB; ++cb) o[db][cb] = mfma16(av, pf[cb], o[db][cb]);
       }
       PRIO_LO();
     }
     VDS_WAIT_VM(0);
     __syncthreads();
   };
-  for (int j = 0; j < nkt; j += 2) {
-    kv_tile(j, std::integral_constant<int, 0>{});
-    if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
-  }
+  auto run = [&](auto NCBT) {
+    for (int j = 0; j < nkt; j += 2) {
+      kv_tile(j, std::integral_constant<int, 0>{}, NCBT);
+      if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{}, NCBT);
+    }
+  };
+  const int ncb = min(4, max(0, (p.Lq - (qt * 256 + wave * 64) + 15) >> 4));  // wave-uniform
+  if (ncb > 2) run(std::integral_constant<int, 4>{});
+  else if (ncb == 2) run(std::integral_constant<int, 2>{});
+  else if (ncb == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
 
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
@@ -1342,8 +1367,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
   VDS_WAIT_VM(0);
   __syncthreads();  // tile 0 landed
 
-  auto kv_tile = [&](int j, auto PAR) {
+  // NCB: 16-query blocks of this wave that hold queries (see attn_fwd16_kernel)
+  auto kv_tile = [&](int j, auto PAR, auto NCBT) {
     constexpr int par = decltype(PAR)::value;
+    constexpr int NCB = decltype(NCBT)::value;
     if (j + 1 < nkt) {
       char* nk = smem + (par ^ 1) * 2 * TILE;
       dk.issue(rk, nk, (unsigned)(j + 1) * k_step, wave);
@@ -1352,13 +1379,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
     const char* kt = smem + par * 2 * TILE;
     const char* vt = kt + TILE;
     // keys past Lk need no mask: their K rows are zero-filled, so whatever dS they get multiplies a zero row of K
+    if constexpr (NCB > 0)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x4 s[2][2], dp[2][2];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) { s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int cb = 0; cb < NCB; ++cb) { s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -1366,7 +1394,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
           const bf16x8 ak = frag16_row<HDP>(kt, kb * 32 + rb * 16, ks, lane);
           const bf16x8 av = frag16_row<HDP>(vt, kb * 32 + rb * 16, ks, lane);
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
+          for (int cb = 0; cb < NCB; ++cb) {
             s[rb][cb] = mfma16(ak, qf[cb][ks], s[rb][cb]);
             dp[rb][cb] = mfma16(av, dof[cb][ks], dp[rb][cb]);
           }
@@ -1374,26 +1402,32 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[rb][cb][r] = __builtin_amdgcn_exp2f(s[rb][cb][r]) * dp[rb][cb][r];  // dS^T (unscaled)
       bf16x8 df[2];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) df[cb] = pack2(s[0][cb], s[1][cb]);
+      for (int cb = 0; cb < NCB; ++cb) df[cb] = pack2(s[0][cb], s[1][cb]);
 #pragma unroll
       for (int db = 0; db < NDB; ++db) {
         const bf16x8 akt = frag16_tr<HDP>(kt, kb * 32, db * 16, lane);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) dq[db][cb] = mfma16(akt, df[cb], dq[db][cb]);
+        for (int cb = 0; cb < NCB; ++cb) dq[db][cb] = mfma16(akt, df[cb], dq[db][cb]);
       }
     }
     VDS_WAIT_VM(0);
     __syncthreads();
   };
-  for (int j = 0; j < nkt; j += 2) {
-    kv_tile(j, std::integral_constant<int, 0>{});
-    if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
-  }
+  auto run = [&](auto NCBT) {
+    for (int j = 0; j < nkt; j += 2) {
+      kv_tile(j, std::integral_constant<int, 0>{}, NCBT);
+      if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{}, NCBT);
+    }
+  };
+  const int ncb = min(2, max(0, (p.Lq - (qt * 128 + wave * 32) + 15) >> 4));  // wave-uniform
+  if (ncb == 2) run(std::integral_constant<int, 2>{});
+  else if (ncb == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int qrow = qrow0 + 16 * cb;
