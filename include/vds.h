@@ -425,6 +425,13 @@ int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const float* sinb, 
                          void* q8, void* k8, void* v8, void* v_out, const float* amax_prev, float* amax_cur,
                          int32_t amax_stride, float* deq, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t hdp,
                          vds_stream_t stream);
+/* The operands of cross-attention (model.py:146-157) as fp8 rows for vds_attn_fp8_*: q = the q_cross output
+ * [B*Lq, H*hd] bf16 (contiguous) -> q8 [B,H,Lq,128]; kv = the context_kv output [B*Lk, 2*H*hd] (k columns, then v
+ * columns) -> k8, v8 [B,H,Lk,128] with V's ones byte.  No rotation, no residual-V.  amax_prev / amax_cur / deq as in
+ * vds_qkv_rope_fwd_fp8 (deq[0..2], deq[4]).  head_dim 72. */
+int vds_cross_qkv_fp8(const void* q, const void* kv, void* q8, void* k8, void* v8, const float* amax_prev,
+                      float* amax_cur, int32_t amax_stride, float* deq, int32_t B, int32_t Lq, int32_t Lk, int32_t H,
+                      int32_t hd, vds_stream_t stream);
 
 /* ------------------------------------------------------------------ live profiling ----
  * Per-kernel-class timing with HIP events recorded on the launch stream around each launch of

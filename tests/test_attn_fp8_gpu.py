@@ -43,11 +43,13 @@ def quant_rows(x, fmt, amax_target=None, alpha=None):
     return rows, 1.0 / alpha, q.float() / alpha
 
 
-def make_qkv(B, H, L, seed, dev, spike=None, k_scale=1.0):
+def make_qkv(B, H, L, seed, dev, spike=None, k_scale=1.0, Lk=None):
+    """Lk: number of keys when it differs from the number of queries L (cross-attention)"""
+    Lk = L if Lk is None else Lk
     g = torch.Generator().manual_seed(seed)
     q = torch.randn(B, H, L, HD, generator=g).to(dev)
-    k = (torch.randn(B, H, L, HD, generator=g) * k_scale).to(dev)
-    v = torch.randn(B, H, L, HD, generator=g).to(dev)
+    k = (torch.randn(B, H, Lk, HD, generator=g) * k_scale).to(dev)
+    v = torch.randn(B, H, Lk, HD, generator=g).to(dev)
     if spike is not None:  # one key, late in the sequence, that dominates query 3's softmax: forces the raise-the-maximum path
         k[:, :, spike] = 0.0
         k[:, :, spike, :8] = 3.0
@@ -70,12 +72,13 @@ def ref_attention(qd, kd, vd):
     return torch.softmax(s, dim=-1) @ vd.double(), lse
 
 
-@pytest.mark.parametrize("L,spike,k_scale", [(300, None, 1.0), (1040, None, 1.0), (1040, 900, 1.0), (528, None, 6.0)],
-                         ids=["ragged300", "L1040", "spike", "peaked"])
-def test_attn_fp8_forward_vs_fp32_on_dequantised_operands(ops, parity_log, L, spike, k_scale):
+@pytest.mark.parametrize("L,spike,k_scale,Lk", [(300, None, 1.0, None), (1040, None, 1.0, None), (1040, 900, 1.0, None),
+                                                (528, None, 6.0, None), (1040, None, 1.0, 512), (700, None, 1.0, 300)],
+                         ids=["ragged300", "L1040", "spike", "peaked", "cross_Lq1040_Lk512", "cross_Lq700_Lk300"])
+def test_attn_fp8_forward_vs_fp32_on_dequantised_operands(ops, parity_log, L, spike, k_scale, Lk):
     dev = torch.device("cuda")
     B, H = 2, 3
-    (q8, k8, v8), deq, (qd, kd, vd) = make_qkv(B, H, L, 11, dev, spike, k_scale)
+    (q8, k8, v8), deq, (qd, kd, vd) = make_qkv(B, H, L, 11, dev, spike, k_scale, Lk)
     o = torch.full((B * L, H * HD), float("nan"), dtype=bf16, device=dev)
     lse = torch.empty(B, H, L, dtype=f32, device=dev)
     ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(o, B, L, H, HD), lse, HD)
@@ -85,7 +88,7 @@ def test_attn_fp8_forward_vs_fp32_on_dequantised_operands(ops, parity_log, L, sp
     assert torch.isfinite(got.float()).all()
     e_o, c_o = rel(got, o_ref), cos(got, o_ref)
     e_l = (lse.double() - lse_ref).abs().max().item()
-    parity_log("attn_fp8_fwd", L=L, spike=spike, k_scale=k_scale, o_rel=e_o, o_cos=c_o, lse_abs=e_l)
+    parity_log("attn_fp8_fwd", L=L, Lk=Lk, spike=spike, k_scale=k_scale, o_rel=e_o, o_cos=c_o, lse_abs=e_l)
     # P is rounded to e4m3 (relative step 2^-3, rms error ~3 %) before the PV product and the row sum (measured
     # 3.1e-2 / 0.99952 on the diffuse rows of this test)
     assert e_o <= 5e-2 and c_o >= 0.999, (e_o, c_o)
@@ -95,11 +98,12 @@ def test_attn_fp8_forward_vs_fp32_on_dequantised_operands(ops, parity_log, L, sp
     assert e_l <= (9e-2 if k_scale > 1 or spike is not None else 4e-2), e_l
 
 
-@pytest.mark.parametrize("L", [300, 1040], ids=["ragged300", "L1040"])
-def test_attn_fp8_backward_vs_fp32_on_dequantised_operands(ops, parity_log, L):
+@pytest.mark.parametrize("L,Lk", [(300, None), (1040, None), (1040, 512), (700, 300)],
+                         ids=["ragged300", "L1040", "cross_Lq1040_Lk512", "cross_Lq700_Lk300"])
+def test_attn_fp8_backward_vs_fp32_on_dequantised_operands(ops, parity_log, L, Lk):
     dev = torch.device("cuda")
     B, H = 2, 3
-    (q8, k8, v8), deq, (qd, kd, vd) = make_qkv(B, H, L, 12, dev)
+    (q8, k8, v8), deq, (qd, kd, vd) = make_qkv(B, H, L, 12, dev, Lk=Lk)
     o = torch.empty(B * L, H * HD, dtype=bf16, device=dev)
     lse = torch.empty(B, H, L, dtype=f32, device=dev)
     ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(o, B, L, H, HD), lse, HD)
@@ -110,7 +114,8 @@ def test_attn_fp8_backward_vs_fp32_on_dequantised_operands(ops, parity_log, L):
     amax_cur = torch.zeros(1, dtype=f32, device=dev)
     stats = ops.attn_fp8_delta(o, do, lse, doq, amax_prev, amax_cur, deq, B, H, L, HD)
     dq = torch.full((B, H, L, HDP), float("nan"), dtype=bf16, device=dev)
-    dk, dv = torch.full_like(dq, float("nan")), torch.full_like(dq, float("nan"))
+    dk = torch.full((B, H, k8.shape[2], HDP), float("nan"), dtype=bf16, device=dev)
+    dv = torch.full_like(dk, float("nan"))
     ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dq[..., :HD], dk[..., :HD], dv[..., :HD], HD)
     torch.cuda.synchronize()
     # the preprocess: dO as e5m2 scaled to 2^-4, bit-identical to torch's cast; amax recorded; statistics
@@ -135,7 +140,7 @@ def test_attn_fp8_backward_vs_fp32_on_dequantised_operands(ops, parity_log, L):
         got = got[..., :HD]
         assert torch.isfinite(got.float()).all(), name
         figs[name + "_rel"], figs[name + "_cos"] = rel(got, ref), cos(got, ref)
-    parity_log("attn_fp8_bwd", L=L, **figs)
+    parity_log("attn_fp8_bwd", L=L, Lk=Lk, **figs)
     # P in e4m3 (dV), dS in e5m2 (relative step 2^-2: dQ, dK); errors are independent across the contraction
     assert figs["dv_rel"] <= 4e-2 and figs["dv_cos"] >= 0.999, figs
     assert figs["dq_rel"] <= 1.2e-1 and figs["dq_cos"] >= 0.993, figs
@@ -184,6 +189,40 @@ def test_qkv_rope_fp8_is_the_bf16_kernel_quantised(ops, mix, L):
             assert int(pad.max()) == 0
         assert abs(hist[i, 1].item() / hist[i, 0].item() - 1.0) <= 1e-2  # the recorded amax is this tensor's
     assert torch.equal(vb.view(torch.int16), v.view(torch.int16))
+
+
+def test_cross_qkv_fp8_rows_are_the_operands_quantised(ops):
+    """vds_cross_qkv_fp8: the q_cross / context_kv outputs become the fp8 rows of the attention kernels with the
+    self-attention producer's scales (k and v onto 448, q's factor tied to k's), ones byte in V, amax recorded; ragged
+    token counts (tiles of 4 tokens straddle samples)"""
+    dev = torch.device("cuda")
+    B, Lq, Lk, H = 3, 203, 77, 4
+    D = H * HD
+    g = torch.Generator().manual_seed(8)
+    qc = torch.randn(B * Lq, D, generator=g).to(bf16).to(dev)
+    ckv = (torch.randn(B * Lk, 2 * D, generator=g) * 1.7).to(bf16).to(dev)
+    heads = lambda t, L, off: t[:, off:off + D].view(B, L, H, HD).permute(0, 2, 1, 3)
+    q, k, v = heads(qc, Lq, 0), heads(ckv, Lk, 0), heads(ckv, Lk, D)
+    hist = torch.zeros(3, 2, dtype=f32, device=dev)
+    for i, t in enumerate((q, k, v)):
+        hist[i, 0] = t.float().abs().max()
+    deq = torch.zeros(8, dtype=f32, device=dev)
+    q8, k8, v8 = ops.cross_qkv_fp8(qc, ckv, B, Lq, Lk, H, HD, hist[:, 0], hist[:, 1], 2, deq)
+    torch.cuda.synchronize()
+    aq, ak, E = ops.attn_fp8_qk_factors(hist[0, 0].item(), hist[1, 0].item(), HD)
+    assert deq[4].item() == E
+    for i, (t8, t) in enumerate(((q8, q), (k8, k), (v8, v))):
+        alpha = (aq, ak, 448.0 / hist[2, 0].item())[i]
+        assert abs(deq[i].item() * alpha - 1.0) <= 1e-5
+        want = (t.float() * alpha).to(E4).view(torch.uint8)
+        got = t8.view(torch.uint8)
+        assert torch.equal(got[..., :HD], want), i
+        pad = got[..., HD:]
+        if i == 2:
+            assert int(pad[..., 0].min()) == 0x38 and int(pad[..., 0].max()) == 0x38 and int(pad[..., 1:].max()) == 0
+        else:
+            assert int(pad.max()) == 0
+        assert hist[i, 1].item() == hist[i, 0].item()  # the recorded amax is this tensor's
 
 
 def test_fp8_attention_step_close_to_oracle(parity_log):

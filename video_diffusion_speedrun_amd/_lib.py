@@ -142,6 +142,7 @@ SIGNATURES = {
     "vds_attn_fp8_bwd": [C.POINTER(Attn8Args), c_vp],
     "vds_qkv_rope_fwd_fp8": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
                              c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_cross_qkv_fp8": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_selftest_lanemaps": [c_vp, c_vp],
     "vds_prof_enable": [C.c_uint32],
     "vds_prof_collect": [c_vp],

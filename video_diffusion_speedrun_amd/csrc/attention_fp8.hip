@@ -910,20 +910,24 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_kernel(const bf16_t* qkv
 // LDS-DMA, q / k rotated in place there (bf16, the rounding points of the bf16 kernel), then one lane = one 16-byte
 // chunk of a 128-byte fp8 row: every global access is 16 bytes wide and a (tensor, head) leaves the workgroup as a run
 // of T complete rows.  Same values, scales and recorded amax as the element-wise kernel.
-template <int HD, int HDP, int T>
+// NT / ROPE / tid0: the rows hold NT tensors side by side ([tokens, NT * D]), the first of which is tensor tid0 of
+// (q, k, v) -- NT = 3, ROPE: the self-attention qkv rows; NT = 1, tid0 = 0 and NT = 2, tid0 = 1 without rotation: the
+// q_cross and context_kv outputs of cross-attention (model.py:147-155), which become fp8 rows the same way.
+template <int HD, int HDP, int T, int NT = 3, bool ROPE = true>
 __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_tile_kernel(const bf16_t* qkv, const float* cosb, const float* sinb,
                                                                     const bf16_t* v0, const bf16_t* lamp,
                                                                     unsigned char* q8, unsigned char* k8,
                                                                     unsigned char* v8, bf16_t* v_out,
                                                                     const float* amax_prev, float* amax_cur,
-                                                                    int amax_stride, float* deq, long ntok, int L, int H) {
+                                                                    int amax_stride, float* deq, long ntok, int L, int H,
+                                                                    int tid0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int D = H * HD, row_b = 6 * D;
+  const int D = H * HD, row_b = 2 * NT * D;
   const long tok0 = (long)blockIdx.x * T;
   const int nt = (int)min((long)T, ntok - tok0);
-  ropestage::issue_rows(qkv + tok0 * 3 * D, smem, nt, row_b, wave, lane);
+  ropestage::issue_rows(qkv + tok0 * NT * D, smem, nt, row_b, wave, lane);
   float alpha[3];
   {
     float E;
@@ -931,10 +935,9 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_tile_kernel(const bf16_t
     const float av = amax_prev[2 * amax_stride];
     alpha[2] = av > 0.f ? 448.0f / av : 1.0f;
     if (blockIdx.x == 0 && tid == 0) {
-      deq[0] = 1.0f / alpha[0];
-      deq[1] = 1.0f / alpha[1];
-      deq[2] = 1.0f / alpha[2];
-      deq[4] = E;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) deq[tid0 + i] = 1.0f / (tid0 + i == 0 ? alpha[0] : tid0 + i == 1 ? alpha[1] : alpha[2]);
+      if (tid0 == 0) deq[4] = E;
     }
   }
   float lam = 0.f, oml = 0.f;
@@ -944,23 +947,26 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_tile_kernel(const bf16_t
   }
   VDS_WAIT_VM(0);
   __syncthreads();
-  ropestage::rotate_rows<HD>(smem, cosb, sinb, tok0, nt, L, H, row_b, tid);
-  __syncthreads();
+  if constexpr (ROPE) {
+    ropestage::rotate_rows<HD>(smem, cosb, sinb, tok0, nt, L, H, row_b, tid);
+    __syncthreads();
+  }
   const ropestage::Div by_nt((unsigned)nt), by_h((unsigned)H);
   const int b0 = (int)(tok0 / L), l0 = (int)(tok0 % L);
   float am[3] = {0.f, 0.f, 0.f};
-  const int nch = nt * 3 * H * 8;
+  const int nch = nt * NT * H * 8;
   for (int u = tid; u < nch; u += 256) {
     const int c = u & 7;
     unsigned t, hh;
     const unsigned r = by_nt.div((unsigned)(u >> 3), t);
-    const unsigned tensor = by_h.div(r, hh);
+    const unsigned tl = by_h.div(r, hh);        // tensor index inside the row
+    const unsigned tensor = (unsigned)tid0 + tl;  // ... and among (q, k, v)
     int l = l0 + (int)t, b = b0;
     if (l >= L) { l -= L; ++b; }
     const long row = ((long)b * H + hh) * L + l;
     u32x4 w = {0u, 0u, 0u, 0u};
     if (16 * c < HD) {
-      const char* src = smem + t * row_b + ((tensor * H + hh) * HD + 16 * c) * 2;
+      const char* src = smem + t * row_b + ((tl * H + hh) * HD + 16 * c) * 2;
       u32x4 x[2];
       x[0] = *reinterpret_cast<const u32x4*>(src);
       x[1] = (16 * c + 8 < HD) ? *reinterpret_cast<const u32x4*>(src + 16) : u32x4{0u, 0u, 0u, 0u};
@@ -1016,6 +1022,7 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_tile_kernel(const bf16_t
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
+    if (i < tid0 || i >= tid0 + NT) continue;
     const float m = wave_max(am[i]);
     float* ac = amax_cur + i * amax_stride;
     if (lane == 0 && m > *ac) atomicMax(reinterpret_cast<int*>(ac), __float_as_int(m));
@@ -1163,7 +1170,7 @@ extern "C" int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const fl
     hipLaunchKernelGGL((qkv_rope_fwd_fp8_tile_kernel<72, 96, T>), dim3((unsigned)((ntok + T - 1) / T)), dim3(256),  \
                        ropestage::lds_bytes(T, H * 72), s, (const bf16_t*)qkv, cosb, sinb, (const bf16_t*)v0,       \
                        (const bf16_t*)lam, (unsigned char*)q8, (unsigned char*)k8, (unsigned char*)v8,              \
-                       (bf16_t*)v_out, amax_prev, amax_cur, amax_stride, deq, ntok, L, H);                          \
+                       (bf16_t*)v_out, amax_prev, amax_cur, amax_stride, deq, ntok, L, H, 0);                       \
     return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;                                               \
   } while (0)
     if (tile == 2) ROPE8_TILE(2);
@@ -1174,5 +1181,36 @@ extern "C" int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const fl
   hipLaunchKernelGGL(qkv_rope_fwd_fp8_kernel, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, s, (const bf16_t*)qkv,
                      cosb, sinb, (const bf16_t*)v0, (const bf16_t*)lam, (unsigned char*)q8, (unsigned char*)k8,
                      (unsigned char*)v8, (bf16_t*)v_out, amax_prev, amax_cur, amax_stride, deq, B, L, H, hd, hdp);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+// cross-attention operands as fp8 rows (no rotation, no residual-V): q [B*Lq, H*hd] (the q_cross output, model.py:147)
+// -> q8 [B,H,Lq,128]; kv [B*Lk, 2*H*hd] (the context_kv output, model.py:149-155: k columns, then v columns) -> k8, v8
+// [B,H,Lk,128].  Scales, amax slots and deq entries as vds_qkv_rope_fwd_fp8 (q's factor tied to k's).  Both inputs
+// contiguous; head_dim 72.
+extern "C" int vds_cross_qkv_fp8(const void* q, const void* kv, void* q8, void* k8, void* v8, const float* amax_prev,
+                                 float* amax_cur, int32_t amax_stride, float* deq, int32_t B, int32_t Lq, int32_t Lk,
+                                 int32_t H, int32_t hd, vds_stream_t stream) {
+  if (!q || !kv || !q8 || !k8 || !v8 || !amax_prev || !amax_cur || !deq || B < 1 || Lq < 1 || Lk < 1 || H < 1) return VDS_ERR_ARG;
+  if (hd != 72 || H > 256) return VDS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int T = 4;
+  static bool attr = false;
+  if (!attr) {
+    set_lds(qkv_rope_fwd_fp8_tile_kernel<72, 96, T, 1, false>, 160 * 1024);
+    set_lds(qkv_rope_fwd_fp8_tile_kernel<72, 96, T, 2, false>, 160 * 1024);
+    attr = true;
+  }
+  vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, s, 0.0, (double)B * H * ((double)Lq + 2.0 * Lk) * (2.0 * hd + ROWB));
+  const int D = H * 72;
+  const long nq = (long)B * Lq, nk = (long)B * Lk;
+  hipLaunchKernelGGL((qkv_rope_fwd_fp8_tile_kernel<72, 96, T, 1, false>), dim3((unsigned)((nq + T - 1) / T)), dim3(256),
+                     (T * 2 * D + 1023) / 1024 * 1024, s, (const bf16_t*)q, (const float*)nullptr, (const float*)nullptr,
+                     (const bf16_t*)nullptr, (const bf16_t*)nullptr, (unsigned char*)q8, (unsigned char*)k8,
+                     (unsigned char*)v8, (bf16_t*)nullptr, amax_prev, amax_cur, amax_stride, deq, nq, Lq, H, 0);
+  hipLaunchKernelGGL((qkv_rope_fwd_fp8_tile_kernel<72, 96, T, 2, false>), dim3((unsigned)((nk + T - 1) / T)), dim3(256),
+                     (T * 4 * D + 1023) / 1024 * 1024, s, (const bf16_t*)kv, (const float*)nullptr, (const float*)nullptr,
+                     (const bf16_t*)nullptr, (const bf16_t*)nullptr, (unsigned char*)q8, (unsigned char*)k8,
+                     (unsigned char*)v8, (bf16_t*)nullptr, amax_prev, amax_cur, amax_stride, deq, nk, Lk, H, 1);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }

@@ -246,6 +246,19 @@ def qkv_rope_fwd_fp8(qkv, cos, sin, v0, lam, B, L, H, hd, hdp, amax_prev, amax_c
     return q8, k8, v8, v
 
 
+def cross_qkv_fp8(qc, ckv, B, Lq, Lk, H, hd, amax_prev, amax_cur, amax_stride, deq):
+    """the cross-attention operands as fp8 rows: qc [B*Lq, H*hd] (q_cross output), ckv [B*Lk, 2*H*hd] (context_kv output:
+    k columns, then v columns) -> (q8 [B,H,Lq,128], k8, v8 [B,H,Lk,128]) e4m3; amax / deq as qkv_rope_fwd_fp8"""
+    dev = qc.device
+    assert qc.is_contiguous() and ckv.is_contiguous() and qc.shape == (B * Lq, H * hd) and ckv.shape == (B * Lk, 2 * H * hd)
+    q8 = torch.empty(B, H, Lq, FP8_ROW, dtype=torch.float8_e4m3fn, device=dev)
+    k8 = torch.empty(B, H, Lk, FP8_ROW, dtype=torch.float8_e4m3fn, device=dev)
+    v8 = torch.empty_like(k8)
+    check(_lib.load().vds_cross_qkv_fp8(_p(qc), _p(ckv), _p(q8), _p(k8), _p(v8), _p(amax_prev), _p(amax_cur), amax_stride,
+                                        _p(deq), B, Lq, Lk, H, hd, _stream()), "vds_cross_qkv_fp8")
+    return q8, k8, v8
+
+
 def _attn8_args(q8, k8, v8, deq, hd):
     B, H, Lq, row = q8.shape
     assert row == FP8_ROW and q8.is_contiguous() and k8.is_contiguous() and v8.is_contiguous()
