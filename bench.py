@@ -84,10 +84,11 @@ WORKLOADS = {
     # BASELINE.json configs[3]
     "c4": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=1), (16, 33, 64, 64), 2,
            "C4 DiT-XL/2 bf16, latents [16,33,64,64] pt=1 -> 33792+16 tokens, ctx [512,4096]"),
-    # BASELINE.json configs[4]: the C3b shapes with the qkv / MLP GEMMs on the fp8 MFMA path (fp8.py)
+    # BASELINE.json configs[4]: the C3b shapes with every linear of the blocks and the attention products on the fp8 MFMA
+    # path (fp8.py)
     "c5": (dict(hidden_size=1152, depth=28, num_heads=16, time_patch_size=2), (16, 16, 64, 64), 12,
-           "C5 DiT-XL/2 fp8 (e4m3 activations/weights/P, e5m2 gradients: qkv + MLP GEMMs and the self-attention "
-           "products on the fp8 MFMA; cross-attention, 1152^2 projections, norms, optimizer bf16/fp32), "
+           "C5 DiT-XL/2 fp8 (e4m3 activations/weights/P, e5m2 gradients: all seven linears of a block and the self- and "
+           "cross-attention products on the fp8 MFMA; norms, residual stream, loss, optimizer bf16/fp32), "
            "latents [16,16,64,64] pt=2 -> 8192+16 tokens, ctx [512,4096]"),
     # BASELINE.json configs[0] shape, on the GPU
     "c1": (dict(hidden_size=384, depth=12, num_heads=6, time_patch_size=2), (16, 8, 16, 16), 4,
@@ -265,6 +266,8 @@ def main():
                     help="time only the step's collectives (one bf16 all-gather + one fp32 reduce-scatter-average per "
                          "shard group) on the communication stream, under both reduce-scatter schedules; no compute")
     ap.add_argument("--no-fp8-attention", action="store_true", help="c5: keep the attention products in bf16")
+    ap.add_argument("--no-fp8-cross-attention", action="store_true",
+                    help="c5: keep the cross-attention products in bf16 (fp8 self-attention only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -292,7 +295,7 @@ def main():
 
     model = build_model(kw, device, seed=1234)  # same init on every rank
     if args.workload == "c5":
-        model.enable_fp8(attention=not args.no_fp8_attention)
+        model.enable_fp8(attention=not args.no_fp8_attention, cross_attention=not args.no_fp8_cross_attention)
     if world > 1:
         model = apply_fsdp(model, torch.bfloat16, torch.float32)
         model._fsdp.measure = True

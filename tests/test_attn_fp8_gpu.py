@@ -225,8 +225,10 @@ def test_cross_qkv_fp8_rows_are_the_operands_quantised(ops):
         assert hist[i, 1].item() == hist[i, 0].item()  # the recorded amax is this tensor's
 
 
-def test_fp8_attention_step_close_to_oracle(parity_log):
-    """DiT.enable_fp8() with the self-attention products on the fp8 MFMA (head_dim 72): one pass records the amax
+@pytest.mark.parametrize("cross", [False, True], ids=["self", "self_and_cross"])
+def test_fp8_attention_step_close_to_oracle(parity_log, cross):
+    """(cross: with / without the cross-attention products on the same kernels, Lk = 16 context keys)
+    DiT.enable_fp8() with the self-attention products on the fp8 MFMA (head_dim 72): one pass records the amax
     history (bf16 attention kernels), the second pass over the same inputs quantises q / k / v / dO with it and runs
     the fp8 kernels (asserted by launch count).  Against the fp32 CPU oracle of the same step -- stated tolerance:
     output within 2.5e-2 relative, loss within 1e-2, every parameter gradient cosine >= 0.98 and relative error
@@ -252,7 +254,7 @@ def test_fp8_attention_step_close_to_oracle(parity_log):
     m = M.DiT(in_channels=16, hidden_size=288, depth=3, num_heads=4, cross_attn_input_size=64, residual_v=True,
               train_bias_and_rms=False)
     m.load_state_dict(P, strict=True)
-    m = m.to("cuda").enable_fp8()
+    m = m.to("cuda").enable_fp8(cross_attention=cross)
     for it in range(2):
         m.zero_grad()
         ops.prof_enable()
@@ -262,7 +264,9 @@ def test_fp8_attention_step_close_to_oracle(parity_log):
         stats = ops.prof_collect()
         ops.prof_enable(0)
         n8 = sum(stats.get(k, {"launches": 0})["launches"] for k in ("attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq"))
-        assert n8 == (0 if it == 0 else 3 * cfg.depth), (it, stats.keys())
+        assert n8 == (0 if it == 0 else (6 if cross else 3) * cfg.depth), (it, stats.keys())  # 3 kernels per attention
+        if it == 1:  # the armed step: no bf16 cross-attention launch when it runs in fp8, three per block otherwise
+            assert ("attn_fwd_plain" in stats) == (not cross)
     assert m._fp8_hist.ready
 
     def rel_(a, b):
@@ -278,6 +282,6 @@ def test_fp8_attention_step_close_to_oracle(parity_log):
             worst_c = (c, k)
         if e > worst_e[0]:
             worst_e = (e, k)
-    parity_log("fp8_attention_step", out_rel=e_out, loss_rel=e_loss, worst_cos=worst_c, worst_rel=worst_e)
+    parity_log("fp8_attention_step" + ("_cross" if cross else ""), out_rel=e_out, loss_rel=e_loss, worst_cos=worst_c, worst_rel=worst_e)
     assert e_out <= 2.5e-2 and e_loss <= 1e-2, (e_out, e_loss)
     assert worst_c[0] >= 0.98 and worst_e[0] <= 0.2, (worst_c, worst_e)

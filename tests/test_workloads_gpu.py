@@ -85,7 +85,7 @@ def oracle_step(cfg, P, x, ctx, t, v, start):
 
 SUBLAYERS = ("q_rope", "k_rope", "attn", "y_sa", "cattn", "y_ca", "y_mlp")
 # rel-L2 of a bf16 sub-layer output against the fp32 oracle (measured worst: see parity_report.jsonl, "sublayers")
-SUB_REL, FP8_SUB_REL = 1.5e-2, 6e-2
+SUB_REL, FP8_SUB_REL = 1.5e-2, 1.2e-1  # fp8: measured <= 6.0e-2 (cross_proj output; cross-attention itself 4.6e-2)
 
 
 def sublayer_errors(m, out, subs, B, L):
@@ -219,9 +219,10 @@ def test_headline_shape_block_vs_oracle(vds, headline, parity_log, fp8):
         stats = vds["ops"].prof_collect()
         vds["ops"].prof_enable(0)
         assert stats["gemm_fp8"]["launches"] == 20  # the 7 linears of the block x (fwd, dgrad, wgrad); context_kv has no dgrad
-        # ... and so did the three self-attention kernels; no bf16 self-attention launch is left
-        assert [stats[k]["launches"] for k in ("attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq")] == [1, 1, 1]
-        assert "attn_fwd" not in stats and "attn_bwd_dkv" not in stats and "attn_bwd_dq" not in stats
+        # ... and so did the three attention kernels of the self- AND the cross-attention; no bf16 attention launch is left
+        assert [stats[k]["launches"] for k in ("attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq")] == [2, 2, 2]
+        assert not any(k in stats for k in ("attn_fwd", "attn_bwd_dkv", "attn_bwd_dq", "attn_fwd_plain",
+                                            "attn_bwd_dkv_plain", "attn_bwd_dq_plain"))
     parity_log("headline_block_" + ("c5_fp8" if fp8 else "c3b_bf16"), **fig)
 
 

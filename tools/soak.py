@@ -13,10 +13,11 @@ B = int(os.environ.get("B", 4))
 kw, latent_shape, _, desc = bench.WORKLOADS[wl]
 dev = torch.device("cuda", 0)
 out = {"workload": desc, "per_gpu_batch": B, "steps": steps, "runs": {}}
-for mode in ("bf16", "fp8"):
+MODES = os.environ.get("MODES", "bf16,fp8").split(",")  # fp8x = fp8 with the cross-attention products in fp8 too
+for mode in MODES:
     model = bench.build_model(kw, dev, seed=1234)
-    if mode == "fp8":
-        model.enable_fp8()
+    if mode.startswith("fp8"):
+        model.enable_fp8(cross_attention=(mode == "fp8x"))
     groups, _ = model.get_mup_setup(float(os.environ.get("LR", 3e-4)), 0.1, ["patch_proj", "context_kv", "positional_embedding"])
     opt = MuAdamW(groups, betas=(0.95, 0.99))
     sched = get_schedule(opt, "cosine", 10, steps)
@@ -34,6 +35,7 @@ for mode in ("bf16", "fp8"):
                          "every10": [round(sum(losses[i:i + 10]) / 10, 4) for i in range(0, steps, 10)]}
     del model, opt
     torch.cuda.empty_cache()
-a, b = out["runs"]["bf16"]["every10"], out["runs"]["fp8"]["every10"]
-out["max_rel_gap_of_10step_means"] = max(abs(x - y) / x for x, y in zip(a, b))
+a = out["runs"][MODES[0]]["every10"]
+for m in MODES[1:]:
+    out["max_rel_gap_of_10step_means" + ("" if m == "fp8" else "_" + m)] = max(abs(x - y) / x for x, y in zip(a, out["runs"][m]["every10"]))
 print(json.dumps(out))

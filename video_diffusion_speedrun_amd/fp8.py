@@ -40,9 +40,12 @@ E4M3, E5M2 = ops.FP8_E4M3, ops.FP8_E5M2
 # the four 1152^2-class linears (`enable_fp8(all_linears=True)`): 10 attention output (attn_proj input), 11 cross-attention
 # output (cross_proj input), 12 xn2 (q_cross input), 13 d(q_cross output), 14 d(context_kv output), 15 d(attn_proj
 # output), 16 d(cross_proj output); one more row after the blocks' rows: the text context (context_kv input, shared)
-ROWS = 17
+# fp8 cross-attention (same kernels, Lk = context length): 17 q_cross output, 18 / 19 the k / v halves of the context_kv
+# output, 20 d(cross-attention output)
+ROWS = 21
 ROW_Q, ROW_DO = 6, 9
 ROW_ATTN, ROW_CATT, ROW_XN2, ROW_DQC, ROW_DCKV, ROW_DY_AP, ROW_DY_CP = 10, 11, 12, 13, 14, 15, 16
+ROW_QC, ROW_DOC = 17, 20
 
 
 class Q:
