@@ -4,10 +4,11 @@ The reference trains in bf16 only (model.py:516-518), so the recipe is this buil
 
   * every linear layer of a block -- qkv, mlp.0 (fc1), mlp.2 (fc2), and (round 3, `all_linears`) attn_proj, q_cross,
     context_kv, cross_proj -- runs on `vds_gemm_fp8` (v_mfma_f32_16x16x128_f8f6f4, 2x the bf16 MFMA rate) in forward,
-    input gradient and weight gradient; the self-attention products run on the same instruction
-    (csrc/attention_fp8.hip, `attention`: e4m3 Q / K / V / P, e5m2 dO / dS, fp32 softmax statistics; P is rounded to
-    the e4m3 grid in the log domain in the forward pass, see P_BYTE there); cross-attention (L x 512), norms,
-    modulation, residuals, loss and the optimizer stay as in the bf16 path;
+    input gradient and weight gradient; the self-attention and (`cross_attention`, L x 512 context keys) the
+    cross-attention products run on the same instruction (csrc/attention_fp8.hip, `attention`: e4m3 Q / K / V / P,
+    e5m2 dO / dS, fp32 softmax statistics; P is rounded to the e4m3 grid in the log domain in the forward pass, see
+    P_BYTE there; operands as 128-byte fp8 rows from vds_qkv_rope_fwd_fp8 / vds_cross_qkv_fp8); norms, modulation,
+    residuals, loss and the optimizer stay as in the bf16 path;
   * OCP e4m3fn for activations and weights, e5m2 for gradients, fp32 accumulation, bf16 / fp32 outputs;
   * per-tensor scaling with saturating casts.  Weights are scaled by their current amax.  Activations and
     gradients use delayed scaling in training: the scale comes from the amax the previous step recorded
