@@ -10,9 +10,10 @@ print('$w', round(d['value'],3), round(d['ms_per_step'],1), round(d['mfma_util_s
 done
 python bench.py --workload c1 --graph --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/r03final/final_c1_graph_bench.log
 python bench.py --workload c5 --no-fp8-attention --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/r03final/c5_without_fp8_attention_bench.log
+python bench.py --workload c5 --no-fp8-cross-attention --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/r03final/c5_without_fp8_cross_attention_bench.log
 python bench.py --force-shard-runtime --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/r03final/final_c3b_shard_runtime_w1_bench.log
 python tools/bench_sampler.py > gpurun_out/r03final/sampler.log 2>&1; tail -3 gpurun_out/r03final/sampler.log
-for f in final_c1_graph_bench c5_without_fp8_attention_bench final_c3b_shard_runtime_w1_bench; do python -c "
+for f in final_c1_graph_bench c5_without_fp8_attention_bench c5_without_fp8_cross_attention_bench final_c3b_shard_runtime_w1_bench; do python -c "
 import json
 d=json.loads(open('gpurun_out/r03final/$f.log').read()); print('$f', round(d['value'],3), round(d['ms_per_step'],1))"; done
 for b in 1 2 4; do
