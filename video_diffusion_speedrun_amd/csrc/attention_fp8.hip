@@ -1192,9 +1192,9 @@ extern "C" int vds_cross_qkv_fp8(const void* q, const void* kv, void* q8, void* 
                                  float* amax_cur, int32_t amax_stride, float* deq, int32_t B, int32_t Lq, int32_t Lk,
                                  int32_t H, int32_t hd, vds_stream_t stream) {
   if (!q || !kv || !q8 || !k8 || !v8 || !amax_prev || !amax_cur || !deq || B < 1 || Lq < 1 || Lk < 1 || H < 1) return VDS_ERR_ARG;
-  if (hd != 72 || H > 256) return VDS_ERR_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
   constexpr int T = 4;
+  if (hd != 72 || H > 256 || Lq < T || Lk < T) return VDS_ERR_UNSUPPORTED;  // (a tile of T tokens spans at most two samples)
+  hipStream_t s = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) {
     set_lds(qkv_rope_fwd_fp8_tile_kernel<72, 96, T, 1, false>, 160 * 1024);

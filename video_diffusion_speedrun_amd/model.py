@@ -410,7 +410,7 @@ class DiTBlock(nn.Module):
             # fp8 cross-attention: the same kernels as the self-attention (Lk = context length), operands quantised by
             # vds_cross_qkv_fp8 with the previous step's amax; the bf16 kernels record the amax until a step is complete
             qc8 = kc8 = vc8 = deqc = None
-            c8_on = a8_on and fp8_attn >= 2
+            c8_on = a8_on and fp8_attn >= 2 and Lc >= 4  # (vds_cross_qkv_fp8 works on tiles of 4 tokens)
             c8 = c8_on and fp8_hist.ready
             if c8:
                 rc = R0 + F8.ROW_QC
