@@ -458,12 +458,16 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
   VDS_WAIT_VM(0);
   __syncthreads();
 
-  auto q_tile = [&](int j, auto PAR) {
+  // NKB: 16-key blocks of this wave that hold keys (2, except in a head's last workgroup: its waves without keys only
+  // stage and synchronise; see attn_fwd16_kernel in attention.hip)
+  auto q_tile = [&](int j, auto PAR, auto NKBT) {
     constexpr int par = decltype(PAR)::value;
+    constexpr int NKB = decltype(NKBT)::value;
     if (j + 1 < nqt) issue_tile(j + 1, par ^ 1);
     const char* qt = smem + par * 2 * TILE;
     const char* dot = qt + TILE;
     const float* stl = reinterpret_cast<const float*>(stats + par * 1024);
+    if constexpr (NKB > 0) {
     i32x8 pq[2], dsq[2];
     // software pipeline by hand (as in the forward kernel): the S / dP products of block i+1 are issued before the
     // exp2 / multiply / pack VALU work of block i; accumulator register r <-> query 32 g + 4 i + r of the tile
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
       const f32x4 nl4 = *reinterpret_cast<const f32x4*>(stl + 32 * g);
       const f32x4 nd4 = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g);
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < NKB; ++cb) {
         sn[cb] = mfma8s<0, 0>(aq, kf[cb], nl4, sc_s, 127);     // 8 - lse2 + log2-domain score
         dpn[cb] = mfma8s<1, 0>(ad, vf[cb], nd4, SC_DP, 127);   // (dO V^T - delta) / (256 s_do s_v)
       }
@@ -489,10 +493,10 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
       constexpr int i = decltype(I)::value;
       f32x4 s[2], dp[2];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) { s[cb] = sn[cb]; dp[cb] = dpn[cb]; }
+      for (int cb = 0; cb < NKB; ++cb) { s[cb] = sn[cb]; dp[cb] = dpn[cb]; }
       if constexpr (i < 7) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < NKB; ++cb) {
           sn[cb] = mfma8s<0, 0>(aqn, kf[cb], nln, sc_s, 127);
           dpn[cb] = mfma8s<1, 0>(adn, vf[cb], ndn, SC_DP, 127);
         }
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
         ndn = *reinterpret_cast<const f32x4*>(stl + 128 + 32 * g + 4 * (i + 2));
       }
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < NKB; ++cb) {
         f32x4 pr, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -525,19 +529,26 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
         else { dob = fr.trans<db + 1>(dot); qtb = fr.trans<db + 1>(qt); }
       }
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < NKB; ++cb) {
         dv[db][cb] = mfma8<1, 0>((db & 1) ? dob : doa, pq[cb], dv[db][cb]);
         dk[db][cb] = mfma8<0, 1>((db & 1) ? qtb : qta, dsq[cb], dk[db][cb]);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+    }
     VDS_WAIT_VM(0);
     __syncthreads();
   };
-  for (int j = 0; j < nqt; j += 2) {
-    q_tile(j, std::integral_constant<int, 0>{});
-    if (j + 1 < nqt) q_tile(j + 1, std::integral_constant<int, 1>{});
-  }
+  auto run = [&](auto NKBT) {
+    for (int j = 0; j < nqt; j += 2) {
+      q_tile(j, std::integral_constant<int, 0>{}, NKBT);
+      if (j + 1 < nqt) q_tile(j + 1, std::integral_constant<int, 1>{}, NKBT);
+    }
+  };
+  const int nkb = min(2, max(0, (p.Lk - (kt_idx * 128 + wave * 32) + 15) >> 4));  // wave-uniform
+  if (nkb == 2) run(std::integral_constant<int, 2>{});
+  else if (nkb == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
   const float fk = p.scale * s_do * s_v * s_q;  // dS_q = dS / (s_do s_v)
   const float fv = s_do * (1.0f / 256.0f);      // P_q = 256 P
 #pragma unroll
@@ -620,8 +631,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
   VDS_WAIT_VM(0);
   __syncthreads();
 
-  auto kv_tile = [&](int j, auto PAR) {
+  // NCB: 16-query blocks of this wave that hold queries (see attn8_bwd_dkv_kernel)
+  auto kv_tile = [&](int j, auto PAR, auto NCBT) {
     constexpr int par = decltype(PAR)::value;
+    constexpr int NCB = decltype(NCBT)::value;
     if (j + 1 < nkt && wave < 4) {
       char* nk = smem + (par ^ 1) * 2 * TILE;
       st.issue(rk, nk, (unsigned)(j + 1) * TILE, wave);
@@ -629,6 +642,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
     }
     const char* kt = smem + par * 2 * TILE;
     const char* vt = kt + TILE;
+    if constexpr (NCB > 0) {
     i32x8 dsq[2];
     f32x4 sn[2], dpn[2];  // software pipeline by hand, as in the other two kernels
     i32x8 akn, avn;       // fragments read one iteration ahead of the products that consume them
@@ -636,7 +650,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
       const i32x8 ak = fr.row<0>(kt);
       const i32x8 av = fr.row<0>(vt);
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < NCB; ++cb) {
         sn[cb] = mfma8s<0, 0>(ak, qf[cb], nl4[cb], sc_s, 127);
         dpn[cb] = mfma8s<0, 1>(av, dof[cb], nd4[cb], SC_DP, 127);
       }
@@ -647,10 +661,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
       constexpr int i = decltype(I)::value;
       f32x4 s[2], dp[2];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) { s[cb] = sn[cb]; dp[cb] = dpn[cb]; }
+      for (int cb = 0; cb < NCB; ++cb) { s[cb] = sn[cb]; dp[cb] = dpn[cb]; }
       if constexpr (i < 7) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
           sn[cb] = mfma8s<0, 0>(akn, qf[cb], nl4[cb], sc_s, 127);
           dpn[cb] = mfma8s<0, 1>(avn, dof[cb], nd4[cb], SC_DP, 127);
         }
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
         avn = fr.row<i + 2>(vt);
       }
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < NCB; ++cb) {
         f32x4 ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(s[cb][r]) * dp[cb][r];  // P (dP - delta) / (s_do s_v)
@@ -677,16 +691,23 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
         else ktb = fr.trans<db + 1>(kt);
       }
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) dq[db][cb] = mfma8<0, 1>((db & 1) ? ktb : kta, dsq[cb], dq[db][cb]);
+      for (int cb = 0; cb < NCB; ++cb) dq[db][cb] = mfma8<0, 1>((db & 1) ? ktb : kta, dsq[cb], dq[db][cb]);
       __builtin_amdgcn_sched_barrier(0);
     });
+    }
     VDS_WAIT_VM(0);
     __syncthreads();
   };
-  for (int j = 0; j < nkt; j += 2) {
-    kv_tile(j, std::integral_constant<int, 0>{});
-    if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{});
-  }
+  auto run = [&](auto NCBT) {
+    for (int j = 0; j < nkt; j += 2) {
+      kv_tile(j, std::integral_constant<int, 0>{}, NCBT);
+      if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{}, NCBT);
+    }
+  };
+  const int ncb = min(2, max(0, (p.Lq - (qt * (32 * NW) + wave * 32) + 15) >> 4));  // wave-uniform
+  if (ncb == 2) run(std::integral_constant<int, 2>{});
+  else if (ncb == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
   const float fq = p.scale * s_do * s_v * s_k;
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
