@@ -47,6 +47,7 @@ struct AttnP {
   float* delta;
   float scale;
   int n_rt;  // row tiles per (b,h) of the stationary operand
+  int tail_last;  // decode_block: the partly filled last tile of every head is scheduled after all full tiles
   int kv_pad_ones;
 };
 
@@ -115,10 +116,27 @@ __device__ __forceinline__ void retire(float f) { asm volatile("" ::"v"(f)); }
 
 // XCD-aware (b,h,row-tile) decode: all row tiles of a head run on one XCD so that the
 // streamed operand (K/V or Q/dO of that head) stays in that XCD's L2.
-__device__ __forceinline__ bool decode_block(int n_rt, int BH, int& bh, int& rt) {
+// Workgroup -> (head, row tile).  blockIdx & 7 is the XCD; each XCD walks its heads one after the other, so that the
+// workgroups of a head -- which all stream the same K / V (or Q / dO) rows -- run together and share them in that XCD's
+// L2.  tail_last: the sequence length leaves a partly filled last tile (8192 + 16 register tokens = 64 tiles of 128 +
+// 1), whose workgroup costs about half a full one (only one of its waves has rows).  Those tail workgroups of all the
+// XCD's heads are scheduled after the full ones, so that the partly filled LAST ROUND of the launch is made of cheap
+// workgroups: nothing at B = 12 (24 rounds), but at B = 2 the forward launch is 2 rounds + 32 tails instead of 3 rounds.
+__device__ __forceinline__ bool decode_block(int n_rt, int tail_last, int BH, int& bh, int& rt) {
   const int pid = blockIdx.x, xcd = pid & 7, idx = pid >> 3;
-  bh = (idx / n_rt) * 8 + xcd;
-  rt = idx % n_rt;
+  if (tail_last && n_rt > 1) {
+    const int n_full = n_rt - 1, cut = ((BH + 7) >> 3) * n_full;
+    if (idx < cut) {
+      bh = (idx / n_full) * 8 + xcd;
+      rt = idx % n_full;
+    } else {
+      bh = (idx - cut) * 8 + xcd;
+      rt = n_full;
+    }
+  } else {
+    bh = (idx / n_rt) * 8 + xcd;
+    rt = idx % n_rt;
+  }
   return bh < BH;
 }
 
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd_kernel(AttnP p) {
   constexpr int KSQ = HDQ / 16, NDB = HDP / 32, TILE = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, qt)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_wide_kernel(AttnP p) {
   static_assert(!ONES || (HDP == 96 && HDQ == 80), "ones columns: head_dim 72 layout");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, qt)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -642,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   static_assert(!ONES || (HDP == 96 && HDQ == 80), "ones columns: head_dim 72 layout");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, qt)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -770,7 +788,7 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void att
   char* qbuf = smem;
   char* stats = smem + 4 * Q_TILE;
   int bh, kt_idx;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, kt_idx)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, kt_idx)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -956,7 +974,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
   char* qbuf = smem;
   char* stats = smem + 4 * Q_TILE;
   int bh, kt_idx;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, kt_idx)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, kt_idx)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1139,7 +1157,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
   constexpr int KS = HDP / 32, NDB = 5, TILE = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, qt)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1309,7 +1327,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
   constexpr int KS = HDP / 32, NDB = 5, TILE = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, qt)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1459,6 +1477,7 @@ AttnP to_p(const vds_attn_args* a) {
   p.delta = a->delta;
   p.scale = 1.0f / sqrtf((float)a->head_dim);
   p.n_rt = 0;
+  p.tail_last = 0;
   p.kv_pad_ones = a->kv_pad_ones;
   return p;
 }
@@ -1491,6 +1510,16 @@ void set_lds(K kern, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// VDS_ATTN_TAIL_LAST=0 keeps the head-major order for ragged lengths too (A/B)
+static int tail_last_for(int L, int tile) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VDS_ATTN_TAIL_LAST");
+    on = e ? atoi(e) : 1;
+  }
+  return (on && L > tile && (L % tile) != 0) ? 1 : 0;
+}
+
 template <int HDP, int HDQ>
 int run_fwd(AttnP p, hipStream_t s) {
   constexpr int LDS = 4 * 64 * HDP * 2;
@@ -1511,6 +1540,7 @@ int run_fwd(AttnP p, hipStream_t s) {
   if constexpr (HDP == 96) use_wide = wide == 1 || (wide == 2 && p.Lq >= 2048);
   if constexpr (HDP == 64) use_wide = wide == 1 || (wide == 2 && p.Lq >= 2048);  // +2.7 % at head_dim 64
   p.n_rt = cdiv(p.Lq, use_wide ? 256 : 128);
+  p.tail_last = tail_last_for(p.Lq, use_wide ? 256 : 128);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
   const bool ones_fwd = HDP == 96 && HDQ == 80 && use_wide && p.kv_pad_ones && p.hd == 72;
@@ -1572,6 +1602,7 @@ int run_bwd(AttnP p, hipStream_t s) {
   // (a 64-keys-per-wave, one-wave-per-SIMD variant of this kernel -- half the LDS reads per MFMA -- was
   // measured at 0.55-0.8x: hipcc's single-wave schedule does not overlap the VALU softmax with the MFMAs)
   p.n_rt = cdiv(p.Lk, 128);
+  p.tail_last = tail_last_for(p.Lk, 128);
   int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     bool ones_kv = false;
@@ -1586,6 +1617,7 @@ int run_bwd(AttnP p, hipStream_t s) {
     if (!ones_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS_DKV, s, p);
   }
   p.n_rt = cdiv(p.Lq, 128);
+  p.tail_last = tail_last_for(p.Lq, 128);
   grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     bool ones = false;

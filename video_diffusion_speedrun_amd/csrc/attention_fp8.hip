@@ -62,6 +62,7 @@ struct Attn8P {
   const float* deq;                      // {s_q, s_k, s_v, s_do, E}: x = x_q * s; s_q s_k log2(e) / sqrt(hd) = 2^-E
   float scale;
   int n_rt;
+  int tail_last;  // decode_block: partly filled last tiles after all full ones
 };
 
 __device__ __forceinline__ int swz8(int row) { return ((row >> 1) & 3) | ((row >> 3) & 4); }
@@ -166,10 +167,27 @@ struct Stage8 {
   }
 };
 
-__device__ __forceinline__ bool decode_block(int n_rt, int BH, int& bh, int& rt) {
+// Workgroup -> (head, row tile).  blockIdx & 7 is the XCD; each XCD walks its heads one after the other, so that the
+// workgroups of a head -- which all stream the same K / V (or Q / dO) rows -- run together and share them in that XCD's
+// L2.  tail_last: the sequence length leaves a partly filled last tile (8192 + 16 register tokens = 64 tiles of 128 +
+// 1), whose workgroup costs about half a full one (only one of its waves has rows).  Those tail workgroups of all the
+// XCD's heads are scheduled after the full ones, so that the partly filled LAST ROUND of the launch is made of cheap
+// workgroups: nothing at B = 12 (24 rounds), but at B = 2 the forward launch is 2 rounds + 32 tails instead of 3 rounds.
+__device__ __forceinline__ bool decode_block(int n_rt, int tail_last, int BH, int& bh, int& rt) {
   const int pid = blockIdx.x, xcd = pid & 7, idx = pid >> 3;
-  bh = (idx / n_rt) * 8 + xcd;
-  rt = idx % n_rt;
+  if (tail_last && n_rt > 1) {
+    const int n_full = n_rt - 1, cut = ((BH + 7) >> 3) * n_full;
+    if (idx < cut) {
+      bh = (idx / n_full) * 8 + xcd;
+      rt = idx % n_full;
+    } else {
+      bh = (idx - cut) * 8 + xcd;
+      rt = n_full;
+    }
+  } else {
+    bh = (idx / n_rt) * 8 + xcd;
+    rt = idx % n_rt;
+  }
   return bh < BH;
 }
 __device__ __forceinline__ float max_over_lane_groups(float x) {  // max over the 4 lanes (l & 15) + 16 g
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
   constexpr int NDB = 5;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, qt)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* stats = smem + 4 * TILE;  // [2 bufs][nl[128] | nd[128]] floats
   int bh, kt_idx;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, kt_idx)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, kt_idx)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -582,7 +600,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
   constexpr int NDB = 5;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
-  if (!decode_block(p.n_rt, p.B * p.H, bh, qt)) return;
+  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, qt)) return;
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1050,6 +1068,16 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_tile_kernel(const bf16_t
   }
 }
 
+// VDS_ATTN_TAIL_LAST=0 keeps the head-major order for ragged lengths too (A/B)
+int tail_last_for(int L, int tile) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VDS_ATTN_TAIL_LAST");
+    on = e ? atoi(e) : 1;
+  }
+  return (on && L > tile && (L % tile) != 0) ? 1 : 0;
+}
+
 template <typename K>
 void set_lds(K kern, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1078,6 +1106,7 @@ Attn8P to_p(const vds_attn_fp8_args* a) {
   p.deq = a->deq;
   p.scale = 1.0f / sqrtf((float)a->head_dim);
   p.n_rt = 0;
+  p.tail_last = 0;
   return p;
 }
 
@@ -1093,6 +1122,7 @@ extern "C" int vds_attn_fp8_fwd(const vds_attn_fp8_args* a, vds_stream_t stream)
   if (!once) { set_lds(attn8_fwd_kernel<72>, LDS); once = true; }
   Attn8P p = to_p(a);
   p.n_rt = cdiv(p.Lq, 256);
+  p.tail_last = tail_last_for(p.Lq, 256);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   hipStream_t s = (hipStream_t)stream;
   vdsprof::Scope ps(VDS_PROF_ATTN_FP8_FWD, s, 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd,
@@ -1140,6 +1170,7 @@ extern "C" int vds_attn_fp8_bwd(const vds_attn_fp8_args* a, vds_stream_t stream)
   const double prod = 2.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;  // credit as in attention.hip: 2 + 2 products
   const double bytes = (double)p.B * p.H * ROWB * (2.0 * p.Lq + 2.0 * p.Lk);
   p.n_rt = cdiv(p.Lk, 128);
+  p.tail_last = tail_last_for(p.Lk, 128);
   int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     vdsprof::Scope ps(VDS_PROF_ATTN_FP8_DKV, s, 2.0 * prod, bytes + 4.0 * p.B * p.H * p.hd * (double)p.Lk);
@@ -1151,6 +1182,7 @@ extern "C" int vds_attn_fp8_bwd(const vds_attn_fp8_args* a, vds_stream_t stream)
     dq_waves = (e && atoi(e) == 6) ? 6 : 4;  // measured (B=6, L=8208): 2.0 ms with 4 waves, 2.7 ms with 6
   }
   p.n_rt = cdiv(p.Lq, 32 * dq_waves);
+  p.tail_last = tail_last_for(p.Lq, 32 * dq_waves);
   grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     vdsprof::Scope ps(VDS_PROF_ATTN_FP8_DQ, s, 2.0 * prod, bytes + 2.0 * p.B * p.H * p.hd * (double)p.Lq);
