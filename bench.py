@@ -67,8 +67,18 @@ import torch.distributed as dist
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_JSON = "r03_traffic.json"  # committed rocprofv3 PMC pass of the dominant kernel (tools/collect_profiles.sh)
+TRAFFIC_JSON = "r04_traffic.json"  # committed rocprofv3 PMC pass of the dominant kernel (tools/collect_profiles.sh)
 FP8_CLASSES = ("gemm_fp8", "attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq")
+# What a dense bf16 MFMA stream reaches on THIS chip on random data: a bare v_mfma_f32_16x16x32_bf16 loop, all operands in
+# registers, no LDS / memory traffic, runs 1.79-1.84 PFLOP/s at the board's power limit (tools/mfma_power.hip,
+# profiles/r02_power_clock_probe.txt; 2.16 on all-zero operands) -- the clock the 2.5 PFLOP/s datasheet peak assumes
+# (2.4 GHz) is not held under MFMA load.  `frac_of_practical_ceiling` prices a kernel against this figure (fp8: twice
+# it, same argument); `frac` stays against the datasheet peak.
+PRACTICAL_BF16_TFLOPS = 1800.0
+PROF_NAMES = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_delta", "attn_bwd_dkv", "attn_bwd_dq",
+              "rmsnorm_mod_fwd", "rmsnorm_mod_bwd", "adamw", "qkv_rope_fwd", "qkv_rope_bwd", "gate_bwd",
+              "attn_fwd_plain", "attn_bwd_dkv_plain", "attn_bwd_dq_plain", "gemm_fp8", "attn_fp8_fwd", "attn_fp8_dkv",
+              "attn_fp8_dq", "fp8_quant"]
 
 # name -> (DiT kwargs, latent [C,T,H,W], default per-GPU batch, description)
 WORKLOADS = {
@@ -158,6 +168,171 @@ def cpu_baseline(kw, latent_shape, flops_per_sample):
     return {"value": 1.0 / (dt * depth), "unit": "samples/s", "cores": n_threads, "kind": "port",
             "sample": f"1 of {depth} DiT blocks (+embed/final layers) at the full token count, B=1, fp32, "
                       f"fwd+bwd+AdamW in {dt:.1f} s (~{one_block / dt / 1e12:.2f} TFLOP/s); samples/s = 1/(depth x t)"}
+
+
+def cpu_baseline_c1():
+    """BASELINE.md section 4 / SURVEY 8(d): config C1 (DiT-S/2, 4 clips [16,8,16,16], context [512,4096]) MEASURED on
+    the host cores -- the whole model, forward + backward + AdamW, fp32 and in the reference's bf16 compute mode, one
+    warm-up step and the mean of the following steps (about 5 s in all)."""
+    from oracle import dit_oracle as O
+    n_threads = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(n_threads)
+    kw, lat = WORKLOADS["c1"][0], WORKLOADS["c1"][1]
+    cfg = O.DiTConfig(in_channels=16, patch_size=2, time_patch_size=kw["time_patch_size"], hidden_size=kw["hidden_size"],
+                      depth=kw["depth"], num_heads=kw["num_heads"], cross_attn_input_size=CC, residual_v=True,
+                      train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=0, randomize_zero_init=True, init_std_factor=0.1)
+    table = O.mup_settings(O.param_shapes(cfg), 1e-4, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
+    g = torch.Generator().manual_seed(1)
+    B = 4
+    x, ctx = torch.randn(B, *lat, generator=g), torch.randn(B, LC, CC, generator=g)
+    z, n = torch.randn(B, generator=g), torch.randn(B, *lat, generator=g)
+    out = {}
+    for name, dt_ in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        master = {k: w.clone() for k, w in P.items()}  # fp32 masters; bf16 leg: bf16 compute copies (model.py:516-519)
+        mom = {k: (torch.zeros_like(w), torch.zeros_like(w)) for k, w in P.items()}
+        times = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            Pg = {k: w.to(dt_).requires_grad_(True) for k, w in master.items()}
+            loss = O.train_forward(Pg, cfg, x, ctx, z, n, (0, 0, 0), compute_dtype=dt_)
+            loss.backward()
+            with torch.no_grad():
+                for k, w in Pg.items():
+                    if w.grad is not None:
+                        O.adamw_step(master[k], w.grad.float(), mom[k][0], mom[k][1], it + 1, table[k]["lr"], table[k]["wd"])
+            times.append(time.perf_counter() - t0)
+        t = sum(times[1:]) / len(times[1:])
+        out[name] = {"samples_per_s": round(B / t, 3), "ms_per_step": round(t * 1e3, 1), "loss": round(float(loss.detach()), 5)}
+    return {"workload": WORKLOADS["c1"][3] + ", B=4 (BASELINE.json configs[0])", "cores": n_threads, "kind": "port",
+            "sample": "the whole DiT-S model: 3 steps of fwd+bwd+AdamW per dtype, first one dropped", **out}
+
+
+def measure(one_step, steps, warmup, world, kw, args, fs=None, graphed=None):
+    """W untimed warm-up steps (the last one ranks the kernel classes by time with HIP events around every launch),
+    then exactly K steps between barrier + synchronize with events around the dominant class only.
+    -> dict(dt, median_ms, breakdown, dominant, dom, loss, n_ag0, n_rs0)"""
+    from video_diffusion_speedrun_amd import ops
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    breakdown, dominant, loss = {}, None, None
+    for w in range(warmup):
+        last = (w == warmup - 1) and not args.no_prof
+        if last:
+            torch.cuda.synchronize()
+            ops.prof_enable()
+        loss = one_step()
+        if last:
+            breakdown = ops.prof_collect()
+            ops.prof_enable(0)
+    if breakdown:
+        dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])
+    elif not args.no_prof:  # --warmup 0: no ranking step; time the kernel that dominates every attention-heavy config
+        dominant = "attn_bwd_dkv" if (kw["hidden_size"] // kw["num_heads"]) == 72 else "attn_bwd_dkv_plain"
+    sync()
+    r = {"n_ag0": 0, "n_rs0": 0}
+    if fs is not None:
+        fs.exposed_comm_ms()  # drop the warm-up's stall records
+        r["n_ag0"], r["n_rs0"] = fs.n_all_gather, fs.n_reduce_scatter
+    if dominant is not None and graphed is None:
+        ops.prof_enable(1 << PROF_NAMES.index(dominant))  # events around the dominant kernel's launches only
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # per-step times (median); no syncs
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        loss = one_step()
+        marks[i + 1].record()
+    sync()
+    dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    r["median_ms"] = (step_ms[(len(step_ms) - 1) // 2] + step_ms[len(step_ms) // 2]) / 2 if step_ms else float("nan")
+    if graphed is not None:  # a replay has no per-launch events: the kernel's duration comes from the eager warmup step
+        r["dom"] = breakdown.get(dominant)
+    else:
+        r["dom"] = ops.prof_collect().get(dominant) if dominant is not None else None
+    ops.prof_enable(0)
+    r.update(dt=dt, breakdown=breakdown, dominant=dominant, loss=loss)
+    return r
+
+
+def roofline_of(dominant, dom, workload, B):
+    """the JSON `roofline` object of one kernel class measured live (dom = its launches in the timed region)"""
+    mfma_bound = dom["flops"] > 0
+    fp8 = dominant in FP8_CLASSES
+    if mfma_bound:
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        peak, unit = (PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS), "TFLOP/s"
+    else:
+        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        peak, unit = PEAK_HBM_GBS, "GB/s"
+    # HBM bytes per launch: PMC counters cannot be read from inside this process (rocprofv3 wraps the command in
+    # separate --pmc passes), so the figure is the committed pass of this kernel at this workload and batch,
+    # stamped with the commit and kernel symbol it was taken on; null when there is none
+    traffic, traffic_src = None, None
+    for tjname in (TRAFFIC_JSON, "r03_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", tjname)))
+            # (the file holds the self-attention kernels at the C3b / C5 shape, bf16 and fp8)
+            if workload in (tj["workload"], "c5") and tj["per_gpu_batch"] == B and dominant in tj["kernels"]:
+                k = tj["kernels"][dominant]
+                traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
+                traffic_src = f"profiles/{tjname}: rocprofv3 PMC pass of {k['symbol']} at commit {tj['commit']}"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    out = {"bound": "mfma" if mfma_bound else "hbm", "achieved": ach, "peak": peak, "unit": unit,
+           "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+           "kernel": dominant, "launches": dom["launches"], "avg_ms": dom["ms"] / dom["launches"]}
+    if mfma_bound:
+        ceil = PRACTICAL_BF16_TFLOPS * (2.0 if fp8 else 1.0)
+        out["frac_of_practical_ceiling"] = ach / ceil
+        out["practical_ceiling"] = {"TFLOP/s": ceil, "source": "bare register-resident MFMA loop on random data at the "
+                                    "board power limit, tools/mfma_power.hip + profiles/r02_power_clock_probe.txt"}
+    return out
+
+
+def rates_of(breakdown):
+    """the HBM-bound glue is reported separately, as achieved GB/s (algorithmic bytes: every operand read
+    once, every result written once) against the HBM peak; MFMA classes as TFLOP/s"""
+    return {
+        k: ({"TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1),
+             "frac_of_peak": round(v["flops"] / v["ms"] / 1e9 / (PEAK_FP8_TFLOPS if k in FP8_CLASSES else PEAK_BF16_TFLOPS), 4),
+             "dtype": "fp8" if k in FP8_CLASSES else "bf16"}
+            if v["flops"] > 0 and k != "attn_bwd_delta" else  # (the delta preprocess streams O and dO: HBM-bound)
+            {"GB/s": round(v["bytes"] / v["ms"] / 1e6, 1), "frac_of_peak": round(v["bytes"] / v["ms"] / 1e6 / PEAK_HBM_GBS, 4)})
+        for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}
+
+
+def secondary_c5(model, one_step, kw, args, B, flops):
+    """BASELINE config 5 in the same run: the SAME model, batch and optimizer with `DiT.enable_fp8()` (every linear of
+    the blocks and the self- and cross-attention products on the fp8 MFMA, fp8.py).  Three untimed steps -- the first
+    records the amax history on the bf16 attention kernels, the second is the first armed one, the third ranks the
+    kernel classes -- then 8 timed steps; its own roofline is priced against the 5 PFLOP/s fp8 peak, and `fp8_quant`
+    is the time of the separate quantise / transpose / absmax passes."""
+    model.enable_fp8()
+    steps, warmup = 8, 3
+    r = measure(one_step, steps, warmup, 1, kw, args)
+    ms = r["dt"] / steps * 1e3
+    value = B * steps / r["dt"]
+    loss_val = float(r["loss"].item())
+    out = {"metric": "train-step samples/sec (video latents)", "value": value, "unit": "samples/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": ms, "ms_per_step_median": r["median_ms"], "dtype": "fp8+bf16",
+           "config": {"workload": WORKLOADS["c5"][3], "per_gpu_batch": B, "step_tflop_per_sample": flops / 1e12},
+           "mfma_util_step_vs_bf16_peak": value * flops / (PEAK_BF16_TFLOPS * 1e12),
+           "mfma_util_step_vs_fp8_peak": value * flops / (PEAK_FP8_TFLOPS * 1e12), "loss": loss_val,
+           "finite": math.isfinite(loss_val)}
+    if r["dom"]:
+        out["roofline"] = roofline_of(r["dominant"], r["dom"], "c5", B)
+    if r["breakdown"]:
+        bd = r["breakdown"]
+        out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(bd.items(), key=lambda kv: -kv[1]["ms"])}
+        out["kernel_breakdown_ms"]["_sum"] = round(sum(v["ms"] for v in bd.values()), 3)
+        out["kernel_rates"] = rates_of(bd)
+    return out
 
 
 def require_vds_comm(sharded: bool, comm_mod):
@@ -266,6 +441,9 @@ def main():
                     help="time only the step's collectives (one bf16 all-gather + one fp32 reduce-scatter-average per "
                          "shard group) on the communication stream, under both reduce-scatter schedules; no compute")
     ap.add_argument("--no-fp8-attention", action="store_true", help="c5: keep the attention products in bf16")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="c3b on 1 GPU: skip the `secondary` measurement (the same model and batch with DiT.enable_fp8() = "
+                         "BASELINE config 5)")
     ap.add_argument("--no-fp8-cross-attention", action="store_true",
                     help="c5: keep the cross-attention products in bf16 (fp8 self-attention only)")
     args = ap.parse_args()
@@ -333,54 +511,11 @@ def main():
         for _ in range(3 if args.workload == "c5" else 2):
             graphed.step(batch)
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- warmup (untimed); the last warmup step ranks the kernel classes by time ----------
-    breakdown, dominant = {}, None
-    for w in range(args.warmup):
-        last = (w == args.warmup - 1) and not args.no_prof
-        if last:
-            torch.cuda.synchronize()
-            ops.prof_enable()
-        loss = one_step()
-        if last:
-            breakdown = ops.prof_collect()
-            ops.prof_enable(0)
-    if breakdown:
-        dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])
-    elif not args.no_prof:  # --warmup 0: no ranking step; time the kernel that dominates every attention-heavy config
-        dominant = "attn_bwd_dkv" if (kw["hidden_size"] // kw["num_heads"]) == 72 else "attn_bwd_dkv_plain"
-    names = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_delta", "attn_bwd_dkv", "attn_bwd_dq",
-             "rmsnorm_mod_fwd", "rmsnorm_mod_bwd", "adamw", "qkv_rope_fwd", "qkv_rope_bwd", "gate_bwd",
-             "attn_fwd_plain", "attn_bwd_dkv_plain", "attn_bwd_dq_plain", "gemm_fp8", "attn_fp8_fwd", "attn_fp8_dkv",
-             "attn_fp8_dq"]
-
-    # ---- timed region: exactly K steps between barrier + synchronize --------------------------
-    sync()
     fs = getattr(model, "_fsdp", None)
-    if fs is not None:
-        fs.exposed_comm_ms()  # drop the warm-up's stall records
-        n_ag0, n_rs0 = fs.n_all_gather, fs.n_reduce_scatter
-    if dominant is not None and graphed is None:
-        ops.prof_enable(1 << names.index(dominant))  # events around the dominant kernel's launches only
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # per-step times (median); no syncs
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        loss = graphed.step(batch) if graphed is not None else one_step()
-        marks[i + 1].record()
-    sync()
-    dt = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    median_ms = (step_ms[(len(step_ms) - 1) // 2] + step_ms[len(step_ms) // 2]) / 2 if step_ms else float("nan")
-    if graphed is not None:  # a replay has no per-launch events: the kernel's duration comes from the eager warmup step
-        dom = breakdown.get(dominant)
-    else:
-        dom = ops.prof_collect().get(dominant) if dominant is not None else None
-    ops.prof_enable(0)
+    step_fn = (lambda: graphed.step(batch)) if graphed is not None else one_step
+    r = measure(step_fn, args.steps, args.warmup, world, kw, args, fs=fs, graphed=graphed)
+    dt, median_ms, breakdown, dominant, dom, loss = r["dt"], r["median_ms"], r["breakdown"], r["dominant"], r["dom"], r["loss"]
+    n_ag0, n_rs0 = r["n_ag0"], r["n_rs0"]
     comm_info = None
     if fs is not None:  # sharded run: what the communicator saw, per rank
         from video_diffusion_speedrun_amd import comm
@@ -434,49 +569,23 @@ def main():
             assert comm_info["communicator_world"] == world, comm_info
             out["comm"] = comm_info
         if dom:
-            mfma_bound = dom["flops"] > 0
-            if mfma_bound:
-                ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-                peak, unit = (PEAK_FP8_TFLOPS if dominant in FP8_CLASSES else PEAK_BF16_TFLOPS), "TFLOP/s"
-            else:
-                ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-                peak, unit = PEAK_HBM_GBS, "GB/s"
-            # HBM bytes per launch: PMC counters cannot be read from inside this process (rocprofv3 wraps the command in
-            # separate --pmc passes), so the figure is the committed pass of this kernel at this workload and batch,
-            # stamped with the commit and kernel symbol it was taken on; null when there is none
-            traffic, traffic_src = None, None
-            try:
-                tj = json.load(open(os.path.join(REPO, "profiles", TRAFFIC_JSON)))
-                # (the file holds the self-attention kernels at the C3b / C5 shape, bf16 and fp8)
-                if args.workload in (tj["workload"], "c5") and tj["per_gpu_batch"] == B and dominant in tj["kernels"]:
-                    k = tj["kernels"][dominant]
-                    traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
-                    traffic_src = f"profiles/{TRAFFIC_JSON}: rocprofv3 PMC pass of {k['symbol']} at commit {tj['commit']}"
-            except (OSError, KeyError, ValueError):
-                pass
-            out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": ach, "peak": peak, "unit": unit,
-                               "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": dominant, "launches": dom["launches"], "avg_ms": dom["ms"] / dom["launches"]}
+            out["roofline"] = roofline_of(dominant, dom, args.workload, B)
         if breakdown:
             tot = sum(v["ms"] for v in breakdown.values())
             out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in
                                           sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"])}
             out["kernel_breakdown_ms"]["_sum"] = round(tot, 3)
-            # the HBM-bound glue is reported separately, as achieved GB/s (algorithmic bytes: every
-            # operand read once, every result written once) against the HBM peak; MFMA classes as TFLOP/s
-            out["kernel_rates"] = {
-                k: ({"TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1), "frac_of_peak": round(v["flops"] / v["ms"] / 1e9 / (PEAK_FP8_TFLOPS if k in FP8_CLASSES else PEAK_BF16_TFLOPS), 4),
-                     "dtype": "fp8" if k in FP8_CLASSES else "bf16"}
-                    if v["flops"] > 0 and k != "attn_bwd_delta" else  # (the delta preprocess streams O and dO: HBM-bound)
-                    {"GB/s": round(v["bytes"] / v["ms"] / 1e6, 1), "frac_of_peak": round(v["bytes"] / v["ms"] / 1e6 / PEAK_HBM_GBS, 4)})
-                for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}
+            out["kernel_rates"] = rates_of(breakdown)
             if args.breakdown:
                 for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]):
                     rate = (f"{v['flops'] / v['ms'] / 1e9:8.1f} TFLOP/s" if v["flops"] > 0 else
                             f"{v['bytes'] / v['ms'] / 1e6:8.1f} GB/s")
                     print(f"[bench] {k:16s} {v['launches']:5d} launches {v['ms']:9.3f} ms  {rate}", file=sys.stderr)
+        if world == 1 and args.workload == "c3b" and graphed is None and fs is None and not args.no_secondary:
+            out["secondary"] = secondary_c5(model, one_step, kw, args, B, flops)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kw, latent_shape, flops)
+            out["cpu_baseline"]["c1_measured"] = cpu_baseline_c1()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

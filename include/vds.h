@@ -444,6 +444,7 @@ enum { VDS_PROF_GEMM_NT = 0, VDS_PROF_GEMM_NN, VDS_PROF_GEMM_TN, VDS_PROF_ATTN_F
        /* the attention kernel instances without the ones-column contract (cross-attention, hd 64/128) */
        VDS_PROF_ATTN_FWD_PLAIN, VDS_PROF_ATTN_BWD_DKV_PLAIN, VDS_PROF_ATTN_BWD_DQ_PLAIN, VDS_PROF_GEMM_FP8,
        VDS_PROF_ATTN_FP8_FWD, VDS_PROF_ATTN_FP8_DKV, VDS_PROF_ATTN_FP8_DQ,
+       VDS_PROF_FP8_QUANT, /* vds_quant_fp8 / vds_transpose_fp8 / vds_absmax: the fp8 path's separate operand passes */
        VDS_PROF_NCLASS };
 typedef struct vds_prof_stat { int64_t launches; double ms; double flops; double bytes; } vds_prof_stat;
 int vds_prof_enable(uint32_t class_mask);

@@ -58,7 +58,7 @@ def test_host_side_argument_checks(lib):
     assert lib.vds_adamw_multi(None, None, None, 1, 1024, 0.9, 0.99, 1e-8, 1, 1.0, 1.0, None) == -1
     assert lib.vds_prof_collect(None) == -1
     assert lib.vds_prof_class_name(0) == b"gemm_nt"
-    assert lib.vds_prof_class_name(_lib.PROF_NCLASS - 1) == b"attn_fp8_dq" and lib.vds_prof_class_name(_lib.PROF_NCLASS) == b""
+    assert lib.vds_prof_class_name(_lib.PROF_NCLASS - 1) == b"fp8_quant" and lib.vds_prof_class_name(_lib.PROF_NCLASS) == b""
     # fp8 attention: null operands / unsupported head_dim are refused before any launch
     a8 = _lib.Attn8Args()
     assert lib.vds_attn_fp8_fwd(C.byref(a8), None) == -1 and lib.vds_attn_fp8_bwd(C.byref(a8), None) == -1

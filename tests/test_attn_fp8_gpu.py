@@ -147,6 +147,59 @@ def test_attn_fp8_backward_vs_fp32_on_dequantised_operands(ops, parity_log, L, L
     assert figs["dk_rel"] <= 1.2e-1 and figs["dk_cos"] >= 0.993, figs
 
 
+@pytest.mark.parametrize("L,Lk", [(300, 300), (700, 300), (8208, 8208)],
+                         ids=["ragged300", "cross_Lq700_Lk300", "headline_8208"])
+def test_attn_fp8_backward_is_finite_when_every_score_is_very_negative(ops, parity_log, L, Lk):
+    """q = +c, k = -c in every column makes every score about -34 nat, i.e. lse * log2(e) about -40.  A
+    zero-filled pad key of the last (partly filled) K tile then gets 'P' = 2^(8 - lse2) = 2^48 in the dQ kernel, its dS
+    leaves the e5m2 range (the cast does not saturate) and inf x the zero column of K^T is NaN for the whole dQ row --
+    unless the ragged tile masks key indices >= Lk.  Lk = 300 leaves 84 pad keys, the headline length 8208 leaves 112.
+    Every gradient must be finite and agree with fp32 attention on the dequantised operands."""
+    dev = torch.device("cuda")
+    B, H = 1, 2
+    g = torch.Generator().manual_seed(21)
+    c = 2.0
+    q = (c * (1.0 + 0.02 * torch.randn(B, H, L, HD, generator=g))).to(dev)
+    k = (-c * (1.0 + 0.02 * torch.randn(B, H, Lk, HD, generator=g))).to(dev)
+    v = torch.randn(B, H, Lk, HD, generator=g).to(dev)
+    aq, ak, E = ops.attn_fp8_qk_factors(q.abs().max().item(), k.abs().max().item(), HD)
+    q8, sq, qd = quant_rows(q, E4, alpha=aq)
+    k8, sk, kd = quant_rows(k, E4, alpha=ak)
+    v8, sv, vd = quant_rows(v, E4, 448.0)
+    v8[..., HD] = 0x38
+    deq = torch.tensor([sq, sk, sv, 0.0, E, 0.0, 0.0, 0.0], dtype=f32, device=dev)
+    q8, k8, v8 = q8.view(E4), k8.view(E4), v8.view(E4)
+    o = torch.empty(B * L, H * HD, dtype=bf16, device=dev)
+    lse = torch.empty(B, H, L, dtype=f32, device=dev)
+    ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(o, B, L, H, HD), lse, HD)
+    assert lse.max().item() * math.log2(math.e) < -20.0  # the regime the bug needs
+    do = (torch.randn(B * L, H * HD, generator=g) * 0.02).to(bf16).to(dev)
+    doq = torch.zeros(B, H, L, ROW, dtype=E5, device=dev)
+    amax_prev = do.float().abs().max().reshape(1)
+    amax_cur = torch.zeros(1, dtype=f32, device=dev)
+    stats = ops.attn_fp8_delta(o, do, lse, doq, amax_prev, amax_cur, deq, B, H, L, HD)
+    dq = torch.full((B, H, L, HDP), float("nan"), dtype=bf16, device=dev)
+    dk = torch.full((B, H, Lk, HDP), float("nan"), dtype=bf16, device=dev)
+    dv = torch.full_like(dk, float("nan"))
+    ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dq[..., :HD], dk[..., :HD], dv[..., :HD], HD)
+    torch.cuda.synchronize()
+    for name, got in (("dq", dq), ("dk", dk), ("dv", dv)):
+        assert torch.isfinite(got[..., :HD].float()).all(), name
+    # fp64 attention on the dequantised operands (on the device: 8208^2 scores per head), dO as quantised
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (qd, kd, vd))
+    s = (qr @ kr.transpose(-1, -2)) / math.sqrt(HD)
+    out = torch.softmax(s, dim=-1) @ vr
+    out.backward(doq.float()[..., :HD].double() * deq[3].item())
+    figs = {}
+    for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        figs[name + "_rel"], figs[name + "_cos"] = rel(got[..., :HD], ref), cos(got[..., :HD], ref)
+    parity_log("attn_fp8_bwd_negative_scores", L=L, Lk=Lk, **figs)
+    # near-uniform softmax: dS = P (dP - delta) is a difference of nearly equal terms, so dQ / dK are small and carry the
+    # e5m2 rounding of dS in full; dV has no such cancellation
+    assert figs["dv_rel"] <= 4e-2 and figs["dv_cos"] >= 0.999, figs
+    assert figs["dq_cos"] >= 0.98 and figs["dk_cos"] >= 0.98, figs
+
+
 @pytest.mark.parametrize("L", [200, 203], ids=["L200", "L203_tiles_straddle_samples"])
 @pytest.mark.parametrize("mix", [False, True], ids=["block0", "mixed"])
 def test_qkv_rope_fp8_is_the_bf16_kernel_quantised(ops, mix, L):

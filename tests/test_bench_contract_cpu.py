@@ -90,3 +90,22 @@ def test_a_fallen_back_communicator_fails_the_bench():
     for flag in ("--comm-only", "--force-shard-runtime", "--batch"):
         assert flag in subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--help"], capture_output=True,
                                       text=True).stdout
+
+
+def test_c1_cpu_leg_and_line_helpers():
+    """the measured C1 legs of `cpu_baseline` (DiT-S/2, 4 clips, fp32 and bf16 on the host
+    cores), the per-kernel roofline object with its practical-ceiling fraction, and the profiler class table"""
+    b = load_bench()
+    c1 = b.cpu_baseline_c1()
+    assert c1["kind"] == "port" and c1["cores"] >= 1
+    for leg in ("fp32", "bf16"):
+        assert c1[leg]["samples_per_s"] > 0 and c1[leg]["ms_per_step"] > 0
+    from video_diffusion_speedrun_amd import _lib
+    assert len(b.PROF_NAMES) == _lib.PROF_NCLASS and b.PROF_NAMES[-1] == "fp8_quant"
+    r = b.roofline_of("attn_bwd_dkv", dict(flops=3.725e12 * 10, bytes=0.0, ms=63.6, launches=10), "c3b", 12)
+    assert r["bound"] == "mfma" and abs(r["frac"] - 0.2343) < 1e-3
+    assert abs(r["frac_of_practical_ceiling"] - r["achieved"] / 1800.0) < 1e-9
+    r8 = b.roofline_of("attn_fp8_dkv", dict(flops=3.725e12, bytes=0.0, ms=4.0, launches=1), "c5", 12)
+    assert r8["peak"] == 5000.0 and abs(r8["frac_of_practical_ceiling"] - r8["achieved"] / 3600.0) < 1e-9
+    h = b.roofline_of("adamw", dict(flops=0.0, bytes=34e9, ms=6.6, launches=1), "c3b", 12)
+    assert h["bound"] == "hbm" and "frac_of_practical_ceiling" not in h

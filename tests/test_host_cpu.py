@@ -64,3 +64,25 @@ def test_shadow_freshness_follows_parameter_writes():
     assert g.shadow_fresh
     g.invalidate_shadow()
     assert not g.shadow_fresh
+
+
+def test_use_rope_false_keeps_the_reference_state_dict_key():
+    """model.py:312-314: `use_rope=False` registers `positional_embedding` [1, 2048, D] (zeros) in place of the RoPE
+    module; train.py:287 names it among the constant muP classes.  The reference's forward cannot run such a model
+    (it calls self.rope unconditionally, model.py:364); a checkpoint of one must still load with strict=True here."""
+    kw = dict(hidden_size=128, depth=1, num_heads=2, train_bias_and_rms=False)
+    m = _dit("cpu", use_rope=False, **kw)
+    sd = m.state_dict()
+    assert "positional_embedding" in sd and tuple(sd["positional_embedding"].shape) == (1, 2048, 128)
+    assert float(sd["positional_embedding"].abs().max()) == 0.0
+    names = [n for n, _ in m.named_parameters()]
+    assert names.index("positional_embedding") == names.index("register_tokens") - 1  # the reference's registration order
+    ref_like = {k: torch.randn_like(v) for k, v in sd.items()}
+    m.load_state_dict(ref_like, strict=True)
+    assert torch.equal(m.positional_embedding.data, ref_like["positional_embedding"])
+    _, table = m.get_mup_setup(1e-4, 0.1, CONSTS)
+    assert table["positional_embedding"]["lr"] == 1e-4 * 0.01 and table["positional_embedding"]["wd"] == 0.0
+    assert "positional_embedding" not in _dit("meta", use_rope=True, **kw).state_dict()
+    import pytest
+    with pytest.raises((AttributeError, RuntimeError)):
+        m(torch.zeros(1, 16, 4, 8, 8), torch.zeros(1, 4, 4096), torch.zeros(1))

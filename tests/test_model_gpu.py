@@ -760,11 +760,12 @@ def _emulate_ranks(vds, monkeypatch, cfg, P, W):
     return reps, pending
 
 
-def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch):
-    """The sharded train step with world_size 2 on ONE GPU (see _emulate_ranks).  Each rank takes its own
+@pytest.mark.parametrize("W,prefetch", [(2, 0), (4, 1)], ids=["w2_all_upfront", "w4_window1"])
+def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch, W, prefetch):
+    """The sharded train step with world_size 2 / 4 on ONE GPU (see _emulate_ranks).  Each rank takes its own
     micro-batch; after one step the concatenated parameter shards must equal the unsharded model stepped on the
-    concatenated batch (gradient = average over ranks, model.py:516-519)."""
-    W = 2
+    concatenated batch (gradient = average over ranks, model.py:516-519).  prefetch: the all-gather window of
+    fsdp.ShardRuntime (0 = every group up-front, 1 = one group ahead like FSDP2)."""
     cfg = O.DiTConfig(in_channels=16, hidden_size=128, depth=3, num_heads=2, cross_attn_input_size=64,
                       residual_v=True, train_bias_and_rms=False)
     P = O.init_params(cfg, seed=61, randomize_zero_init=True, init_std_factor=1.0)
@@ -789,9 +790,11 @@ def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch):
     want = ref.full_state_dict()
 
     reps, pending = _emulate_ranks(vds, monkeypatch, cfg, P, W)
+    per = 4 // W
     opts, losses = [], []
     for r in range(W):
-        o, l = step(reps[r], slice(2 * r, 2 * r + 2))
+        reps[r]._fsdp.prefetch = prefetch
+        o, l = step(reps[r], slice(per * r, per * (r + 1)))
         opts.append(o)
         losses.append(l.item())
     torch.cuda.synchronize()  # rank 0's gradient shards were completed while rank 1 ran its backward
@@ -807,9 +810,11 @@ def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch):
             got = flat[o0:o0 + want[n].numel()].view(want[n].shape)
             assert rel(got, want[n]) <= 1e-4, (n, rel(got, want[n]))
     # every parameter of a sharded replica is this rank's 1-D piece, and the pieces tile the tensor
+    others = [dict(m.named_parameters()) for m in reps[1:]]
     for n, p0 in reps[0].named_parameters():
-        p1 = dict(reps[1].named_parameters())[n]
-        assert p0.dim() == 1 and p0.numel() + p1.numel() == want[n].numel()
+        assert p0.dim() == 1 and p0.numel() + sum(o[n].numel() for o in others) == want[n].numel()
+    for i in range(1, cfg.depth):  # a residual-V lambda (1 element) lives on exactly one rank
+        assert sum(dict(m.named_parameters())[f"blocks.{i}.lambda_param"].numel() for m in reps) == 1
 
 
 def test_sharded_hip_step_matches_the_reference_fsdp_run(vds, monkeypatch, golden_dir):

@@ -29,10 +29,10 @@ def make_model():
     return m, cfg, P
 
 
-def test_flat_group_layout_covers_every_element_once():
+@pytest.mark.parametrize("world", [3, 4, 8])
+def test_flat_group_layout_covers_every_element_once(world):
     m, cfg, P = make_model()
     named = [(n, p) for n, p in m.named_parameters() if n.startswith("blocks.1.")]
-    world = 3
     groups = [FlatGroup("blocks.1", named, world, r) for r in range(world)]
     g0 = groups[0]
     assert g0.padded % (world * 256) == 0 and g0.shard * world == g0.padded
@@ -82,25 +82,34 @@ def _oracle_grads(cfg, weights, batch):
     return {k: (w.grad if w.grad is not None else torch.zeros_like(w)) for k, w in Pg.items()}, loss.item()
 
 
-def _batches():
+def _batches(world=2):
+    """a global batch of max(4, world) samples and its per-rank slices (equal sizes: the mean over ranks of the
+    per-rank batch-mean gradients is the batch-mean gradient of the whole batch)"""
+    n = max(4, world)
     g = torch.Generator().manual_seed(3)
-    full = dict(latent=torch.randn(4, 16, 4, 8, 8, generator=g), context=torch.randn(4, 6, 64, generator=g),
-                z=torch.randn(4, generator=g), noise=torch.randn(4, 16, 4, 8, 8, generator=g))
-    halves = [{k: v[2 * r:2 * r + 2] for k, v in full.items()} for r in range(2)]
-    return full, halves
+    full = dict(latent=torch.randn(n, 16, 4, 8, 8, generator=g), context=torch.randn(n, 6, 64, generator=g),
+                z=torch.randn(n, generator=g), noise=torch.randn(n, 16, 4, 8, 8, generator=g))
+    per = n // world
+    parts = [{k: v[per * r:per * (r + 1)] for k, v in full.items()} for r in range(world)]
+    return full, parts
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, prefetch=0):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        torch.set_num_threads(2)
+        torch.set_num_threads(1 if world > 2 else 2)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from video_diffusion_speedrun_amd.fsdp import apply_fsdp, get_device_mesh
         m, cfg, P = make_model()
-        assert get_device_mesh() == {"dp_replicate": 1, "dp_shard": 2, "tp": 1}
+        assert get_device_mesh() == {"dp_replicate": 1, "dp_shard": world, "tp": 1}
         m = apply_fsdp(m, torch.bfloat16, torch.float32, device="cpu")
         fs = m._fsdp
-        assert fs is not None and m._world == 2
+        assert fs is not None and m._world == world and fs.world == world
+        fs.prefetch = prefetch  # all-gather window: 0 = everything up-front, d = d groups beyond the one in use
+        # residual-V lambdas: 1-element tensors live on exactly one rank (SURVEY 2.4: FSDP2 leaves empty shards elsewhere)
+        own = torch.tensor([float(m.block_group(1).local_range("blocks.1.lambda_param") != (0, 0))])
+        dist.all_reduce(own)
+        assert own.item() == 1.0
         # every parameter is now this rank's 1-D piece; the pieces of the two ranks tile the tensor
         for n, p in m.named_parameters():
             assert p.dim() == 1 and p.dtype == torch.float32
@@ -108,13 +117,16 @@ def _worker(rank, world, port, q):
         ref_tbl = O.mup_settings(O.param_shapes(cfg), 1e-3, 0.1, CONSTS)
         assert {k: (v["lr"], v["wd"]) for k, v in settings.items()} == {k: (v["lr"], v["wd"]) for k, v in ref_tbl.items()}
 
-        full, halves = _batches()
-        # ---- forward side: all groups gathered up-front; read the full bf16 weights -------------
+        full, halves = _batches(world)
+        # ---- forward side: groups gathered in use order (window = prefetch); read the full bf16 weights ----
         fs.pre_forward_root()
+        assert fs.n_all_gather == (1 + cfg.depth if prefetch == 0 else min(1 + cfg.depth, 1 + prefetch))
         weights = {}
         for gi, g in enumerate(m._groups):
             if gi > 0:
                 fs.pre_forward_block(gi - 1)
+                if prefetch:
+                    assert fs.n_all_gather == min(1 + cfg.depth, gi + 1 + prefetch)
             for n in g.names:
                 weights[n] = g.w(n).clone()
                 assert torch.equal(weights[n], P[n].to(torch.bfloat16)), n  # bf16 all-gather is exact
@@ -134,19 +146,20 @@ def _worker(rank, world, port, q):
         fs.post_backward_root()
         assert fs.n_all_gather == 1 + cfg.depth and fs.n_reduce_scatter == 1 + cfg.depth
 
-        # ---- single-process truth: mean over both half batches (= FSDP's AVG over ranks) ---------
-        ga, _ = _oracle_grads(cfg, weights, halves[0])
-        gb, _ = _oracle_grads(cfg, weights, halves[1])
+        # ---- single-process truth: the batch-mean gradient of the whole batch (= FSDP's AVG over ranks of the
+        # per-rank batch means; at world 2 additionally formed from the two halves explicitly) ---------
+        per_rank = [_oracle_grads(cfg, weights, h)[0] for h in halves]
+        gfull = {n: sum(gr[n] for gr in per_rank) / world for n in per_rank[0]}
         table = ref_tbl
         for g in m._groups:
             for n in g.names:
                 p = g.params[n]
                 lo, hi = g.local_range(n)
-                mean = ((ga[n] + gb[n]) / 2).reshape(-1)
+                mean = gfull[n].reshape(-1)
                 g0 = g.rank * g.shard + lo - g.offsets[n]
                 ref = mean[g0:g0 + (hi - lo)]
                 assert p.grad is not None and p.grad.shape == ref.shape, n
-                assert torch.allclose(p.grad, ref, rtol=1e-5, atol=1e-7), n
+                assert torch.allclose(p.grad, ref, rtol=1e-4, atol=1e-7), n
                 # optimizer on the local shard == the slice of the full-tensor update
                 if hi > lo:
                     full_p = P[n].clone().reshape(-1)
@@ -155,7 +168,10 @@ def _worker(rank, world, port, q):
                     loc = p.data.clone()
                     O.adamw_step(loc, p.grad.clone(), torch.zeros_like(loc), torch.zeros_like(loc), 1, table[n]["lr"],
                                  table[n]["wd"])
-                    assert torch.allclose(loc, full_p[g0:g0 + (hi - lo)], rtol=1e-6, atol=1e-8), n
+                    # (elements whose gradient is ~0 are left out: AdamW's first step is lr * g / (|g| + eps), and the
+                    # ring's summation order may differ from the in-order mean in the last fp32 bit)
+                    keep = ref.abs() > 1e-4 * mean.abs().max()
+                    assert torch.allclose(loc[keep], full_p[g0:g0 + (hi - lo)][keep], rtol=1e-6, atol=1e-8), n
         # full_tensor() re-assembles the fp32 master across ranks
         assert torch.equal(m._groups[1].full_tensor("blocks.0.qkv.weight"), P["blocks.0.qkv.weight"])
         sd = m.full_state_dict()
@@ -243,11 +259,11 @@ def _g6_worker(rank, world, port, q, golden):
         q.put((rank, traceback.format_exc()))
 
 
-def _run_two_ranks(target, *extra):
+def _run_two_ranks(target, *extra, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=target, args=(r, 2, port, q) + extra) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=540) for _ in procs]
@@ -291,3 +307,13 @@ def test_reference_shard_shapes_and_reduction_contract(golden_dir):
 @pytest.mark.timeout(600)
 def test_two_rank_gloo_sharded_step_matches_single_process():
     _run_two_ranks(_worker)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,prefetch", [(4, 1), (8, 0), (8, 2)], ids=["w4_window1", "w8_all_upfront", "w8_window2"])
+def test_four_and_eight_rank_gloo_sharded_step(world, prefetch):
+    """the shard layout (flat pieces, lambda ownership), the per-group bf16 all-gathers -- all
+    up-front or through a bounded window (`ShardRuntime.prefetch`, FSDP2-like at 1) -- and the fp32
+    reduce-scatter-averages at the world sizes the driver's scaling run uses (model.py:523-541), on gloo: every
+    rank must end up with its slice of the single-process batch-mean gradient and AdamW update."""
+    _run_two_ranks(_worker, prefetch, world=world)

@@ -184,6 +184,27 @@ def test_c2_dit_b_two_blocks_residual_v(vds, parity_log):
 LAMBDA_ERR = 1e-4  # measured worst 4.1e-5 (gpurun_out/parity_report.jsonl, DiT-XL depth 6)
 
 
+# -------------------------------------------------------------------------------- C3a ----
+@pytest.mark.timeout(900)
+def test_c3a_literal_shape_block_vs_oracle(vds, parity_log):
+    """BASELINE configs[2] literally: DiT-XL width (16 heads of 72) on latent [1,16,17,32,32] -- an ODD frame count,
+    which only round-trips with `time_patch_size=1` (model.py:283; with pt=2 the Conv3d floors T to 16 and the
+    unpatchify of model.py:392-401 no longer matches the latent) -> 17*16*16 = 4352 video tokens + 16 registers,
+    context [512,4096].  Two blocks (block 1 mixes block 0's V) + embed / final layers against the fp32 oracle:
+    output, loss, every gradient, the last block's sub-layer outputs."""
+    cfg = O.DiTConfig(in_channels=16, patch_size=2, time_patch_size=1, hidden_size=1152, depth=2, num_heads=16,
+                      cross_attn_input_size=4096, residual_v=True, train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=61, randomize_zero_init=True, init_std_factor=0.1)
+    x, ctx, t, v = make_inputs((1, 16, 17, 32, 32), 512, 4096, 62, 0.5)
+    start = (100, 3, 57)  # 17 frames from t = 100: the RoPE time axis is used up to row 116 of its 128
+    ref = oracle_step(cfg, P, x, ctx, t, v, start)
+    m = build(vds, cfg, P)
+    fig = check_step(vds, m, x, ctx, t, v, start, ref, GRAD_COS, GRAD_REL, log=(parity_log, "c3a_literal_shape"))
+    assert len(fig["lambda_param"]) == 1
+    out = m(x.cuda(), ctx.cuda(), t.cuda(), rope_start=start)
+    assert tuple(out.shape) == (1, 16, 17, 32, 32)
+
+
 # ---------------------------------------------------------------------------- C3b / C5 ----
 @pytest.fixture(scope="module")
 def headline():

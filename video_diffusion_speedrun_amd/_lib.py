@@ -59,7 +59,7 @@ class ProfStat(C.Structure):
     _fields_ = [("launches", c_i64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-PROF_NCLASS = 20
+PROF_NCLASS = 21
 
 
 class AdamWTensor(C.Structure):

@@ -590,7 +590,11 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
 // ===================================== dQ ===================================================
 // Workgroup = 128 queries (4 waves x 2 column blocks of 16), Q / dO rows as B operands in registers, the query's
 // 8 - lse2 as the exponent's addend and -delta' as the dP accumulator's start; K / V tiles of 128 keys by LDS-DMA.
-// Keys past Lk are zero rows of K: whatever dS they get multiplies a zero column of K^T.
+// Keys past Lk are zero rows of K, but their dS is NOT harmless: S = 8 - lse2 + 0 there, so P = 2^(8 - lse2), and for a
+// query whose lse2 is a few units negative P (dP - delta) leaves the e5m2 range -- the cast does not saturate, inf (or
+// NaN) times the zero column of K^T is NaN inside the MFMA and poisons the whole dQ row.  The last, partly filled tile
+// therefore runs the RAGGED instantiation, which forces dS = 0 for key index >= Lk before the pack (the forward kernel
+// masks the same keys with -inf); full tiles pay nothing.
 // NW = 6 (192 queries per workgroup, VDS_ATTN8_DQ_WAVES=6): the kernel needs <= 168 registers, so three waves fit on a
 // SIMD with two workgroups of six waves.  Measured SLOWER than NW = 4 (2.7 vs 2.0 ms at B=6, L=8208): kept as an
 // experiment only.
@@ -650,9 +654,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
   __syncthreads();
 
   // NCB: 16-query blocks of this wave that hold queries (see attn8_bwd_dkv_kernel)
-  auto kv_tile = [&](int j, auto PAR, auto NCBT) {
+  auto kv_tile = [&](int j, auto PAR, auto NCBT, auto RAG) {
     constexpr int par = decltype(PAR)::value;
     constexpr int NCB = decltype(NCBT)::value;
+    constexpr bool ragged = decltype(RAG)::value;
+    const int key_lim = p.Lk - j * 128 - 32 * g;  // keys of this lane's 32-row range that exist: [0, key_lim)
     if (j + 1 < nkt && wave < 4) {
       char* nk = smem + (par ^ 1) * 2 * TILE;
       st.issue(rk, nk, (unsigned)(j + 1) * TILE, wave);
@@ -695,7 +701,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
       for (int cb = 0; cb < NCB; ++cb) {
         f32x4 ds;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(s[cb][r]) * dp[cb][r];  // P (dP - delta) / (s_do s_v)
+        for (int r = 0; r < 4; ++r) {
+          ds[r] = __builtin_amdgcn_exp2f(s[cb][r]) * dp[cb][r];  // P (dP - delta) / (s_do s_v)
+          if constexpr (ragged) {
+            if (4 * i + r >= key_lim) ds[r] = 0.f;  // accumulator register r of block i = tile row 32 g + 4 i + r
+          }
+        }
         dsq[cb][i] = cvt4_e5m2(ds);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -716,10 +727,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
     VDS_WAIT_VM(0);
     __syncthreads();
   };
+  const bool last_ragged = (p.Lk & 127) != 0;
+  const int n_full = last_ragged ? nkt - 1 : nkt;
   auto run = [&](auto NCBT) {
-    for (int j = 0; j < nkt; j += 2) {
-      kv_tile(j, std::integral_constant<int, 0>{}, NCBT);
-      if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{}, NCBT);
+    int j = 0;
+    for (; j + 1 < n_full; j += 2) {
+      kv_tile(j, std::integral_constant<int, 0>{}, NCBT, std::false_type{});
+      kv_tile(j + 1, std::integral_constant<int, 1>{}, NCBT, std::false_type{});
+    }
+    if (j < n_full) {
+      kv_tile(j, std::integral_constant<int, 0>{}, NCBT, std::false_type{});
+      if (last_ragged) kv_tile(j + 1, std::integral_constant<int, 1>{}, NCBT, std::true_type{});
+    } else if (last_ragged) {
+      kv_tile(j, std::integral_constant<int, 0>{}, NCBT, std::true_type{});
     }
   };
   const int ncb = min(2, max(0, (p.Lq - (qt * (32 * NW) + wave * 32) + 15) >> 4));  // wave-uniform
@@ -829,6 +849,9 @@ __device__ __forceinline__ void qk_scales(const float* amax_prev, int stride, in
   const float cl = LOG2E / sqrtf((float)hd);
   int e = 1;
   if (aq > 0.f) (void)frexpf(448.0f * alpha_k / (cl * aq), &e);  // x = f 2^e, f in [0.5, 1): floor(log2 x) = e - 1
+  // the kernels pass 127 - E and 127 + 3 - E as E8M0 scale bytes: E is kept in [-120, 120] (extreme amax products
+  // only; alpha_q follows E, so q merely leaves its top binade there instead of wrapping the byte)
+  e = e - 1 < -120 ? -119 : e - 1 > 120 ? 121 : e;
   E = (float)(e - 1);
   alpha_q = cl * exp2f(E) / alpha_k;
 }
@@ -1211,7 +1234,8 @@ extern "C" int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const fl
     const char* e = getenv("VDS_ROPE_TILE");
     tile = e ? atoi(e) : 4;
   }
-  if (tile > 0 && hd == 72 && hdp == 96 && H <= 256 && L >= 8) {
+  if (tile > 0 && hd == 72 && hdp == 96 && H <= 256 && L >= 8 &&
+      ropestage::lds_bytes(tile == 2 ? 2 : tile == 8 ? 8 : 4, H * 72) <= 160 * 1024) {  // else: the element-wise kernel
     const long ntok = (long)B * L;
 #define ROPE8_TILE(T)                                                                                               \
   do {                                                                                                              \
@@ -1247,6 +1271,7 @@ extern "C" int vds_cross_qkv_fp8(const void* q, const void* kv, void* q8, void* 
   if (!q || !kv || !q8 || !k8 || !v8 || !amax_prev || !amax_cur || !deq || B < 1 || Lq < 1 || Lk < 1 || H < 1) return VDS_ERR_ARG;
   constexpr int T = 4;
   if (hd != 72 || H > 256 || Lq < T || Lk < T) return VDS_ERR_UNSUPPORTED;  // (a tile of T tokens spans at most two samples)
+  if ((T * 4 * H * 72 + 1023) / 1024 * 1024 > 160 * 1024) return VDS_ERR_UNSUPPORTED;  // the kv rows of a tile must fit the LDS
   hipStream_t s = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) {

@@ -28,7 +28,7 @@ static const char* kNames[VDS_PROF_NCLASS] = {"gemm_nt", "gemm_nn", "gemm_tn", "
                                               "attn_bwd_dkv", "attn_bwd_dq", "rmsnorm_mod_fwd", "rmsnorm_mod_bwd",
                                               "adamw", "qkv_rope_fwd", "qkv_rope_bwd", "gate_bwd",
                                               "attn_fwd_plain", "attn_bwd_dkv_plain", "attn_bwd_dq_plain", "gemm_fp8",
-                                              "attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq"};
+                                              "attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq", "fp8_quant"};
 
 extern "C" const char* vds_prof_class_name(int cls) { return (cls >= 0 && cls < VDS_PROF_NCLASS) ? kNames[cls] : ""; }
 

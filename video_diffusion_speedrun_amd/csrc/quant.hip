@@ -10,6 +10,7 @@
 // loads, 8-byte row-major stores, and the transposed copy through LDS with 4x4 byte transposes (v_perm_b32) so
 // that every global store instruction still writes 128 contiguous bytes per row.
 #include "common.h"
+#include "prof.h"
 #include "../../include/vds.h"
 
 namespace {
@@ -176,6 +177,7 @@ extern "C" int vds_transpose_fp8(const void* q, int64_t ldq, int32_t M, int32_t 
                                  vds_stream_t stream) {
   if (!q || !qt || M < 1 || K < 16 || (K & 15) || (ldq & 15) || (ldt & 3)) return VDS_ERR_ARG;
   const dim3 grid((K + QT - 1) / QT, (M + QT - 1) / QT);
+  vdsprof::Scope ps(VDS_PROF_FP8_QUANT, (hipStream_t)stream, 0.0, 2.0 * M * K);
   hipLaunchKernelGGL(transpose_u8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)q, (long)ldq, M,
                      K, (unsigned char*)qt, (long)ldt);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
@@ -184,6 +186,7 @@ extern "C" int vds_transpose_fp8(const void* q, int64_t ldq, int32_t M, int32_t 
 extern "C" int vds_absmax(const void* x, int64_t ldx, int32_t M, int32_t K, float* amax, vds_stream_t stream) {
   if (!x || !amax || M < 1 || K < 8 || (K & 7) || (ldx & 7)) return VDS_ERR_ARG;
   const dim3 grid((K + QT - 1) / QT, (M + QT - 1) / QT);
+  vdsprof::Scope ps(VDS_PROF_FP8_QUANT, (hipStream_t)stream, 0.0, 2.0 * M * K);
   hipLaunchKernelGGL(absmax_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, M, K, amax);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
@@ -195,6 +198,7 @@ extern "C" int vds_quant_fp8(const void* x, int64_t ldx, int32_t M, int32_t K, i
   if ((q && (ldq & 7)) || (qt && (ldt & 3))) return VDS_ERR_ARG;
   const dim3 grid((K + QT - 1) / QT, (M + QT - 1) / QT);
   hipStream_t s = (hipStream_t)stream;
+  vdsprof::Scope ps(VDS_PROF_FP8_QUANT, s, 0.0, (2.0 + (q ? 1.0 : 0.0) + (qt ? 1.0 : 0.0)) * M * K);
 #define GOQ(F, T)                                                                                                  \
   if (fmt == F && (qt != nullptr) == T) {                                                                          \
     hipLaunchKernelGGL((quant_kernel<F, T>), grid, dim3(256), 0, s, (const bf16_t*)x, (long)ldx, M, K, amax,      \

@@ -13,9 +13,12 @@ MI355X-first re-design of the same contract:
   * 288 GB of HBM per GPU: the gathered bf16 copy of EVERY group (2.3 GB for DiT-XL) stays
     resident from forward to backward, so the reference's backward re-all-gather
     (`reshard_after_forward`, model.py:525) is not needed at all -- all-gather traffic is halved;
-  * all gathers of a step are issued up-front, in use order, on a dedicated communication
-    stream; the compute stream waits on the per-group event right before the first kernel that
-    reads the group (prefetch depth = everything);
+  * the gathers of a step are issued in use order on a dedicated communication stream; the compute stream
+    waits on the per-group event right before the first kernel that reads the group.  By default ALL of them
+    are issued up-front (prefetch depth = everything: the links are busy for the first 11-78 ms of the step and
+    idle afterwards); `VDS_AG_PREFETCH=d` (or `ShardRuntime.prefetch = d`) bounds the window to d groups beyond
+    the one in use, i.e. group i + d is issued when block i starts -- FSDP2's behaviour is d = 1 -- so that the
+    first multi-GPU run can A/B the burst against a spread (RCCL's kernels take workgroup slots while they run);
   * each group's reduce-scatter is issued on the communication stream as soon as that group's
     last weight-gradient kernel is queued, overlapping with the backward of the next block;
   * world_size == 1 works (no communication, no streams) -- the reference cannot
@@ -72,6 +75,10 @@ class ShardRuntime:
         prio = int(os.environ.get("VDS_COMM_PRIORITY", "0"))
         self.comm = torch.cuda.Stream(device=model._groups[0].device, priority=prio) if self.cuda else None
         self.gather_ev = [None] * len(model._groups)
+        self.world = model._world
+        # all-gather window: 0 = issue every group's gather up-front; d > 0 = at most d groups ahead of the one in use
+        self.prefetch = max(0, int(os.environ.get("VDS_AG_PREFETCH", "0")))
+        self._next_gather = len(model._groups)  # first group whose gather has not been issued in this forward
         self.n_all_gather = 0
         self.n_reduce_scatter = 0
         # measure=True: bracket every point where the compute stream waits for the communication stream with an
@@ -126,20 +133,36 @@ class ShardRuntime:
         self.n_reduce_scatter += 1
 
     # ---- forward --------------------------------------------------------------------------
-    def pre_forward_root(self):
-        """issue the bf16 cast + all-gather of every group, in use order, on the comm stream"""
-        self._comm_waits_compute()  # the optimizer step that wrote master / shadow is done
+    def _issue_gathers(self, upto: int):
+        """bf16 cast + all-gather of the groups [_next_gather, upto) on the comm stream, one event per group.  A
+        gather reads the group's bf16 shadow (written by the optimizer step, which the comm stream has waited for in
+        pre_forward_root) and writes its gathered copy, whose last readers -- the previous step's backward kernels --
+        are older than that optimizer step: no further wait on the compute stream is needed"""
+        upto = min(upto, len(self.model._groups))
+        if self._next_gather >= upto:
+            return
         with self._on_comm():
-            for gi, g in enumerate(self.model._groups):
-                g.gather(self.cast_fn, self.pg)
+            for gi in range(self._next_gather, upto):
+                self.model._groups[gi].gather(self.cast_fn, self.pg)
                 self.n_all_gather += 1
                 if self.cuda:
                     ev = torch.cuda.Event()
                     ev.record(self.comm)
                     self.gather_ev[gi] = ev
+        self._next_gather = upto
+
+    def pre_forward_root(self):
+        """issue the bf16 cast + all-gather of the first groups (all of them unless `prefetch` bounds the window), in
+        use order, on the comm stream"""
+        self._comm_waits_compute()  # the optimizer step that wrote master / shadow is done
+        self._next_gather = 0
+        n = len(self.model._groups)
+        self._issue_gathers(n if self.prefetch == 0 else 1 + self.prefetch)  # root + the first `prefetch` blocks
         self._compute_waits(0)
 
     def pre_forward_block(self, i: int):
+        if self.prefetch:
+            self._issue_gathers(1 + i + 1 + self.prefetch)  # keep `prefetch` groups beyond block i in flight
         self._compute_waits(1 + i)
 
     def post_forward_block(self, i: int):

@@ -25,7 +25,12 @@ capturing stream (`comm.wait_stream(compute)`), the per-group bf16 all-gathers a
 on that stream (RCCL collectives are capturable), the compute stream joins on the per-group events, and the final
 `wait_stream` closes the fork before the capture ends.  Every rank captures and replays the same sequence.  The
 exposed-communication measurement (timing events) is off inside a capture.  Proven on one GPU with the runtime
-forced on over a 1-rank RCCL group (tests/test_model_gpu.py::test_graph_replay_with_the_sharding_runtime).
+forced on over a 1-rank RCCL group (tests/test_model_gpu.py::test_graph_replay_with_the_sharding_runtime).  A capture
+over MORE than one rank has never run (no multi-GPU box in this pool): it is refused unless the caller passes
+`multi_rank_capture=True`, so that nobody gets an untested path by default.
+
+A captured graph bakes in device pointers (static batch buffers, the fp8 amax tables, the activation buffers the
+allocator handed out): `step()` refuses a batch whose latent / context shape differs from the captured one.
 """
 from __future__ import annotations
 
@@ -41,9 +46,15 @@ bf16 = torch.bfloat16
 class GraphedTrainStep:
     """`step(batch) -> loss` with the semantics of `train.train_step` (train.py:412-434)."""
 
-    def __init__(self, dit_model, optimizer, lr_scheduler, device, eager_steps: int = 2):
+    def __init__(self, dit_model, optimizer, lr_scheduler, device, eager_steps: int = 2,
+                 multi_rank_capture: bool = False):
         if eager_steps < 1:
             raise ValueError("at least one eager step is needed before the capture (descriptor tables, shadows)")
+        fs = getattr(dit_model, "_fsdp", None)
+        if fs is not None and getattr(fs, "world", 1) > 1 and not multi_rank_capture:
+            raise RuntimeError("GraphedTrainStep over a model sharded across more than one rank is untested (only a "
+                               "1-rank RCCL group on one GPU has captured and replayed the sharding runtime); pass "
+                               "multi_rank_capture=True to try it")
         self.model, self.opt, self.sched = dit_model, optimizer, lr_scheduler
         self.device = torch.device(device)
         self.eager_left = eager_steps

@@ -361,7 +361,7 @@ class DiTBlock(nn.Module):
         if a8:
             r0 = F8.ROWS * i + F8.ROW_Q
             deq = torch.empty(8, dtype=f32, device=dev)  # {s_q, s_k, s_v, s_do, E}: include/vds.h, vds_attn_fp8_args
-            cur = fp8_hist.tab[r0:r0 + 3, 1] if save else fp8_hist.scratch(3)  # (no-grad forwards record nothing)
+            cur = fp8_hist.tab[r0:r0 + 3, 1] if save else fp8_hist.scratch(5)[0::2]  # (no-grad forwards record nothing; the producers write elements 0, 2, 4 at amax_stride 2)
             q8, k8, v8, v = ops.qkv_rope_fwd_fp8(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None,
                                                  B, L, H, hd, hdp, fp8_hist.tab[r0:r0 + 3, 0], cur, 2, deq,
                                                  want_v=self.residual_v and v0 is None)
@@ -415,7 +415,7 @@ class DiTBlock(nn.Module):
             if c8:
                 rc = R0 + F8.ROW_QC
                 deqc = torch.empty(8, dtype=f32, device=dev)
-                cur = fp8_hist.tab[rc:rc + 3, 1] if save else fp8_hist.scratch(3)
+                cur = fp8_hist.tab[rc:rc + 3, 1] if save else fp8_hist.scratch(5)[0::2]
                 qc8, kc8, vc8 = ops.cross_qkv_fp8(qc, ckv, B, L, Lc, H, hd, fp8_hist.tab[rc:rc + 3, 0], cur, 2, deqc)
                 ops.attn_fp8_fwd(qc8, kc8, vc8, deqc, ops.heads_view(catt, B, L, H, hd), lse2, hd)
             else:
@@ -660,7 +660,7 @@ class DiT(nn.Module):
         self.in_channels = self.out_channels = in_channels
         self.patch_size, self.time_patch_size = patch_size, time_patch_size
         self.hidden_size, self.num_heads, self.depth, self.mlp_ratio = hidden_size, num_heads, depth, mlp_ratio
-        self.use_rope = use_rope  # the reference always applies RoPE; kept for signature parity
+        self.use_rope = use_rope
         self.residual_v = residual_v
         self.cross_attn_input_size = cross_attn_input_size
         self.head_dim = hidden_size // num_heads
@@ -669,7 +669,14 @@ class DiT(nn.Module):
                              f"({sorted(HDP_OF)}: DiT-S/B = 64, DiT-XL = 72, the reference's sweep = 128, its smoke "
                              "test = 32); the kernels are templates on the padded head dim, see csrc/attention.hip")
         self.patch_embed = PatchEmbed(patch_size, in_channels, hidden_size, time_patch_size)
-        self.rope = ThreeDimRotary(hidden_size // (2 * num_heads), h=128, w=128, t=128)
+        if use_rope:
+            self.rope = ThreeDimRotary(hidden_size // (2 * num_heads), h=128, w=128, t=128)
+        else:
+            # model.py:312-314: without RoPE the reference registers a learned table it never reads -- its forward
+            # calls self.rope unconditionally (model.py:364) and raises AttributeError.  The parameter is
+            # kept so that such a model's state dict (and train.py:287's constant class "positional_embedding") round
+            # trips with strict loading; forward refuses like the reference does.
+            self.positional_embedding = nn.Parameter(torch.zeros(1, 2048, hidden_size))
         self.register_tokens = nn.Parameter(torch.randn(1, N_REG, hidden_size))
         self.time_embed = nn.Sequential(_Linear(hidden_size, 4 * hidden_size), _Act("silu"),
                                         _Linear(4 * hidden_size, hidden_size))
@@ -767,6 +774,10 @@ class DiT(nn.Module):
         """x [B,C,T,H,W], context [B,Lc,Cc], timesteps [B] -> [B,C,T,H,W] bf16 (model.py:358-402)."""
         if not x.is_cuda:
             raise RuntimeError("video_diffusion_speedrun_amd.DiT runs on the GPU only (no CPU fallback)")
+        if not self.use_rope:
+            raise AttributeError("'DiT' object has no attribute 'rope': a DiT built with use_rope=False cannot run -- the "
+                                 "reference's forward calls self.rope unconditionally (model.py:364) and fails the same "
+                                 "way; the model only exists to hold / convert such a checkpoint")
         b, c, t, h, w = x.shape
         thw = (t // self.time_patch_size, h // self.patch_size, w // self.patch_size)
         if rope_start is None:
