@@ -188,16 +188,22 @@ def test_attn_fp8_backward_is_finite_when_every_score_is_very_negative(ops, pari
     # fp64 attention on the dequantised operands (on the device: 8208^2 scores per head), dO as quantised
     qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (qd, kd, vd))
     s = (qr @ kr.transpose(-1, -2)) / math.sqrt(HD)
+    s.retain_grad()
     out = torch.softmax(s, dim=-1) @ vr
     out.backward(doq.float()[..., :HD].double() * deq[3].item())
     figs = {}
     for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         figs[name + "_rel"], figs[name + "_cos"] = rel(got[..., :HD], ref), cos(got[..., :HD], ref)
+    # With a near-uniform softmax and near-constant K rows, dQ = sum_k dS[q,k] K[k] / sqrt(hd) is what is left of terms that
+    # cancel (sum_k dS[q,k] = 0 exactly): its natural error scale is the sum of the |terms|, not the cancelled sum -- the
+    # e5m2 rounding of every dS (2 mantissa bits) is an error of ~2^-3 of its term.  (dK sums over queries with
+    # independent dO and does not cancel this way.)
+    terms = (s.grad.abs() @ kd.double().abs()) / math.sqrt(HD)
+    figs["dq_err_over_terms"] = ((dq[..., :HD].double() - qr.grad).norm() / terms.norm()).item()
     parity_log("attn_fp8_bwd_negative_scores", L=L, Lk=Lk, **figs)
-    # near-uniform softmax: dS = P (dP - delta) is a difference of nearly equal terms, so dQ / dK are small and carry the
-    # e5m2 rounding of dS in full; dV has no such cancellation
     assert figs["dv_rel"] <= 4e-2 and figs["dv_cos"] >= 0.999, figs
-    assert figs["dq_cos"] >= 0.98 and figs["dk_cos"] >= 0.98, figs
+    assert figs["dk_rel"] <= 1.2e-1 and figs["dk_cos"] >= 0.993, figs
+    assert figs["dq_err_over_terms"] <= 2e-2, figs  # ~2^-3 / sqrt(#keys) per element for independent roundings
 
 
 @pytest.mark.parametrize("L", [200, 203], ids=["L200", "L203_tiles_straddle_samples"])

@@ -56,9 +56,17 @@ def _small_ints(M, K, seed, vals):
     return v[torch.randint(0, len(vals), (M, K), generator=g)]
 
 
+@pytest.fixture(params=[0, 256, 192], ids=["auto", "t256", "t256x192"])
+def tile8(request, ops):
+    """the fp8 GEMM under the dispatcher's choice and with the 256 x 256 / 256 x 192 (round 4) output tiles pinned"""
+    ops.gemm_force_tile(request.param)
+    yield request.param
+    ops.gemm_force_tile(0)
+
+
 @pytest.mark.parametrize("a_fmt", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(300, 264, 272), (256, 256, 128), (1000, 520, 1152), (16, 8, 16)])
-def test_gemm_fp8_exact_on_small_integers(ops, a_fmt, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(300, 264, 272), (256, 256, 128), (1000, 520, 1152), (16, 8, 16), (700, 1152, 400)])
+def test_gemm_fp8_exact_on_small_integers(ops, tile8, a_fmt, M, N, K):
     """operands exactly representable in both fp8 formats, products and fp32 sums exact: the lane maps of
     v_mfma_f32_16x16x128_f8f6f4, the K tail and ragged tiles must give the exact matrix product"""
     from video_diffusion_speedrun_amd._lib import EPI_F32, EPI_STORE
@@ -102,7 +110,7 @@ def test_linear_fp8_close_to_bf16_linear(ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(304, 264, 144), (1024, 4608, 1152)])
-def test_gemm_epilogue_emits_fp8_copies(ops, M, N, K):
+def test_gemm_epilogue_emits_fp8_copies(ops, tile8, M, N, K):
     """vds_fp8_out: the fc1 epilogue (bias + GELU) and the fc2-dgrad epilogue (gelu') write their result as fp8
     row-major + transposed, record its amax and (dgrad) its column sums -- bit-identical to quantising the bf16
     result in a separate pass with the same scale."""

@@ -53,10 +53,10 @@ def test_lane_maps(ops):
 
 
 # ------------------------------------------------------------------------------- GEMM ----
-@pytest.fixture(params=[0, 128, 256, 2], ids=["auto", "t128", "t256", "t256x128"])
+@pytest.fixture(params=[0, 128, 256, 2, 192], ids=["auto", "t128", "t256", "t256x128", "t256x192"])
 def tile(request, ops):
-    """every GEMM test runs under the dispatcher's own choice and with each of the three tilings pinned
-    (vds_gemm_force_tile): 128x128, 256x256 and 256x128 (two workgroups per CU)"""
+    """every GEMM test runs under the dispatcher's own choice and with each of the four tilings pinned
+    (vds_gemm_force_tile): 128x128, 256x256, 256x128 (two workgroups per CU) and 256x192 (round 4)"""
     ops.gemm_force_tile(request.param)
     yield request.param
     ops.gemm_force_tile(0)

@@ -44,6 +44,7 @@ struct GemmP {
   const bf16_t* aux; long ldaux;
   const float* gate; long ldgate;
   int rows_per_batch;
+  int row_base;    // GATE_RES: index of this launch's row 0 in the whole matrix (row-peeled launches; gate row = (row + base) / rows_per_batch)
   int split_k;
   int atomic;
   unsigned a_bytes, b_bytes;
@@ -209,21 +210,23 @@ __device__ __forceinline__ unsigned cvt4_fp8(int fmt, float a, float b, float c,
 // The aux operand of a fused epilogue (GATE_RES: the residual stream, DGELU: the saved pre-activation) is requested
 // for all 8 row groups of the sub-tile BEFORE the accumulators are staged through LDS, so that the 8 loads are in
 // flight together and under the staging instead of one exposed HBM round trip per row group behind the stores.
-template <int EPI>
+// WC: columns of the staged sub-tile that exist (64; 48 in the 256 x 192 tiling, whose lanes c8 >= 6 idle)
+template <int EPI, int WC = 64>
 __device__ __forceinline__ void epilogue_prefetch(const GemmP& p, int row0, int col0, int lane, u32x4 (&auxr)[8]) {
   if constexpr (EPI == VDS_EPI_GATE_RES || EPI == VDS_EPI_DGELU) {
     const int c8 = lane & 7, rin = lane >> 3;
     const int gcol = col0 + c8 * 8;
+    const bool cok = gcol < p.N && (WC == 64 || c8 * 8 < WC);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const long grow = row0 + it * 8 + rin;
-      auxr[it] = (grow < p.M && gcol < p.N) ? *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol)
-                                            : u32x4{0u, 0u, 0u, 0u};
+      auxr[it] = (grow < p.M && cok) ? *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol)
+                                     : u32x4{0u, 0u, 0u, 0u};
     }
   }
 }
 
-template <int EPI, bool EMIT = false, bool LUT = false>
+template <int EPI, bool EMIT = false, bool LUT = false, int WC = 64>
 __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int row0, int col0, int lane,
                                                float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8],
                                                const char* lut = nullptr) {
@@ -232,7 +235,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
       // split-K / accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256
       // contiguous bytes, the full-rate shape of global_atomic_add_f32 on gfx950)
       const int acol = col0 + lane;
-      if (acol < p.N) {
+      if (acol < p.N && lane < WC) {
         float* cbase = reinterpret_cast<float*>(p.C) + (long)row0 * p.ldc + acol;
         const int rmax = min(64, p.M - row0);
         for (int row = 0; row < rmax; ++row) atomicAdd(cbase + (long)row * p.ldc, stg[row * EPI_LD + lane]);
@@ -242,10 +245,10 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
   }
   const int c8 = lane & 7, rin = lane >> 3;
   const int gcol = col0 + c8 * 8;
+  const bool col_ok = gcol < p.N && (WC == 64 || c8 * 8 < WC);
   if constexpr (!EMIT) {
-    if (gcol >= p.N) return;
+    if (!col_ok) return;
   }
-  const bool col_ok = gcol < p.N;
   [[maybe_unused]] float e_max = 0.f, e_scale = 1.f, e_fmax = 448.f;
   [[maybe_unused]] const bool emit = EMIT && (p.e_q || p.e_qt);
   if constexpr (EMIT) {
@@ -296,7 +299,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
       if (p.C2) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + grow * p.ldc2 + gcol) = o2;
       if constexpr (EMIT) ev = o2;
     } else if constexpr (EPI == VDS_EPI_GATE_RES) {
-      const int b = (int)(grow / p.rows_per_batch);
+      const int b = (int)((grow + p.row_base) / p.rows_per_batch);
       const float* gp = p.gate + (long)b * p.ldgate + gcol;
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp);
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(gp + 4);
@@ -361,11 +364,20 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
 // results as epilogue_64x64<.., LUT = true>.  e_max: running |max| of the emitted values (the caller folds it).
 // The bf16 results leave with non-temporal stores: each is 0.2-0.9 GB written once and read by a later kernel from HBM
 // anyway, and keeping it out of the way of the operands in L2 / MALL measured -4.5 ms (bf16) / -6.5 ms (fp8) per step.
-template <int EPI, int EFMT, bool C1, bool C2, bool EQ, bool CS>
+template <int EPI, int EFMT, bool C1, bool C2, bool EQ, bool CS, int WC = 64>
 __device__ __forceinline__ void epilogue_full(const GemmP& p, const float* stg, const char* lut, int row0, int col0, int lane,
                                               float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8], float e_scale,
                                               float& e_max) {
   const int c8 = lane & 7, rin = lane >> 3;
+  if constexpr (WC < 64) {
+    if (c8 * 8 >= WC) {  // 256 x 192 tiling: the wave's sub-tile is 48 columns wide, lanes of chunks 6, 7 have no columns
+      if constexpr (EQ) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) ew[it] = u32x2{0u, 0u};
+      }
+      return;
+    }
+  }
   const int gcol = col0 + c8 * 8;
   const long grow0 = row0 + rin;
   f32x2 bias[4];
@@ -380,7 +392,7 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, const float* stg, 
   }
   [[maybe_unused]] f32x2 g[4];
   if constexpr (EPI == VDS_EPI_GATE_RES) {
-    const float* gp = p.gate + (long)(row0 / p.rows_per_batch) * p.ldgate + gcol;
+    const float* gp = p.gate + (long)((row0 + p.row_base) / p.rows_per_batch) * p.ldgate + gcol;
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
     g[0] = f32x2{g0[0], g0[1]}; g[1] = f32x2{g0[2], g0[3]}; g[2] = f32x2{g1[0], g1[1]}; g[3] = f32x2{g1[2], g1[3]};
   }
@@ -455,7 +467,7 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, const float* stg, 
 }
 
 // picks the specialisation for the outputs this launch has; false = not covered (the caller takes epilogue_64x64)
-template <int EPI, bool EMIT>
+template <int EPI, bool EMIT, int WC = 64>
 __device__ __forceinline__ bool epilogue_full_dispatch(const GemmP& p, const float* stg, const char* lut, int row0, int col0,
                                                        int lane, float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8],
                                                        float e_scale, float& e_max) {
@@ -466,7 +478,7 @@ __device__ __forceinline__ bool epilogue_full_dispatch(const GemmP& p, const flo
     eany = p.e_q || p.e_qt;
     csum = p.e_colsum != nullptr;
   }
-#define VDS_FULL(E, F, A, B, Q, S) epilogue_full<E, F, A, B, Q, S>(p, stg, lut, row0, col0, lane, cs, ew, auxr, e_scale, e_max)
+#define VDS_FULL(E, F, A, B, Q, S) epilogue_full<E, F, A, B, Q, S, WC>(p, stg, lut, row0, col0, lane, cs, ew, auxr, e_scale, e_max)
   if constexpr (EPI == VDS_EPI_STORE) {
     VDS_FULL(EPI, 0, true, false, false, false);
     return true;
@@ -620,44 +632,79 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 // K tiles past the end of the contraction (and the K tail) are fetched as zeros through the SRD
 // bounds, which keeps the wait counts uniform to the last iteration.
 namespace big {
-constexpr int BM = 256, BN = 256;
+constexpr int BM = 256;
 constexpr int HALF = 16384;                                 // one half-tile
-constexpr int SLOT_A0 = 0, SLOT_A1 = HALF, SLOT_B0 = 2 * HALF, SLOT_B1 = 3 * HALF, BUF = 4 * HALF;
 constexpr int LDS_BYTES = 8 * 64 * EPI_LD * 4;               // 139264 >= 2 * BUF (131072)
+// Geometry of the two output-tile widths.  WN = 256: the four-half-tile scheme described above.  WN = 192 (round 4):
+// a wave owns 128 x 48 outputs = 2 quadrant rows x (one 32-column + one 16-column block); B is staged as B0 = the
+// 32-column blocks of the four wave columns (128 rows, 16 KiB) and B1 = their 16-column blocks (64 rows, 8 KiB),
+// and a K tile is consumed in THREE phases of 16 MFMAs  (A0,B0) -> B1 with both A halves -> (A1, B0 from registers).
+// 1152 = 6 x 192 (and 3456 = 18, 4608 = 24): the N = 1152 linears of DiT-XL lose the half-empty fifth column of
+// 256-wide tiles (10 % of their MFMA work).
+template <int WN> struct Geo;
+template <> struct Geo<256> {
+  static constexpr int BN = 256, WCOLS = 64, NJ = 4, A0 = 0, A1 = HALF, B0 = 2 * HALF, B1 = 3 * HALF, BUF = 4 * HALF;
+};
+template <> struct Geo<192> {
+  static constexpr int BN = 192, WCOLS = 48, NJ = 3, A0 = 0, A1 = HALF, B0 = 2 * HALF, B1 = 3 * HALF, BUF = 3 * HALF + HALF / 2;
+};
 
-// local index (row of a k-contiguous half-tile, or 8-column chunk base of a k-major one) -> offset
-// inside the 256-wide tile: groups of G consecutive indices alternate between the two halves
-template <int G>
-__device__ __forceinline__ int to_tile(int local, int half) { return (local / G) * (2 * G) + half * G + (local % G); }
+// local index (row of a k-contiguous half-tile, or 8-column chunk base of a k-major one) -> offset inside the output
+// tile: groups of G consecutive indices, STRIDE apart, starting at OFF (256-wide: halves alternate in groups of 64 rows /
+// 32 columns; 192-wide B: 32-column groups at 48 w, 16-column groups at 48 w + 32)
+template <int G, int STRIDE, int OFF>
+__device__ __forceinline__ int to_tile(int local) { return (local / G) * STRIDE + OFF + (local % G); }
 
-// per-lane source byte offsets of the two 1-KiB pieces this wave stages of one half-tile
-template <bool KMAJOR, int G>
-__device__ __forceinline__ void half_offsets(unsigned (&voff)[2], int (&kchunk)[2], int wave, int lane, long ld,
-                                             int origin, int half) {
+// k-major [64 k][64 cols] quarter tile (B1 of the 192-wide tiling in NN problems): 128-byte rows, two k rows per 256-byte
+// bank row; 32-byte segment c of row k is stored at segment c ^ swz_km64(k), which makes the 8 rows x 32 B a
+// ds_read_b64_tr_b16 half-wave touches land on 8 different 32-byte bank groups
+__device__ __forceinline__ int swz_km64(int krow) { return ((krow >> 1) & 1) | (((krow >> 3) & 1) << 1); }
+__device__ __forceinline__ bf16x8 frag_km64(const char* tile, int col0, int ks, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int krow = ks * 32 + 8 * g + (i >> 2);
+  const int seg = (col0 >> 4) ^ swz_km64(krow);
+  const char* p = tile + krow * 128 + seg * 32 + (i & 3) * 8;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 4 * 128));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// per-lane source byte offsets of the NP 1-KiB pieces this wave stages of one half-tile (NP = 2: 16 KiB) or quarter
+// tile (NP = 1: the 8-KiB B1 of the 192-wide tiling)
+template <bool KMAJOR, int G, int STRIDE, int OFF, int NP>
+__device__ __forceinline__ void half_offsets(unsigned (&voff)[NP], int (&kchunk)[NP], int wave, int lane, long ld,
+                                             int origin) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = wave * 2 + j;
+  for (int j = 0; j < NP; ++j) {
+    const int q = wave * NP + j;
     if constexpr (!KMAJOR) {
       const int row = q * 8 + (lane >> 3);
       const int chunk = swz_kc(row, lane & 7);
       kchunk[j] = chunk * 8;
-      voff[j] = (unsigned)(((long)(origin + to_tile<G>(row, half)) * ld + chunk * 8) * 2);
-    } else {
+      voff[j] = (unsigned)(((long)(origin + to_tile<G, STRIDE, OFF>(row)) * ld + chunk * 8) * 2);
+    } else if constexpr (NP == 2) {
       const int krow = q * 4 + (lane >> 4);
       const int pc = lane & 15;
       const int chunk = (((pc >> 1) ^ swz_km(krow)) << 1) | (pc & 1);
       kchunk[j] = 0;
-      voff[j] = (unsigned)(((long)krow * ld + origin + to_tile<G>(chunk * 8, half)) * 2);
+      voff[j] = (unsigned)(((long)krow * ld + origin + to_tile<G, STRIDE, OFF>(chunk * 8)) * 2);
+    } else {
+      const int krow = q * 8 + (lane >> 3);
+      const int pc = lane & 7;
+      const int chunk = (((pc >> 1) ^ swz_km64(krow)) << 1) | (pc & 1);
+      kchunk[j] = 0;
+      voff[j] = (unsigned)(((long)krow * ld + origin + to_tile<G, STRIDE, OFF>(chunk * 8)) * 2);
     }
   }
 }
 
-template <bool KMAJOR>
-__device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigned (&voff)[2],
-                                           const int (&kchunk)[2], unsigned koff, int krem, int wave) {
-  const unsigned base = lds_addr_of(slot) + wave * 2048;
+template <bool KMAJOR, int NP = 2>
+__device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigned (&voff)[NP],
+                                           const int (&kchunk)[NP], unsigned koff, int krem, int wave) {
+  const unsigned base = lds_addr_of(slot) + wave * (NP * 1024);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NP; ++j) {
     unsigned off = voff[j] + koff;
     if constexpr (!KMAJOR) {
       if (kchunk[j] >= krem) off = 0xfffffff0u;  // K tail / tiles past the range: zeros
@@ -672,10 +719,14 @@ __device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigne
 // 128 k instead of 64, one v_mfma_f32_16x16x128_f8f6f4 replaces two 16x16x32 bf16 MFMAs in the same 32 cycles --
 // bytes staged, LDS reads and the phase schedule are identical, the contraction per K tile doubles.  The
 // addressing below counts in 2-byte units (p.K, lda, ldb = bytes / 2).
-template <int LAYOUT, int EPI, int FMT = 0>
+template <int LAYOUT, int EPI, int FMT = 0, int WN = 256>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(FMT == 0 || LAYOUT == VDS_NT, "fp8 operands are k-contiguous (transposed copies are made by the quantiser)");
+  using G = Geo<WN>;
+  constexpr int BN = G::BN, WCOLS = G::WCOLS, NJ = G::NJ, BUF = G::BUF;
+  constexpr int SLOT_A0 = G::A0, SLOT_A1 = G::A1, SLOT_B0 = G::B0, SLOT_B1 = G::B1;
+  constexpr int NPB1 = WN == 256 ? 2 : 1;  // 1-KiB pieces per wave of the B1 half / quarter tile
   constexpr bool A_KM = (LAYOUT == VDS_TN);
   constexpr bool B_KM = (LAYOUT != VDS_NT);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -717,12 +768,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     lds_dma16(rl, lb, (unsigned)(wave * 2048 + lane * 16));
     lds_dma16(rl, lb + 1024, (unsigned)(wave * 2048 + 1024 + lane * 16));
   }
-  unsigned va[2][2], vb[2][2];
-  int ca[2][2], cb[2][2];
-#pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    half_offsets<A_KM, 64>(va[hf], ca[hf], wave, lane, p.lda, m0, hf);
-    half_offsets<B_KM, 32>(vb[hf], cb[hf], wave, lane, p.ldb, n0, hf);
+  unsigned va[2][2], vb0[2], vb1[NPB1];
+  int ca[2][2], cb0[2], cb1[NPB1];
+  half_offsets<A_KM, 64, 128, 0, 2>(va[0], ca[0], wave, lane, p.lda, m0);
+  half_offsets<A_KM, 64, 128, 64, 2>(va[1], ca[1], wave, lane, p.lda, m0);
+  if constexpr (WN == 256) {
+    half_offsets<B_KM, 32, 64, 0, 2>(vb0, cb0, wave, lane, p.ldb, n0);
+    half_offsets<B_KM, 32, 64, 32, 2>(vb1, cb1, wave, lane, p.ldb, n0);
+  } else {
+    half_offsets<B_KM, 32, 48, 0, 2>(vb0, cb0, wave, lane, p.ldb, n0);
+    half_offsets<B_KM, 16, 48, 32, 1>(vb1, cb1, wave, lane, p.ldb, n0);
   }
   const unsigned a_step = A_KM ? (unsigned)(BK * p.lda * 2) : BK * 2;
   const unsigned b_step = B_KM ? (unsigned)(BK * p.ldb * 2) : BK * 2;
@@ -734,27 +789,24 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     char* buf = ring + par * BUF;
     if (which == 0) issue_half<A_KM>(ra, buf + SLOT_A0, va[0], ca[0], (unsigned)T * a_step, krem, wave);
     else if (which == 3) issue_half<A_KM>(ra, buf + SLOT_A1, va[1], ca[1], (unsigned)T * a_step, krem, wave);
-    else if (which == 1) issue_half<B_KM>(rb, buf + SLOT_B0, vb[0], cb[0], (unsigned)T * b_step, krem, wave);
-    else issue_half<B_KM>(rb, buf + SLOT_B1, vb[1], cb[1], (unsigned)T * b_step, krem, wave);
+    else if (which == 1) issue_half<B_KM>(rb, buf + SLOT_B0, vb0, cb0, (unsigned)T * b_step, krem, wave);
+    else issue_half<B_KM, NPB1>(rb, buf + SLOT_B1, vb1, cb1, (unsigned)T * b_step, krem, wave);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][NJ];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue: 7 half-tiles in flight, A0 / B0 of the first tile landed -------------------
-  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0);
-  issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1); issue(kt_begin + 1, 2, 1);
-  VDS_WAIT_VM(10);
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   constexpr int KS = FMT == 0 ? 2 : 1;  // MFMA k-steps per K tile
   using frag_t = std::conditional_t<FMT == 0, bf16x8, i32x8>;
-  frag_t fa[4][KS], fb0[2][KS], fb1[2][KS];
-  auto read_a = [&](const char* slot) {
+  auto mma = [&](const frag_t& a, const frag_t& b, f32x4 c) {
+    if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    // cbsz: format of A (0 e4m3, 1 e5m2), blgp: format of B; block scales unused (0 selects the unscaled form)
+    else return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, FMT == 2 ? 1 : 0, 0, 0, 0, 0, 0);
+  };
+  auto read_a4 = [&](const char* slot, frag_t (&fa)[4][KS]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -764,7 +816,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
         else fa[i][ks] = frag_kc(slot, wr * 64 + i * 16, ks, lane);
       }
   };
-  auto read_b = [&](const char* slot, frag_t (&fb)[2][KS]) {
+  auto read_b2 = [&](const char* slot, frag_t (&fb)[2][KS]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -774,11 +826,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
         else fb[j][ks] = frag_kc(slot, wc * 32 + j * 16, ks, lane);
       }
   };
-  auto mma = [&](const frag_t& a, const frag_t& b, f32x4 c) {
-    if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    // cbsz: format of A (0 e4m3, 1 e5m2), blgp: format of B; block scales unused (0 selects the unscaled form)
-    else return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, FMT == 2 ? 1 : 0, 0, 0, 0, 0, 0);
-  };
+
+  if constexpr (WN == 256) {
+  // ---- prologue: 7 half-tiles in flight, A0 / B0 of the first tile landed -------------------
+  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0);
+  issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1); issue(kt_begin + 1, 2, 1);
+  VDS_WAIT_VM(10);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
+
+  frag_t fa[4][KS], fb0[2][KS], fb1[2][KS];
 #define VDS_QUADRANT(QA, QB, FB)                                                                      \
   do {                                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                    \
@@ -794,8 +851,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     constexpr int par = decltype(PAR)::value;
     const char* buf = ring + par * BUF;
     // ---- phase 0: quadrant (0,0) <- A0, B0 ----
-    read_a(buf + SLOT_A0);
-    read_b(buf + SLOT_B0, fb0);
+    read_a4(buf + SLOT_A0, fa);
+    read_b2(buf + SLOT_B0, fb0);
     issue(T + 1, 3, par ^ 1);
     VDS_WAIT_LGKM0();
     VDS_WAIT_VM(10);  // B1(T) landed
@@ -803,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     VDS_QUADRANT(0, 0, fb0);
     __builtin_amdgcn_s_barrier();
     // ---- phase 1: quadrant (0,1) <- B1 ----
-    read_b(buf + SLOT_B1, fb1);
+    read_b2(buf + SLOT_B1, fb1);
     issue(T + 2, 0, par);
     VDS_WAIT_LGKM0();
     VDS_WAIT_VM(10);  // A1(T) landed
@@ -811,7 +868,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     VDS_QUADRANT(0, 1, fb1);
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: quadrant (1,1) <- A1 ----
-    read_a(buf + SLOT_A1);
+    read_a4(buf + SLOT_A1, fa);
     issue(T + 2, 1, par);
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
@@ -829,6 +886,81 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
   }
 #undef VDS_QUADRANT
+  } else {
+  // ---- 256 x 192: pieces per wave A0 2, B0 2, A1 2, B1 1, issued in the order A0 B0 (A1 B1) of every K tile --------
+  // prologue: the first tile and A0 / B0 of the second in flight (11 pieces), A0 / B0 of the first landed
+  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 3, 0); issue(kt_begin, 2, 0);
+  issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1);
+  VDS_WAIT_VM(7);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
+
+  frag_t fa0[4][KS], fa1[4][KS], fb0[2][KS], fb1[KS];
+  auto read_b1 = [&](const char* slot) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if constexpr (FMT != 0) fb1[ks] = frag_kc8(slot, wc * 16, lane);
+      else if constexpr (B_KM) fb1[ks] = frag_km64(slot, wc * 16, ks, lane);
+      else fb1[ks] = frag_kc(slot, wc * 16, ks, lane);
+    }
+  };
+  // one K tile = 3 phases of 16 MFMAs; a wait retires a piece one phase before it is read, a slot is re-staged at the
+  // earliest one phase after its last read (same distances as the four-phase loop above)
+  auto k_tile = [&](int T, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    const char* buf = ring + par * BUF;
+    // ---- phase 0: rows of A0 x the 32-column blocks ----
+    read_a4(buf + SLOT_A0, fa0);
+    read_b2(buf + SLOT_B0, fb0);
+    issue(T + 1, 3, par ^ 1);
+    issue(T + 1, 2, par ^ 1);
+    VDS_WAIT_LGKM0();
+    VDS_WAIT_VM(7);  // A1(T), B1(T) landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma(fa0[i][ks], fb0[j][ks], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: the 16-column block x both row halves ----
+    read_b1(buf + SLOT_B1);
+    read_a4(buf + SLOT_A1, fa1);
+    issue(T + 2, 0, par);
+    VDS_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][2] = mma(fa0[i][ks], fb1[ks], acc[i][2]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[4 + i][2] = mma(fa1[i][ks], fb1[ks], acc[4 + i][2]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: rows of A1 x the 32-column blocks (both operands in registers) ----
+    issue(T + 2, 1, par);
+    VDS_WAIT_VM(7);  // A0(T+1), B0(T+1) landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[4 + i][j] = mma(fa1[i][ks], fb0[j][ks], acc[4 + i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int T = kt_begin; T < kt_end; T += 2) {
+    k_tile(T, std::integral_constant<int, 0>{});
+    if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
+  }
+  }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
   VDS_WAIT_VM(0);                              // the zero-fill tail DMAs target LDS the epilogue reuses
   __builtin_amdgcn_s_barrier();
@@ -855,12 +987,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa) {
     u32x4 auxr[8];
-    const int row0 = m0 + wr * 128 + qa * 64, col0 = n0 + wc * 64;
-    epilogue_prefetch<EPI>(p, row0, col0, lane, auxr);
+    const int row0 = m0 + wr * 128 + qa * 64, col0 = n0 + wc * WCOLS;
+    epilogue_prefetch<EPI, WCOLS>(p, row0, col0, lane, auxr);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           stg[(i * 16 + 4 * (lane >> 4) + r) * EPI_LD + j * 16 + (lane & 15)] =
@@ -868,12 +1000,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_wave_barrier();
     // sub-tiles completely inside the matrix (all but the last row / column of tiles) take the lean path
-    bool full = row0 + 64 <= p.M && col0 + 64 <= p.N;
-    if constexpr (EPI == VDS_EPI_GATE_RES) full = full && (row0 % p.rows_per_batch) + 64 <= p.rows_per_batch;
+    bool full = row0 + 64 <= p.M && col0 + WCOLS <= p.N;
+    if constexpr (EPI == VDS_EPI_GATE_RES) full = full && ((row0 + p.row_base) % p.rows_per_batch) + 64 <= p.rows_per_batch;
     if constexpr (EPI == VDS_EPI_F32) full = false;
     bool done = false;
-    if (full) done = epilogue_full_dispatch<EPI, EMIT>(p, stg, lut, row0, col0, lane, cs, ew[qa], auxr, e_scale, e_max);
-    if (!done) epilogue_64x64<EPI, EMIT, USE_LUT>(p, stg, row0, col0, lane, cs, ew[qa], auxr, lut);
+    if (full) done = epilogue_full_dispatch<EPI, EMIT, WCOLS>(p, stg, lut, row0, col0, lane, cs, ew[qa], auxr, e_scale, e_max);
+    if (!done) epilogue_64x64<EPI, EMIT, USE_LUT, WCOLS>(p, stg, row0, col0, lane, cs, ew[qa], auxr, lut);
     __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
   }
   if constexpr (EMIT) {
@@ -912,8 +1044,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
                                __builtin_amdgcn_perm(t3, t1, 0x05040100u), __builtin_amdgcn_perm(t3, t1, 0x07060302u)};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int col = n0 + wc * 64 + 4 * kq + j;
-          if (col >= p.N || m >= p.M) continue;
+          const int col = n0 + wc * WCOLS + 4 * kq + j;
+          if (col >= p.N || m >= p.M || 4 * kq + j >= WCOLS) continue;
           unsigned char* dst = p.e_qt + (long)col * p.e_ldqt + m;
           if (m + 4 <= p.M) *reinterpret_cast<unsigned*>(dst) = c[j];
           else
@@ -936,9 +1068,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) stg[lane * 8 + e] = cs[e];
       __syncthreads();
-      if (wr == 0 && lane < 8) {
+      if (wr == 0 && lane < WCOLS / 8) {
         const float* other = reinterpret_cast<const float*>(ring) + (wave + 4) * 64 * EPI_LD;
-        const int gcol = n0 + wc * 64 + lane * 8;
+        const int gcol = n0 + wc * WCOLS + lane * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (gcol + e < p.N) atomicAdd(p.e_colsum + gcol + e, cs[e] + other[lane * 8 + e]);
@@ -947,13 +1079,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   }
 }
 
-template <int LAYOUT, int EPI, int FMT = 0>
+template <int LAYOUT, int EPI, int FMT = 0, int WN = 256>
 int launch(const GemmP& p, hipStream_t s) {
   constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
   constexpr int LDS_TOTAL = LDS_BYTES + (USE_LUT ? LUT_BYTES : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI, FMT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI, FMT, WN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     attr_set = true;
   }
@@ -965,7 +1097,7 @@ int launch(const GemmP& p, hipStream_t s) {
   vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : LAYOUT == VDS_NN ? VDS_PROF_GEMM_NN
                                                                                                        : VDS_PROF_GEMM_TN,
                     s, 2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
-  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT>), grid, dim3(512), LDS_TOTAL, s, p);
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT, WN>), grid, dim3(512), LDS_TOTAL, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 }  // namespace big
@@ -1198,11 +1330,32 @@ int launch(const GemmP& p, hipStream_t s) {
 
 }  // namespace
 
-static int g_force_tile = -1;  // -1: read VDS_GEMM_TILE on first use; 0 auto; 128 | 256 | 2 (= 256 x 128) forced
+static int g_force_tile = -1;  // -1: read VDS_GEMM_TILE on first use; 0 auto; 128 | 256 | 192 (= 256 x 192) | 2 (= 256 x 128) forced
+
+// 256 x 192 against 256 x 256 tiles on an NT / NN problem: rounds of 256 workgroups (one per CU) x time per tile.
+// Measured (tools/bench_gemm_w192.py, profiles/r04/gemm_w192_vs_256_b12.log, DiT-XL shapes, B = 12, same box): a
+// 192-wide tile takes 0.87 of the time of a 256-wide one for 0.75 of its MFMA work -- 22 instead of 24 fragment reads and
+// 7 instead of 8 LDS-DMA pieces per K tile feed 48 instead of 64 MFMAs, three barrier pairs instead of four, and the
+// epilogue issues the same number of store instructions with a quarter of their lanes idle -- so at B = 12 (385 row
+// tiles) it LOSES everywhere: N = 1152: 6 column tiles -> 10 rounds x 0.87 = 8.7 against 5 -> 8 rounds (measured 0.255
+// against 0.235 ms); N = 3456: 28 x 0.87 against 22.  It wins where the round count does not grow: per-GPU batches of
+// 1-2 (65 row tiles: 325 tiles of 256 and 390 of 192 are both two rounds) and the sampler.  VDS_GEMM_W192_FACTOR
+// (default 1.16 = 0.87 / 0.75) is the measured time per unit of MFMA work relative to the 256-wide tile.
+static bool prefer_w192(long M, long N) {
+  static double f = -1.0;
+  if (f < 0) {
+    const char* e = getenv("VDS_GEMM_W192_FACTOR");
+    f = e ? atof(e) : 1.16;
+  }
+  const long tm = (M + 255) / 256;
+  const double c256 = (double)((tm * ((N + 255) / 256) + 255) / 256);
+  const double c192 = (double)((tm * ((N + 191) / 192) + 255) / 256) * 0.75 * f;
+  return c192 < c256;
+}
 
 extern "C" int vds_gemm_force_tile(int32_t tile) {
   const int prev = g_force_tile < 0 ? 0 : g_force_tile;
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 2) return VDS_ERR_ARG;
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 2 && tile != 192) return VDS_ERR_ARG;
   g_force_tile = tile;
   return prev;
 }
@@ -1219,6 +1372,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   p.aux = (const bf16_t*)a->aux; p.ldaux = a->ldaux;
   p.gate = a->gate; p.ldgate = a->ldgate;
   p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
+  p.row_base = 0;
   // split_k: > 1 that many K splits (atomic accumulation into a pre-zeroed C); 1 none; <= -2: |split_k| splits and
   // atomic accumulation; 0 / -1 (TN + F32 only): the library picks tiling and split count itself (-1: and always
   // accumulates atomically, so that several calls can sum into one C)
@@ -1273,7 +1427,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   const long rounds_small = ((long)p.tiles_m * p.tiles_n + 511) / 512;
   bool use_big = a->layout != VDS_TN && a->K >= 256 && (double)rounds_big * (2.0 / 1.24) < (double)rounds_small;
   if (force_tile == 128) use_big = false;
-  if (force_tile == 256) use_big = true;
+  if (force_tile == 256 || force_tile == 192) use_big = true;
   static int group_m = -1;
   if (group_m < 0) {
     const char* e = getenv("VDS_GEMM_GROUP_M");
@@ -1362,7 +1516,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     (void)rounds_mid;
     if (force_tile == 2) use_mid = true;
     if (a->colsum && a->layout != VDS_NN) use_mid = false;
-    if (force_tile == 128 || force_tile == 256) use_mid = false;
+    if (force_tile == 128 || force_tile == 256 || force_tile == 192) use_mid = false;
     if (use_mid && a->colsum) {  // no fused column sums in this tiling either
       p.tiles_m = tmm;
       p.tiles_n = tnm;
@@ -1381,6 +1535,18 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
       GOM(VDS_TN, VDS_EPI_F32)
 #undef GOM
     }
+  }
+  if (use_big && a->layout != VDS_TN && (force_tile == 192 || (force_tile == 0 && prefer_w192(a->M, a->N)))) {
+    p.tiles_m = tm;
+    p.tiles_n = cdiv(a->N, 192);
+    p.e_colsum = a->colsum;
+#define GOW(L, E) if (a->layout == L && a->epilogue == E) return big::launch<L, E, 0, 192>(p, s);
+    GOW(VDS_NT, VDS_EPI_STORE)
+    GOW(VDS_NT, VDS_EPI_BIAS_GELU)
+    GOW(VDS_NT, VDS_EPI_GATE_RES)
+    GOW(VDS_NN, VDS_EPI_STORE)
+    GOW(VDS_NN, VDS_EPI_DGELU)
+#undef GOW
   }
   if (use_big) {
     p.tiles_m = tm;
@@ -1428,6 +1594,7 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   p.aux = (const bf16_t*)a->aux; p.ldaux = a->ldaux;
   p.gate = a->gate; p.ldgate = a->ldgate;
   p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
+  p.row_base = 0;
   p.split_k = a->split_k > 1 ? a->split_k : (a->split_k < -1 ? -a->split_k : 1);
   p.atomic = (a->split_k > 1 || a->split_k < 0) ? 1 : 0;
   p.sa = scale_a; p.sb = scale_b;
@@ -1454,6 +1621,22 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   if (p.atomic && a->epilogue != VDS_EPI_F32) return VDS_ERR_ARG;
   if (!a->C && a->epilogue != VDS_EPI_GATE_RES && !(emit && a->epilogue == VDS_EPI_DGELU)) return VDS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (g_force_tile < 0) {
+    const char* e = getenv("VDS_GEMM_TILE");
+    g_force_tile = e ? atoi(e) : 0;
+  }
+  // 256 x 192 tiles where they save rounds (N = 1152 / 3456: see prefer_w192); not for the split-K weight gradients
+  if (p.split_k == 1 && (g_force_tile == 192 || (g_force_tile == 0 && prefer_w192(a->M, a->N)))) {
+    p.tiles_n = cdiv(a->N, 192);
+#define GOFW(E, F) if (a->epilogue == E && a_fmt == F - 1) return big::launch<VDS_NT, E, F, 192>(p, s);
+    GOFW(VDS_EPI_STORE, 1)
+    GOFW(VDS_EPI_BIAS_GELU, 1)
+    GOFW(VDS_EPI_GATE_RES, 1)
+    GOFW(VDS_EPI_STORE, 2)
+    GOFW(VDS_EPI_DGELU, 2)
+#undef GOFW
+    p.tiles_n = cdiv(a->N, 256);
+  }
 #define GOF(E, F) if (a->epilogue == E && a_fmt == F - 1) return big::launch<VDS_NT, E, F>(p, s);
   GOF(VDS_EPI_STORE, 1)
   GOF(VDS_EPI_BIAS_GELU, 1)
