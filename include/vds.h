@@ -167,6 +167,11 @@ typedef struct vds_attn_args {
    * padded to head_dim+8 columns as well: vds_attn_bwd OVERWRITES their columns head_dim, head_dim+1
    * (scratch: -lse*log2(e) as a bf16 hi/lo pair for the dK/dV kernel). */
   int32_t kv_pad_ones;
+  /* backward only: number of floats `delta` points to.  0 = exactly 2*B*H*Lq (the statistics).  With the size
+   * vds_attn_bwd_workspace_bytes returns, the dK/dV kernel may split the query range over several workgroups per key
+   * tile when the key sequence is short (cross-attention, model.py:157: 512 context keys = 4 key tiles per head) and
+   * keep its fp32 partial sums behind the statistics. */
+  int64_t ws_floats;
 } vds_attn_args;
 
 int vds_attn_fwd(const vds_attn_args* args, vds_stream_t stream);
@@ -175,7 +180,8 @@ int vds_attn_bwd(const vds_attn_args* args, vds_stream_t stream);
  * v_mfma_f32_32x32x16_bf16 -- bit 0: dK/dV, bit 1: dQ, bit 2: forward; -1 = back to the default / VDS_ATTN_MFMA16.
  * Returns the previous mask.  Results agree up to fp32 summation order. */
 int vds_attn_set_variant(int32_t mask);
-/* bytes of the caller-allocated `delta` workspace vds_attn_bwd needs for these B, H, Lq (2*B*H*Lq floats) */
+/* bytes of the caller-allocated `delta` workspace vds_attn_bwd wants for these B, H, Lq, Lk, head_dim, kv_pad_ones:
+ * 2*B*H*Lq floats of statistics + the partial sums of a query-split dK/dV launch (see ws_floats) */
 size_t vds_attn_bwd_workspace_bytes(const vds_attn_args* args);
 
 /* ------------------------------------------------------ normalisation / modulation ---

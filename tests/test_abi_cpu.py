@@ -43,7 +43,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.AdamWTensor) == 5 * 8 + 8 + 4 + 4
     assert C.sizeof(_lib.GemmArgs) == 5 * 4 + 4 + 8 * 13 + 4 + 4 + 8  # 5 int32 + pad, 13 pointer/int64, 2 int32, colsum
     assert _lib.GemmArgs.colsum.offset == 136 and _lib.GemmArgs.split_k.offset == 132
-    assert C.sizeof(_lib.AttnArgs) == 5 * 4 + 4 + 8 * (4 * 4 + 1 + 4 * 4 + 1) + 8  # + kv_pad_ones (padded)
+    assert C.sizeof(_lib.AttnArgs) == 5 * 4 + 4 + 8 * (4 * 4 + 1 + 4 * 4 + 1) + 8 + 8  # + kv_pad_ones (padded) + ws_floats
+    assert _lib.AttnArgs.ws_floats.offset == C.sizeof(_lib.AttnArgs) - 8
     assert C.sizeof(_lib.ProfStat) == 32
     assert C.sizeof(_lib.Fp8Out) == 7 * 8 + 4 + 4 + 8  # 7 pointer/int64, fmt + pad, colsum
     assert _lib.Fp8Out.colsum.offset == 64 and _lib.Fp8Out.fmt.offset == 56

@@ -312,6 +312,42 @@ def test_attention_token_major_cross(ops):
     close("cross.dv", dkvb[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dv_ref, 8e-3)
 
 
+@pytest.mark.parametrize("hd,L,Lc", [(72, 2100, 300), (64, 1111, 512), (72, 4368, 512)],
+                         ids=["hd72_Lk300", "hd64_Lk512", "c3a_tokens_Lk512"])
+def test_attention_cross_dkv_with_split_query_range(ops, hd, L, Lc):
+    """round 4: with a short key sequence (cross-attention, model.py:157) the dK/dV launch has only ceil(Lk/128) workgroups
+    per head; given the workspace vds_attn_bwd_workspace_bytes asks for (delta=None) the library splits the query range
+    over several workgroups per key tile (fp32 partials + a reduction kernel).  Result == the unsplit launch (legacy
+    [2,B,H,Lq] workspace) up to the summation order, and both == the fp32 reference; ragged Lq / Lk included."""
+    B, H = 1, 2
+    D = H * hd
+    qb, kvb = gen(B * L, D, seed=33), gen(B * Lc, 2 * D, seed=34)
+    qd, kvd = qb.cuda(), kvb.cuda()
+    o = torch.zeros(B * L, D, dtype=bf16, device="cuda")
+    lse = torch.zeros(B, H, L, dtype=f32, device="cuda")
+    qv, kv_k, kv_v = ops.heads_view(qd, B, L, H, hd), ops.heads_view(kvd, B, Lc, H, hd, 0), ops.heads_view(kvd, B, Lc, H, hd, D)
+    ops.attn_fwd(qv, kv_k, kv_v, ops.heads_view(o, B, L, H, hd), lse)
+    do = gen(B * L, D, seed=35)
+    q = qb.reshape(B, L, H, hd).permute(0, 2, 1, 3)
+    k = kvb[:, :D].reshape(B, Lc, H, hd).permute(0, 2, 1, 3)
+    v = kvb[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3)
+    _, _, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, do.reshape(B, L, H, hd).permute(0, 2, 1, 3))
+    assert ops.attn_bwd_workspace_floats(B, H, L, Lc, hd) > 2 * B * H * L  # the library wants room for partials here
+    outs = []
+    for delta in (torch.zeros(2, B, H, L, dtype=f32, device="cuda"), None):
+        dqb = torch.full_like(qd, float("nan"))
+        dkvb = torch.full_like(kvd, float("nan"))
+        ops.attn_bwd(qv, kv_k, kv_v, ops.heads_view(o, B, L, H, hd), lse, ops.heads_view(do.cuda(), B, L, H, hd),
+                     ops.heads_view(dqb, B, L, H, hd), ops.heads_view(dkvb, B, Lc, H, hd, 0),
+                     ops.heads_view(dkvb, B, Lc, H, hd, D), delta)
+        assert torch.isfinite(dkvb.float()).all()
+        close("split.dq", dqb.reshape(B, L, H, hd).permute(0, 2, 1, 3), dq_ref, 8e-3)
+        close("split.dk", dkvb[:, :D].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dk_ref, 8e-3)
+        close("split.dv", dkvb[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dv_ref, 8e-3)
+        outs.append(dkvb.float().cpu())
+    close("split.vs_unsplit", outs[1], outs[0], 4e-3)  # bf16 roundings of two fp32 summation orders
+
+
 def test_attention_online_softmax_rescale(ops):
     """spike one key late in the sequence so the running max jumps in the last tile"""
     B, H, hd, L = 1, 1, 64, 256

@@ -35,7 +35,7 @@ class AttnArgs(C.Structure):
                 ("dq", c_vp), ("dq_sb", c_i64), ("dq_sh", c_i64), ("dq_sl", c_i64),
                 ("dk", c_vp), ("dk_sb", c_i64), ("dk_sh", c_i64), ("dk_sl", c_i64),
                 ("dv", c_vp), ("dv_sb", c_i64), ("dv_sh", c_i64), ("dv_sl", c_i64),
-                ("delta", c_vp), ("kv_pad_ones", c_i32)]
+                ("delta", c_vp), ("kv_pad_ones", c_i32), ("ws_floats", c_i64)]
 
 
 class Attn8Args(C.Structure):  # vds_attn_fp8_args

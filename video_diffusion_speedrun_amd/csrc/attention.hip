@@ -49,6 +49,11 @@ struct AttnP {
   int n_rt;  // row tiles per (b,h) of the stationary operand
   int tail_last;  // decode_block: the partly filled last tile of every head is scheduled after all full tiles
   int kv_pad_ones;
+  // dK/dV kernel, short key sequences (cross-attention: 512 context keys = 4 key tiles per head): the query range is
+  // split over q_split workgroups per key tile, each writing an fp32 partial [q_split][B*H][Lk][2][hd] that
+  // dkv_reduce_kernel sums into the bf16 outputs (run_bwd picks q_split; 1 = the kernel stores bf16 itself)
+  int q_split;
+  float* dkv_part;
 };
 
 // ---- LDS image (a): rows x HDP bf16, 8x32 sub-tiles of 512 B -------------------------------
@@ -155,6 +160,41 @@ __device__ __forceinline__ void store_rows(bf16_t* rowp, const f32x16 (&acc)[NDB
         *reinterpret_cast<u32x2*>(rowp + d) = w;
       }
     }
+}
+
+// the same accumulator set as fp32 rows (partial sums of the query-split dK/dV kernel)
+template <int NDB>
+__device__ __forceinline__ void store_rows_f32(float* rowp, const f32x16 (&acc)[NDB], int hd, int h) {
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = db * 32 + 8 * rg + 4 * h;
+      if (d < hd)
+        *reinterpret_cast<f32x4*>(rowp + d) = f32x4{acc[db][4 * rg], acc[db][4 * rg + 1], acc[db][4 * rg + 2], acc[db][4 * rg + 3]};
+    }
+}
+// dk / dv (bf16, strided) = sum over the q_split partials; one thread = 4 consecutive head-dim columns of one
+// (b, h, key, dk | dv) row; dk is scaled by the softmax scale here (the bf16 path does it in store_rows)
+__global__ __launch_bounds__(256) void dkv_reduce_kernel(AttnP p) {
+  const int hq = p.hd >> 2;
+  const long n = (long)p.B * p.H * p.Lk * 2 * hq;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n) return;
+  const int c = (int)(gid % hq);
+  const int which = (int)((gid / hq) & 1);
+  const long row = gid / (2 * hq);  // (b * H + h) * Lk + key
+  const int key = (int)(row % p.Lk);
+  const int bh = (int)(row / p.Lk), b = bh / p.H, hh = bh % p.H;
+  const long stride = (long)p.B * p.H * p.Lk * 2 * p.hd;
+  const float* src = p.dkv_part + (row * 2 + which) * p.hd + 4 * c;
+  f32x4 a = *reinterpret_cast<const f32x4*>(src);
+  for (int sp = 1; sp < p.q_split; ++sp) a += *reinterpret_cast<const f32x4*>(src + sp * stride);
+  const float mul = which == 0 ? p.scale : 1.0f;
+  bf16_t* dst = which == 0 ? p.dk + b * p.dk_sb + hh * p.dk_sh + (long)key * p.dk_sl
+                           : p.dv + b * p.dv_sb + hh * p.dv_sh + (long)key * p.dv_sl;
+  const u32x2 w = {pack_bf2(a[0] * mul, a[1] * mul), pack_bf2(a[2] * mul, a[3] * mul)};
+  *reinterpret_cast<u32x2*>(dst + 4 * c) = w;
 }
 
 // ===================================== forward ==============================================
@@ -787,8 +827,16 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void att
   // LDS: [buf0: Q | dO][buf1: Q | dO][stats: 2 bufs x (lse2[64], delta[64])]
   char* qbuf = smem;
   char* stats = smem + 4 * Q_TILE;
-  int bh, kt_idx;
-  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, kt_idx)) return;
+  int bh, kt_idx, sp = 0;
+  if (p.q_split > 1) {  // (head, key tile, query range): the workgroups of a head stay on one XCD like the unsplit order
+    const int per = p.n_rt * p.q_split, pid = blockIdx.x, idx = pid >> 3;
+    bh = (idx / per) * 8 + (pid & 7);
+    if (bh >= p.B * p.H) return;
+    kt_idx = (idx % per) % p.n_rt;
+    sp = (idx % per) / p.n_rt;
+  } else if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, kt_idx)) {
+    return;
+  }
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -822,7 +870,10 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void att
       lds_dma4(rdl, sa + 256, (unsigned)((j * 64 + lane) * 4));
     }
   };
-  issue_tile(0, 0);
+  // this workgroup's query tiles [j0, j1) (all of them unless the query range is split)
+  const int nqt_all = (p.Lq + 63) / 64, jper = (nqt_all + p.q_split - 1) / (p.q_split > 0 ? p.q_split : 1);
+  const int j0 = sp * jper, j1 = min(nqt_all, j0 + jper);
+  issue_tile(j0, 0);
 
   // this lane's key row as B-operand fragments (rows past Lk / columns past hd read as zero)
   bf16x8 kf[KSQ], vf[KSQ];
@@ -847,15 +898,14 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void att
   f32x16 dk[NDB], dv[NDB];
 #pragma unroll
   for (int i = 0; i < NDB; ++i) { dk[i] = zero16(); dv[i] = zero16(); }
-  const int nqt = (p.Lq + 63) / 64;
 #pragma unroll
   for (int ks = 0; ks < KSQ; ++ks) { retire(kf[ks]); retire(vf[ks]); }
   VDS_WAIT_VM(0);
-  __syncthreads();  // tile 0 landed
+  __syncthreads();  // tile j0 landed
 
   auto q_tile = [&](int j, auto PAR) {  // unrolled by two: compile-time LDS buffer parity (see the forward kernel)
     constexpr int par = decltype(PAR)::value;
-    if (j + 1 < nqt) issue_tile(j + 1, par ^ 1);
+    if (j + 1 < j1) issue_tile(j + 1, par ^ 1);
     const char* qt = qbuf + par * 2 * Q_TILE;
     const char* dot = qt + Q_TILE;
     const float* stl = reinterpret_cast<const float*>(stats + par * 512);
@@ -914,13 +964,19 @@ __global__ __launch_bounds__(256, (HDP > 96 ? 1 : (HDP == 64 ? 3 : 2))) void att
     VDS_WAIT_VM(0);
     __syncthreads();
   };
-  for (int j = 0; j < nqt; j += 2) {
+  for (int j = j0; j < j1; j += 2) {
     q_tile(j, std::integral_constant<int, 0>{});
-    if (j + 1 < nqt) q_tile(j + 1, std::integral_constant<int, 1>{});
+    if (j + 1 < j1) q_tile(j + 1, std::integral_constant<int, 1>{});
   }
   if (krow < p.Lk) {
-    store_rows<NDB>(p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl, dk, p.scale, p.hd, h);
-    store_rows<NDB>(p.dv + b * p.dv_sb + hh * p.dv_sh + (long)krow * p.dv_sl, dv, 1.0f, p.hd, h);
+    if (p.q_split > 1) {  // fp32 partial of this query range (an empty range stores zeros); dkv_reduce_kernel finishes
+      float* part = p.dkv_part + ((((long)sp * p.B * p.H + bh) * p.Lk + krow) * 2) * p.hd;
+      store_rows_f32<NDB>(part, dk, p.hd, h);
+      store_rows_f32<NDB>(part + p.hd, dv, p.hd, h);
+    } else {
+      store_rows<NDB>(p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl, dk, p.scale, p.hd, h);
+      store_rows<NDB>(p.dv + b * p.dv_sb + hh * p.dv_sh + (long)krow * p.dv_sl, dv, 1.0f, p.hd, h);
+    }
   }
 }
 
@@ -1479,6 +1535,8 @@ AttnP to_p(const vds_attn_args* a) {
   p.n_rt = 0;
   p.tail_last = 0;
   p.kv_pad_ones = a->kv_pad_ones;
+  p.q_split = 1;
+  p.dkv_part = nullptr;
   return p;
 }
 
@@ -1570,8 +1628,19 @@ int run_fwd(AttnP p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 
+// query-range split of the plain dK/dV kernel: target ~3 rounds of the 512 co-resident workgroups, each range at
+// least 8 query tiles of 64 (the prologue -- K / V fragments, first tile -- is ~2 tile times)
+int dkv_qsplit(int B, int H, int Lq, int Lk) {
+  const long wgs = (long)cdiv(B * H, 8) * 8 * cdiv(Lk, 128);
+  const int nqt = cdiv(Lq, 64);
+  if (wgs >= 3 * 512 || nqt < 16) return 1;
+  long sp = (3 * 512 + wgs - 1) / wgs;
+  if (sp > nqt / 8) sp = nqt / 8;
+  return (int)(sp < 1 ? 1 : sp > 16 ? 16 : sp);
+}
+
 template <int HDP, int HDQ>
-int run_bwd(AttnP p, hipStream_t s) {
+int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
   constexpr int LDS_DQ = 4 * 64 * HDP * 2;
   constexpr int LDS_DKV = 4 * 64 * HDP * 2 + 2 * 128 * 4;
   static bool once = false;
@@ -1614,7 +1683,33 @@ int run_bwd(AttnP p, hipStream_t s) {
       else if (ones_kv)
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DKV, s, p);
     }
-    if (!ones_kv) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS_DKV, s, p);
+    if (!ones_kv) {
+      // few key tiles per head (cross-attention): B*H*n_rt workgroups leave most of the 2 x 256 slots empty (B = 2: 128
+      // of 512) or end on a half-filled round (B = 12: 768 = 1.5 rounds).  The query range is then split so that the
+      // launch is ~3 rounds of proportionally shorter workgroups; the fp32 partials (q_split x B*H*Lk*2*hd floats, at
+      // the end of the caller's workspace) are summed by dkv_reduce_kernel.  Needs the workspace vds_attn_bwd_workspace_
+      // bytes asks for (args->ws_floats); VDS_ATTN_QSPLIT=1 turns it off, =N forces N.
+      static int force = -1;
+      if (force < 0) {
+        const char* e = getenv("VDS_ATTN_QSPLIT");
+        force = e ? atoi(e) : 0;
+      }
+      const int split = force > 0 ? force : dkv_qsplit(p.B, p.H, p.Lq, p.Lk);
+      const size_t need = (size_t)2 * rows + (size_t)split * p.B * p.H * p.Lk * 2 * p.hd;
+      if (split > 1 && (p.hd & 3) == 0 && ws_floats >= need && (p.dk_sl & 3) == 0) {
+        p.q_split = split;
+        p.dkv_part = p.delta + 2 * rows;
+        p.tail_last = 0;
+        const int g2 = cdiv(p.B * p.H, 8) * 8 * p.n_rt * split;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, false>), dim3(g2), dim3(256), LDS_DKV, s, p);
+        const long n = (long)p.B * p.H * p.Lk * 2 * (p.hd >> 2);
+        hipLaunchKernelGGL(dkv_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+        p.q_split = 1;
+        p.dkv_part = nullptr;
+      } else {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS_DKV, s, p);
+      }
+    }
   }
   p.n_rt = cdiv(p.Lq, 128);
   p.tail_last = tail_last_for(p.Lq, 128);
@@ -1660,7 +1755,10 @@ extern "C" int vds_attn_fwd(const vds_attn_args* a, vds_stream_t stream) {
 
 extern "C" size_t vds_attn_bwd_workspace_bytes(const vds_attn_args* a) {
   if (!a || a->B <= 0 || a->H <= 0 || a->Lq <= 0) return 0;
-  return (size_t)2 * a->B * a->H * a->Lq * sizeof(float);
+  size_t fl = (size_t)2 * a->B * a->H * a->Lq;
+  if (a->Lk > 0 && a->head_dim > 0 && !a->kv_pad_ones)  // fp32 partials of the query-split dK/dV kernel (short key sequences)
+    fl += (size_t)dkv_qsplit(a->B, a->H, a->Lq, a->Lk) * a->B * a->H * a->Lk * 2 * a->head_dim;
+  return fl * sizeof(float);
 }
 
 extern "C" int vds_attn_bwd(const vds_attn_args* a, vds_stream_t stream) {
@@ -1669,12 +1767,14 @@ extern "C" int vds_attn_bwd(const vds_attn_args* a, vds_stream_t stream) {
   if (!strides_ok(a, true)) return VDS_ERR_ARG;
   AttnP p = to_p(a);
   hipStream_t s = (hipStream_t)stream;
+  // floats in `delta`: 2*B*H*Lq when the caller does not say (ws_floats = 0: the pre-round-4 contract, no query split)
+  const size_t ws = a->ws_floats > 0 ? (size_t)a->ws_floats : (size_t)2 * a->B * a->H * a->Lq;
   switch (a->head_dim) {
-    case 32: return run_bwd<32, 32>(p, s);
-    case 64: return run_bwd<64, 64>(p, s);
-    case 72: return run_bwd<96, 80>(p, s);
-    case 96: return run_bwd<96, 96>(p, s);
-    case 128: return run_bwd<128, 128>(p, s);
+    case 32: return run_bwd<32, 32>(p, s, ws);
+    case 64: return run_bwd<64, 64>(p, s, ws);
+    case 72: return run_bwd<96, 80>(p, s, ws);
+    case 96: return run_bwd<96, 96>(p, s, ws);
+    case 128: return run_bwd<128, 128>(p, s, ws);
     default: return VDS_ERR_UNSUPPORTED;
   }
 }

@@ -238,8 +238,12 @@ def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32
     groups = [FlatGroup("root", root, world, rank, pg)]
     groups += [FlatGroup(f"blocks.{i}", m, world, rank, pg) for i, m in enumerate(blocks)]
     run = world > 1 or (force_runtime and (dist.is_initialized() or world_rank is not None))
-    for g in groups:
-        g.materialize(device, full_values, separate=run)  # W=1 + runtime: real collectives into separate buffers
+    from .model import grad_arena
+    dit_model._grad_arena = grad_arena(groups, device)
+    off = 0
+    for g in groups:  # (W=1 + runtime: real collectives into separate buffers)
+        g.materialize(device, full_values, separate=run, gfull=dit_model._grad_arena[off:off + g.padded])
+        off += g.padded
     for name, buf in dit_model.named_buffers():
         buf.data = buf.data.to(device)
     dit_model._groups = groups

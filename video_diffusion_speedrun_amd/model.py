@@ -564,11 +564,11 @@ class DiTBlock(nn.Module):
                 ops.attn_fp8_bwd(bs.qc8, bs.kc8, bs.vc8, sv.doq, stats, bs.deqc, ops.heads_view(dqc, B, L, H, hd),
                                  ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), hd)
             else:
-                delta = torch.empty(2, B, H, L, dtype=f32, device=dev)
+                # (workspace sized by the library: statistics + the fp32 partials of its query-split dK/dV launch)
                 ops.attn_bwd(ops.heads_view(bs.qc, B, L, H, hd), ops.heads_view(bs.ckv, B, Lc, H, hd, 0),
                              ops.heads_view(bs.ckv, B, Lc, H, hd, D), ops.heads_view(bs.catt, B, L, H, hd), bs.lse2,
                              ops.heads_view(dcatt, B, L, H, hd), ops.heads_view(dqc, B, L, H, hd),
-                             ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), delta)
+                             ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), None)
                 if bs.c8_on:
                     ops.absmax(dcatt, fp8_hist.cur(R0 + F8.ROW_DOC))
             if G.has(pre + "context_kv.bias"):
@@ -650,6 +650,19 @@ class DiTBlock(nn.Module):
 class _Saved:
     """activations kept for the backward pass"""
     pass
+
+
+def _offsets(groups):
+    off = 0
+    for g in groups:
+        yield off
+        off += g.padded
+
+
+def grad_arena(groups, device):
+    """one fp32 allocation for the full-size gradient buffers of all flat groups (4.5 GB for DiT-XL), 1 KiB-aligned
+    slices (a group's padded size is a multiple of 256 elements)"""
+    return torch.zeros(sum(g.padded for g in groups), dtype=f32, device=device)
 
 
 class DiT(nn.Module):
@@ -736,8 +749,11 @@ class DiT(nn.Module):
         root, blocks = self._group_members()
         groups = [FlatGroup("root", root, self._world, self._rank, self._pg)]
         groups += [FlatGroup(f"blocks.{i}", m, self._world, self._rank, self._pg) for i, m in enumerate(blocks)]
+        self._grad_arena = grad_arena(groups, device)
+        off = 0
         for g in groups:
-            g.materialize(device, full_values)
+            g.materialize(device, full_values, gfull=self._grad_arena[off:off + g.padded])
+            off += g.padded
         self._groups = groups
 
     def _apply(self, fn, *a, **k):  # .to()/.cuda() replace tensors: flat views are rebuilt lazily
@@ -768,6 +784,17 @@ class DiT(nn.Module):
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none)
+
+    def _zero_grad_buffers(self):
+        """clear the full-size fp32 gradient buffers the weight-gradient kernels accumulate into: ONE fill when the
+        groups' buffers are slices of the model's arena (the normal case), else one per group"""
+        arena = getattr(self, "_grad_arena", None)
+        if arena is not None and all(g.gfull.data_ptr() == arena.data_ptr() + 4 * o for g, o in
+                                     zip(self._groups, _offsets(self._groups))):
+            arena.zero_()
+        else:
+            for g in self._groups:
+                g.gfull.zero_()
 
     # ------------------------------------------------------------------------ forward ----
     def forward(self, x, context, timesteps, rope_start: Optional[Tuple[int, int, int]] = None):
@@ -899,8 +926,7 @@ class DiT(nn.Module):
         # gradients already held in p.grad (a second backward before zero_grad: micro-batch accumulation, like
         # autograd's accumulate-into-.grad in the reference loop) are set aside and added back at the end
         held = [g.hold_grads() for g in self._groups]  # per parameter: only slices whose .grad is live are kept
-        for g in self._groups:
-            g.gfull.zero_()
+        self._zero_grad_buffers()
         if fs is not None:
             fs.pre_backward_root()
         Pd = p * p * pt * C
@@ -910,17 +936,20 @@ class DiT(nn.Module):
         ops.linear_wgrad(dyf, sv.xnf, R.g("final_proj.weight"))
         ops.colsum(dyf, R.g("final_proj.bias"))
         dxnf = ops.linear_dgrad(dyf, R.w("final_proj.weight"))
-        dfmod = torch.zeros(B, 2 * D, dtype=f32, device=dev)
+        # the small zero-initialised accumulators of this pass come out of ONE fill: d(final modulation) [B, 2D],
+        # d(conditioning vector) [B, D], d(time-embed hidden) [B, 4D] and the adaLN modulation gradients of all blocks
+        nmods = self.depth * B * 9 * D if sv.batched_adaln else 0
+        zs = torch.zeros(B * 7 * D + nmods, dtype=f32, device=dev)
+        dfmod, dc, dh1 = zs[:B * 2 * D].view(B, 2 * D), zs[B * 2 * D:B * 3 * D].view(B, D), zs[B * 3 * D:B * 7 * D].view(B, 4 * D)
+        dmods = zs[B * 7 * D:].view(self.depth, B, 9 * D) if sv.batched_adaln else None
         wfn = R.w("final_norm.weight") if R.has("final_norm.weight") else None
         dwfn = R.g("final_norm.weight") if wfn is not None else None
         # register rows: dxnf = 0 there, so they get a zero gradient from the final layer (they were sliced off)
         dX = ops.rmsnorm_mod_bwd(dxnf, sv.x_last, wfn, sv.fmod, 0, D, sv.rstdf, None, dfmod, dwfn, B, L)
-        dc = torch.zeros(B, D, dtype=f32, device=dev)
         ops.small_linear_bwd(dfmod, sv.cvec, R.w("final_modulation.1.weight"), R.g("final_modulation.1.weight"),
                              R.g("final_modulation.1.bias"), dc, 1)
         hdp = HDP_OF[hd]
         dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev) if (self.residual_v and self.depth > 1) else None
-        dmods = torch.zeros(self.depth, B, 9 * D, dtype=f32, device=dev) if sv.batched_adaln else None
         for i in reversed(range(self.depth)):
             if fs is not None:
                 fs.pre_backward_block(i)
@@ -940,7 +969,6 @@ class DiT(nn.Module):
         ops.linear_wgrad(dX, sv.patches, R.g("patch_embed.patch_proj.weight").view(D, Pd))
         ops.colsum(dX, R.g("patch_embed.patch_proj.bias"), rows_per_sample=L, row_offset=N_REG)
         # time embed MLP
-        dh1 = torch.zeros(B, 4 * D, dtype=f32, device=dev)
         ops.small_linear_bwd(dc, sv.h1, R.w("time_embed.2.weight"), R.g("time_embed.2.weight"),
                              R.g("time_embed.2.bias"), dh1, 1)
         ops.small_linear_bwd(dh1, sv.temb, None, R.g("time_embed.0.weight"), R.g("time_embed.0.bias"), None, 0)

@@ -197,6 +197,14 @@ def attn_fwd(q, k, v, o, lse, kv_pad_ones: bool = False):
     check(_lib.load().vds_attn_fwd(C.byref(a), _stream()), f"vds_attn_fwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
 
 
+def attn_bwd_workspace_floats(B, H, Lq, Lk, hd, kv_pad_ones: bool = False) -> int:
+    """floats of workspace vds_attn_bwd wants: the [2,B,H,Lq] statistics + the fp32 partials of a query-split dK/dV launch"""
+    a = AttnArgs()
+    a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, hd
+    a.kv_pad_ones = 1 if kv_pad_ones else 0
+    return _lib.load().vds_attn_bwd_workspace_bytes(C.byref(a)) // 4
+
+
 def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta=None, kv_pad_ones: bool = False):
     """delta: f32 workspace of 2*B*H*Lq elements (rowsum(dO*O), then lse*log2 e); allocated here when None
     (size from vds_attn_bwd_workspace_bytes)."""
@@ -205,9 +213,11 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta=None, kv_pad_ones: bool = Fa
     Lk = k.shape[2]
     a = AttnArgs()
     a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, hd
+    a.kv_pad_ones = 1 if kv_pad_ones else 0
     if delta is None:
         delta = torch.empty(_lib.load().vds_attn_bwd_workspace_bytes(C.byref(a)) // 4, dtype=f32, device=q.device)
     assert delta.numel() >= 2 * B * H * Lq and delta.is_contiguous(), "attn_bwd: delta workspace is [2,B,H,Lq] f32"
+    a.ws_floats = delta.numel()
     a.q, (a.q_sb, a.q_sh, a.q_sl) = _p(q), _st(q)
     a.k, (a.k_sb, a.k_sh, a.k_sl) = _p(k), _st(k)
     a.v, (a.v_sb, a.v_sh, a.v_sl) = _p(v), _st(v)

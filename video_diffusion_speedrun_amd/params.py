@@ -70,10 +70,13 @@ class FlatGroup:
             return 0, 0
         return lo - s0, hi - s0
 
-    def materialize(self, device, full_values: Optional[Dict[str, torch.Tensor]] = None, separate: bool = False):
+    def materialize(self, device, full_values: Optional[Dict[str, torch.Tensor]] = None, separate: bool = False,
+                    gfull: Optional[torch.Tensor] = None):
         """Allocate the flat buffers on `device`, move the current parameter values into the fp32
         master chunk and re-point every nn.Parameter at its slice.  `full_values` supplies the
-        full tensors when the parameters are already sharded pieces."""
+        full tensors when the parameters are already sharded pieces.  `gfull`: this group's `padded` floats of a
+        gradient arena the caller owns (DiT keeps the full-size gradient buffers of all groups in ONE allocation, so
+        that a backward pass clears them with one fill instead of one per group)."""
         device = torch.device(device)
         new_master = torch.zeros(self.shard, dtype=torch.float32, device=device)
         for n in self.names:
@@ -94,7 +97,11 @@ class FlatGroup:
         self.device = device
         self.master = new_master
         self.shadow = torch.zeros(self.shard, dtype=torch.bfloat16, device=device)
-        self.gfull = torch.zeros(self.padded, dtype=torch.float32, device=device)
+        if gfull is not None:
+            assert gfull.numel() == self.padded and gfull.dtype == torch.float32 and gfull.device == device
+            self.gfull = gfull
+        else:
+            self.gfull = torch.zeros(self.padded, dtype=torch.float32, device=device)
         if self.world == 1 and not separate:
             self.full, self.gshard = self.shadow, self.gfull
         else:
