@@ -90,6 +90,47 @@ def test_gemm_fp8_exact_on_small_integers(ops, tile8, a_fmt, M, N, K):
     assert torch.equal(Cb.cpu(), (want * 0.5).to(bf16))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1152, 1152, 1040), (144, 3456, 912), (272, 48, 4112), (16, 16, 16)])
+def test_gemm_fp8_tn_weight_gradient_exact_on_small_integers(ops, M, N, K):
+    """round 4: dW[M,N] = sum_k dy[k,m] x[k,n] read straight from the token-major fp8 copies (both operands k-major,
+    ds_read_b64_tr_b8 fragments; dy e5m2, x e4m3): exact on small integers -- lane maps of the transposing reads, the
+    swizzled [128 tokens][128 bytes] LDS image, ragged token counts (K not a multiple of 128), ragged M / N tiles,
+    split-K with atomic accumulation"""
+    from video_diffusion_speedrun_amd._lib import EPI_F32
+    A = _small_ints(K, M, 5, [-2.0, -1.0, -0.5, 0.0, 0.5, 1.0, 2.0, 3.0])      # dy [tokens, out features]
+    B = _small_ints(K, N, 6, [-1.5, -1.0, 0.0, 0.25, 1.0, 2.0])                # x  [tokens, in features]
+    want = A.t() @ B
+    Aq, Bq = A.to(torch.float8_e5m2).cuda(), B.to(torch.float8_e4m3fn).cuda()
+    assert torch.equal(Aq.float().cpu(), A) and torch.equal(Bq.float().cpu(), B)
+    sa, sb = torch.tensor([0.5], device="cuda"), torch.tensor([4.0], device="cuda")
+    for split in (1, 3) if K >= 900 else (1,):  # (token counts are multiples of 16: fp8.supported)
+        C32 = torch.zeros(M, N, dtype=f32, device="cuda")
+        ops.gemm_fp8(EPI_F32, M, N, K, Aq, Bq, sa, sb, 1, C32, N, split_k=-split if split > 1 else 1, tn=True)
+        assert torch.equal(C32.cpu(), want * 2.0), (split, (C32.cpu() - want * 2).abs().max())
+
+
+def test_fp8_wgrad_from_token_major_copies_matches_the_transposed_path(ops):
+    """fp8.wgrad on the row-major copies (TN, default) == the NT product of the transposed copies it replaces, bit for
+    bit up to the fp32 atomic summation order; asymmetric operands (a transposed or permuted fragment map cannot pass)"""
+    from video_diffusion_speedrun_amd import fp8 as F8
+    M, N, K = 4112, 432, 144  # tokens, out features, in features
+    dy, x = gen(M, N, seed=21), gen(M, K, seed=22)
+    dyq = F8.Q(dy.cuda(), F8.E5M2, True, True, weight=True)   # (weight=True: keep both copies for this comparison)
+    xq = F8.Q(x.cuda(), F8.E4M3, True, True, weight=True)
+    assert dyq.t is not None and xq.t is not None
+    got = torch.zeros(N, K, dtype=f32, device="cuda")
+    F8.wgrad(dyq, xq, got)
+    old, F8.TN = F8.TN, False
+    try:
+        ref = torch.zeros(N, K, dtype=f32, device="cuda")
+        F8.wgrad(dyq, xq, ref)
+    finally:
+        F8.TN = old
+    exact = (dyq.q.float() * dyq.s).t() @ (xq.q.float() * xq.s)
+    assert ((got - exact).norm() / exact.norm()).item() <= 1e-4  # (`exact` is torch's fp32 matmul)
+    assert ((got - ref).norm() / ref.norm()).item() <= 1e-5
+
+
 def test_linear_fp8_close_to_bf16_linear(ops):
     """quantise -> fp8 GEMM -> dequantise against the fp32 product of the same bf16 inputs: error at the
     e4m3 quantisation level (2^-4 relative per element, averaged down by the contraction)"""
@@ -110,11 +151,13 @@ def test_linear_fp8_close_to_bf16_linear(ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(304, 264, 144), (1024, 4608, 1152)])
-def test_gemm_epilogue_emits_fp8_copies(ops, tile8, M, N, K):
+def test_gemm_epilogue_emits_fp8_copies(ops, tile8, M, N, K, monkeypatch):
     """vds_fp8_out: the fc1 epilogue (bias + GELU) and the fc2-dgrad epilogue (gelu') write their result as fp8
     row-major + transposed, record its amax and (dgrad) its column sums -- bit-identical to quantising the bf16
-    result in a separate pass with the same scale."""
+    result in a separate pass with the same scale.  (Since round 4 the model no longer asks for the transposed copies
+    -- fp8.TN -- but the C ABI still produces them: the test runs with the pre-round-4 setting.)"""
     from video_diffusion_speedrun_amd import fp8 as F8
+    monkeypatch.setattr(F8, "TN", False)
     x, W, b = gen(M, K, seed=11), gen(N, K, seed=12, scale=0.05), gen(N, seed=13, scale=0.1)
     xq, wq = F8.Q(x.cuda(), 0, True, True), F8.Q(W.cuda(), 0, True, True)
     pre, act = F8.fwd_gelu(xq, wq, b.cuda())

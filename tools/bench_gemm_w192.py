@@ -76,7 +76,7 @@ if os.environ.get("FP8", "1") == "1":
     tot8 = {256: 0.0, 192: 0.0, 0: 0.0}
     q = lambda t, fmt: F8.Q(t, fmt, True, True)
     qx1, qx4 = q(x1, F8.E4M3), q(x4, F8.E4M3)
-    qw = {n: q(t, F8.E4M3) for n, t in w.items()}
+    qw = {n: F8.Q(t, F8.E4M3, True, True, weight=True) for n, t in w.items()}
     qdy1, qdy3, qdy4 = q(dy1, F8.E5M2), q(dy3, F8.E5M2), q(dy4, F8.E5M2)
     y3 = torch.empty(M, 3 * D, dtype=bf16, device=dev)
     y1 = torch.empty(M, D, dtype=bf16, device=dev)

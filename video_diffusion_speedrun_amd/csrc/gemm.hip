@@ -670,6 +670,43 @@ __device__ __forceinline__ bf16x8 frag_km64(const char* tile, int col0, int ks, 
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// ---- k-major fp8 operands (FMT 3: the weight-gradient product dW = dy^T x read straight from the token-major fp8
+// copies, no transposed copies) -----------------------------------------------------------------------------------
+// A half-tile is [128 tokens][128 bytes]: token row r holds the 128 output rows / columns of this half (64-row groups
+// of the two wave rows, or 32-column groups of the four wave columns).  16-byte chunk c of row r is stored at chunk
+// c ^ swz8(r) -- the image of csrc/attention_fp8.hip: conflict-free for ds_read_b64_tr_b8, whose 16-lane group reads an
+// 8-row x 16-byte block (lane 2q + p supplies row q, bytes 8p..; lane d receives column d, row q in byte q).  A
+// fragment = the operand of v_mfma_f32_16x16x128_f8f6f4 for the 16 columns of block db: lane (d = l & 15, g = l >> 4)
+// gets tokens 32g .. 32g+31 of column 16 db + d from four such reads.
+__device__ __forceinline__ int swz8(int row) { return ((row >> 1) & 3) | ((row >> 3) & 4); }
+__device__ __forceinline__ i32x8 frag_km8(const char* tile, int db, int lane) {
+  const int m = lane & 15, g = lane >> 4, q = m >> 1, pp = m & 1;
+  const int st = ((q >> 1) & 3) | ((g & 1) << 2);  // swz8(32 g + 8 t + q), the same for every t
+  const char* p = tile + (32 * g + q) * 128 + ((db ^ st) << 4) + 8 * pp;
+  i32x8 r;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+    const i32x2_t w = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2_t*)LDS_PTR(p + t * 8 * 128));
+    r[2 * t] = w[0];
+    r[2 * t + 1] = w[1];
+  }
+  return r;
+}
+// source byte offsets of the two 1-KiB pieces (8 token rows each) this wave stages of a k-major fp8 half-tile;
+// ld_bytes = row stride of the [tokens][columns] tensor in bytes
+template <int G, int STRIDE, int OFF>
+__device__ __forceinline__ void half_offsets_km8(unsigned (&voff)[2], int (&kchunk)[2], int wave, int lane, long ld_bytes,
+                                                 int origin) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ swz8(row);
+    kchunk[j] = 0;
+    voff[j] = (unsigned)((long)row * ld_bytes + origin + to_tile<G, STRIDE, OFF>(chunk * 16));
+  }
+}
+
 // per-lane source byte offsets of the NP 1-KiB pieces this wave stages of one half-tile (NP = 2: 16 KiB) or quarter
 // tile (NP = 1: the 8-KiB B1 of the 192-wide tiling)
 template <bool KMAJOR, int G, int STRIDE, int OFF, int NP>
@@ -722,7 +759,8 @@ __device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigne
 template <int LAYOUT, int EPI, int FMT = 0, int WN = 256>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(FMT == 0 || LAYOUT == VDS_NT, "fp8 operands are k-contiguous (transposed copies are made by the quantiser)");
+  static_assert(FMT == 0 || (FMT != 3 && LAYOUT == VDS_NT) || (FMT == 3 && LAYOUT == VDS_TN && WN == 256),
+                "fp8 operands: k-contiguous (FMT 1 / 2, NT) or both k-major (FMT 3, TN: the weight gradient)");
   using G = Geo<WN>;
   constexpr int BN = G::BN, WCOLS = G::WCOLS, NJ = G::NJ, BUF = G::BUF;
   constexpr int SLOT_A0 = G::A0, SLOT_A1 = G::A1, SLOT_B0 = G::B0, SLOT_B1 = G::B1;
@@ -770,17 +808,26 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   }
   unsigned va[2][2], vb0[2], vb1[NPB1];
   int ca[2][2], cb0[2], cb1[NPB1];
+  if constexpr (FMT == 3) {  // (p.lda / p.ldb count 2-byte units, origins are byte columns)
+    half_offsets_km8<64, 128, 0>(va[0], ca[0], wave, lane, 2 * p.lda, m0);
+    half_offsets_km8<64, 128, 64>(va[1], ca[1], wave, lane, 2 * p.lda, m0);
+    half_offsets_km8<32, 64, 0>(vb0, cb0, wave, lane, 2 * p.ldb, n0);
+    half_offsets_km8<32, 64, 32>(vb1, cb1, wave, lane, 2 * p.ldb, n0);
+  } else {
   half_offsets<A_KM, 64, 128, 0, 2>(va[0], ca[0], wave, lane, p.lda, m0);
   half_offsets<A_KM, 64, 128, 64, 2>(va[1], ca[1], wave, lane, p.lda, m0);
-  if constexpr (WN == 256) {
+  }
+  if constexpr (FMT == 3) {
+  } else if constexpr (WN == 256) {
     half_offsets<B_KM, 32, 64, 0, 2>(vb0, cb0, wave, lane, p.ldb, n0);
     half_offsets<B_KM, 32, 64, 32, 2>(vb1, cb1, wave, lane, p.ldb, n0);
   } else {
     half_offsets<B_KM, 32, 48, 0, 2>(vb0, cb0, wave, lane, p.ldb, n0);
     half_offsets<B_KM, 16, 48, 32, 1>(vb1, cb1, wave, lane, p.ldb, n0);
   }
-  const unsigned a_step = A_KM ? (unsigned)(BK * p.lda * 2) : BK * 2;
-  const unsigned b_step = B_KM ? (unsigned)(BK * p.ldb * 2) : BK * 2;
+  // (FMT 3: a K tile is 128 token rows of lda / ldb BYTES = 2 BK rows in the 2-byte units the addressing counts in)
+  const unsigned a_step = A_KM ? (unsigned)((FMT == 3 ? 2 * BK : BK) * p.lda * 2) : BK * 2;
+  const unsigned b_step = B_KM ? (unsigned)((FMT == 3 ? 2 * BK : BK) * p.ldb * 2) : BK * 2;
 
   // issue half-tile `which` (0 A0, 1 B0, 2 B1, 3 A1) of K tile T into its slot of buffer `par`
   // (= (T - kt_begin) & 1, passed as a compile-time constant so that every LDS address is base + immediate)
@@ -801,17 +848,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
 
   constexpr int KS = FMT == 0 ? 2 : 1;  // MFMA k-steps per K tile
   using frag_t = std::conditional_t<FMT == 0, bf16x8, i32x8>;
+  // The product is issued TRANSPOSED (round 4): the B-tile fragment is the MFMA's A operand and the A-tile fragment its B
+  // operand, so that a 16 x 16 accumulator block holds, in lane (c = l & 15, g = l >> 4), the FOUR CONSECUTIVE COLUMNS
+  // n = 4 g .. 4 g + 3 of output row m = c (instead of four consecutive rows of one column): the epilogue stages a
+  // block with one 16-byte LDS store per lane instead of four 4-byte ones.  Same products, same k order: bit-identical.
   auto mma = [&](const frag_t& a, const frag_t& b, f32x4 c) {
-    if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    // cbsz: format of A (0 e4m3, 1 e5m2), blgp: format of B; block scales unused (0 selects the unscaled form)
-    else return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, FMT == 2 ? 1 : 0, 0, 0, 0, 0, 0);
+    if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+    // cbsz: format of the MFMA's A operand (0 e4m3, 1 e5m2) = our B tile (always e4m3), blgp: format of its B operand
+    // = our A tile; block scales unused (0 selects the unscaled form)
+    else return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, c, 0, FMT >= 2 ? 1 : 0, 0, 0, 0, 0);
   };
   auto read_a4 = [&](const char* slot, frag_t (&fa)[4][KS]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if constexpr (FMT != 0) fa[i][ks] = frag_kc8(slot, wr * 64 + i * 16, lane);
+        if constexpr (FMT == 3) fa[i][ks] = frag_km8(slot, wr * 4 + i, lane);
+        else if constexpr (FMT != 0) fa[i][ks] = frag_kc8(slot, wr * 64 + i * 16, lane);
         else if constexpr (A_KM) fa[i][ks] = frag_km(slot, wr * 64 + i * 16, ks, lane);
         else fa[i][ks] = frag_kc(slot, wr * 64 + i * 16, ks, lane);
       }
@@ -821,7 +874,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if constexpr (FMT != 0) fb[j][ks] = frag_kc8(slot, wc * 32 + j * 16, lane);
+        if constexpr (FMT == 3) fb[j][ks] = frag_km8(slot, wc * 2 + j, lane);
+        else if constexpr (FMT != 0) fb[j][ks] = frag_kc8(slot, wc * 32 + j * 16, lane);
         else if constexpr (B_KM) fb[j][ks] = frag_km(slot, wc * 32 + j * 16, ks, lane);
         else fb[j][ks] = frag_kc(slot, wc * 32 + j * 16, ks, lane);
       }
@@ -992,11 +1046,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          stg[(i * 16 + 4 * (lane >> 4) + r) * EPI_LD + j * 16 + (lane & 15)] =
-              FMT != 0 ? acc[qa * 4 + i][j][r] * dq : acc[qa * 4 + i][j][r];
+      for (int j = 0; j < NJ; ++j) {  // lane (c, g): row i * 16 + c, columns j * 16 + 4 g .. + 3 (see `mma`)
+        f32x4 v = acc[qa * 4 + i][j];
+        if constexpr (FMT != 0) v *= dq;
+        *reinterpret_cast<f32x4*>(stg + (i * 16 + (lane & 15)) * EPI_LD + j * 16 + 4 * (lane >> 4)) = v;
+      }
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_wave_barrier();
     // sub-tiles completely inside the matrix (all but the last row / column of tiles) take the lean path
@@ -1583,8 +1637,10 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
 extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const float* scale_b, int32_t a_fmt,
                             int32_t b_fmt, const vds_fp8_out* emit, vds_stream_t stream) {
   if (!a || !a->A || !a->B || a->M <= 0 || a->N <= 0 || a->K <= 0) return VDS_ERR_ARG;
-  if (a->layout != VDS_NT || b_fmt != 0 || (a_fmt != 0 && a_fmt != 1)) return VDS_ERR_UNSUPPORTED;
+  if ((a->layout != VDS_NT && a->layout != VDS_TN) || b_fmt != 0 || (a_fmt != 0 && a_fmt != 1)) return VDS_ERR_UNSUPPORTED;
   if ((a->N & 7) || (a->K & 15) || (a->lda & 15) || (a->ldb & 15)) return VDS_ERR_ARG;
+  const bool tn = a->layout == VDS_TN;  // C[M,N] = sum_k A[k,m] B[k,n]: both operands [K, .] row-major (token-major)
+  if (tn && (a->epilogue != VDS_EPI_F32 || a_fmt != 1 || emit || (a->M & 15))) return VDS_ERR_UNSUPPORTED;
   GemmP p;
   p.M = a->M; p.N = a->N; p.K = a->K / 2;  // the kernel addresses in 2-byte units
   p.A = (const bf16_t*)a->A; p.lda = a->lda / 2;
@@ -1601,7 +1657,8 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   p.prof_k = a->K;
   p.tiles_m = cdiv(a->M, 256);
   p.tiles_n = cdiv(a->N, 256);
-  const size_t abytes = (size_t)(a->M - 1) * a->lda + a->K, bbytes = (size_t)(a->N - 1) * a->ldb + a->K;
+  const size_t abytes = tn ? (size_t)(a->K - 1) * a->lda + a->M : (size_t)(a->M - 1) * a->lda + a->K;
+  const size_t bbytes = tn ? (size_t)(a->K - 1) * a->ldb + a->N : (size_t)(a->N - 1) * a->ldb + a->K;
   if (abytes >= (1ull << 32) || bbytes >= (1ull << 32)) return VDS_ERR_UNSUPPORTED;
   p.a_bytes = (unsigned)abytes;
   p.b_bytes = (unsigned)bbytes;
@@ -1625,6 +1682,7 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
     const char* e = getenv("VDS_GEMM_TILE");
     g_force_tile = e ? atoi(e) : 0;
   }
+  if (tn) return big::launch<VDS_TN, VDS_EPI_F32, 3>(p, s);
   // 256 x 192 tiles where they save rounds (N = 1152 / 3456: see prefer_w192); not for the split-K weight gradients
   if (p.split_k == 1 && (g_force_tile == 192 || (g_force_tile == 0 && prefer_w192(a->M, a->N)))) {
     p.tiles_n = cdiv(a->N, 192);

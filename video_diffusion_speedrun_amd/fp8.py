@@ -29,6 +29,8 @@ tests/test_model_gpu.py::test_fp8_step_close_to_oracle (whole step against the f
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -43,6 +45,12 @@ E4M3, E5M2 = ops.FP8_E4M3, ops.FP8_E5M2
 # output), 16 d(cross_proj output); one more row after the blocks' rows: the text context (context_kv input, shared)
 # fp8 cross-attention (same kernels, Lk = context length): 17 q_cross output, 18 / 19 the k / v halves of the context_kv
 # output, 20 d(cross-attention output)
+# Round 4: the weight-gradient GEMMs contract the token-major (row-major) fp8 copies directly -- both operands k-major,
+# fragments by ds_read_b64_tr_b8 (vds_gemm_fp8 with layout VDS_TN) -- so NO activation or gradient needs a transposed
+# copy any more: the 1-byte transposes, the transposed halves of the quantiser passes and of the GEMM epilogues'
+# emission are gone.  VDS_FP8_TN=0 restores the NT products of transposed copies (A/B).  Weights keep both copies
+# (forward: W, input gradient: W^T; 1.3-5 M elements each).
+TN = os.environ.get("VDS_FP8_TN", "1") != "0"
 ROWS = 21
 ROW_Q, ROW_DO = 6, 9
 ROW_ATTN, ROW_CATT, ROW_XN2, ROW_DQC, ROW_DCKV, ROW_DY_AP, ROW_DY_CP = 10, 11, 12, 13, 14, 15, 16
@@ -54,12 +62,16 @@ class Q:
     __slots__ = ("q", "t", "s", "rows", "cols")
 
     def __init__(self, x: torch.Tensor = None, fmt: int = 0, rowmajor: bool = True, transposed: bool = False,
-                 hist: "AmaxHistory" = None, row: int = 0):
+                 hist: "AmaxHistory" = None, row: int = 0, weight: bool = False):
         """hist / row: this tensor's slot in the delayed-scaling table.  With a history the single quantisation pass
         scales by the previous step's amax and records the current one; without (first step, weights, inference)
-        the tensor's own amax is computed first (and recorded, so that the next step has a history)."""
+        the tensor's own amax is computed first (and recorded, so that the next step has a history).
+        transposed: the tensor is also a weight-gradient operand; with TN (default) that needs the row-major copy
+        only, except for weights (`weight=True`), whose transposed copy feeds the input-gradient GEMM."""
         if x is None:
             return
+        if TN and transposed and not weight:
+            rowmajor, transposed = True, False
         self.rows, self.cols = x.shape
         if hist is not None and hist.ready:
             self.q, self.t, self.s = ops.quant_fp8(x, fmt, hist.prev(row), rowmajor, transposed, amax_out=hist.cur(row))
@@ -72,6 +84,8 @@ class Q:
     @classmethod
     def empty(cls, M: int, K: int, fmt: int, rowmajor: bool, transposed: bool, device):
         """uninitialised buffers for a GEMM epilogue to fill (`emit_args`)"""
+        if TN and transposed:
+            rowmajor, transposed = True, False
         o = cls()
         o.rows, o.cols = M, K
         o.q = torch.empty(M, K, dtype=ops.fp8_dtypes[fmt], device=device) if rowmajor else None
@@ -86,7 +100,7 @@ class Q:
         o = cls()
         o.rows, o.cols = q.shape
         o.q, o.s = q, s
-        o.t = ops.transpose_fp8(q) if transposed else None
+        o.t = ops.transpose_fp8(q) if (transposed and not TN) else None
         return o
 
     def emit_args(self, fmt: int, amax_in, amax_out, colsum=None):
@@ -219,4 +233,7 @@ def wgrad(dyq: Q, xq: Q, dW: torch.Tensor, n_cu: int = 256):
     M, N, K = dyq.rows, dyq.cols, xq.cols
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     split = ops._wgrad_split(tiles, (M + 127) // 128, n_cu)
-    ops.gemm_fp8(EPI_F32, N, K, M, dyq.t, xq.t, dyq.s, xq.s, E5M2, dW, K, split_k=-split)
+    if TN and dyq.q is not None and xq.q is not None and N % 16 == 0:
+        ops.gemm_fp8(EPI_F32, N, K, M, dyq.q, xq.q, dyq.s, xq.s, E5M2, dW, K, split_k=-split, tn=True)
+    else:
+        ops.gemm_fp8(EPI_F32, N, K, M, dyq.t, xq.t, dyq.s, xq.s, E5M2, dW, K, split_k=-split)

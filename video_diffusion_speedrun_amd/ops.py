@@ -130,9 +130,18 @@ def quant_fp8(x: torch.Tensor, fmt: int, amax: torch.Tensor, rowmajor: bool = Tr
 
 
 def gemm_fp8(epi: int, M: int, N: int, K: int, A, B, sa, sb, a_fmt: int, Cp=None, ldc=0, C2=None, ldc2=0, bias=None,
-             aux=None, ldaux=0, gate=None, ldgate=0, rows_per_batch=0, split_k=1, emit=None):
+             aux=None, ldaux=0, gate=None, ldgate=0, rows_per_batch=0, split_k=1, emit=None, tn: bool = False):
     """C = epilogue((A[M,K] . B[N,K]^T) * sa * sb), A / B contiguous fp8 (A e4m3 or e5m2, B e4m3).
+    tn: C[M,N] = sum_k A[k,m] B[k,n] with A [K,M] (e5m2) and B [K,N] (e4m3) row-major -- the weight gradient read
+    straight from the token-major fp8 copies (EPI_F32 only).
     emit = dict(q=, qt=, amax_in=, amax_out=, dq_out=, fmt=, colsum=): fp8 copies of the epilogue result (vds_fp8_out)."""
+    if tn:
+        assert A.is_contiguous() and B.is_contiguous() and A.shape == (K, M) and B.shape == (K, N) and emit is None
+        a = GemmArgs(VDS_TN, epi, M, N, K, _p(A), M, _p(B), N, _p(Cp), ldc, _p(C2), ldc2, _p(bias), _p(aux), ldaux,
+                     _p(gate), ldgate, rows_per_batch, split_k, None)
+        check(_lib.load().vds_gemm_fp8(C.byref(a), _p(sa), _p(sb), a_fmt, 0, None, _stream()),
+              f"vds_gemm_fp8(tn,M={M},N={N},K={K})")
+        return
     assert A.is_contiguous() and B.is_contiguous() and A.shape == (M, K) and B.shape == (N, K)
     a = GemmArgs(VDS_NT, epi, M, N, K, _p(A), K, _p(B), K, _p(Cp), ldc, _p(C2), ldc2, _p(bias), _p(aux), ldaux,
                  _p(gate), ldgate, rows_per_batch, split_k, None)
