@@ -1392,15 +1392,18 @@ static int g_force_tile = -1;  // -1: read VDS_GEMM_TILE on first use; 0 auto; 1
 // 7 instead of 8 LDS-DMA pieces per K tile feed 48 instead of 64 MFMAs, three barrier pairs instead of four, and the
 // epilogue issues the same number of store instructions with a quarter of their lanes idle -- so at B = 12 (385 row
 // tiles) it LOSES everywhere: N = 1152: 6 column tiles -> 10 rounds x 0.87 = 8.7 against 5 -> 8 rounds (measured 0.255
-// against 0.235 ms); N = 3456: 28 x 0.87 against 22.  It wins where the round count does not grow: per-GPU batches of
-// 1-2 (65 row tiles: 325 tiles of 256 and 390 of 192 are both two rounds) and the sampler.  VDS_GEMM_W192_FACTOR
-// (default 1.16 = 0.87 / 0.75) is the measured time per unit of MFMA work relative to the 256-wide tile.
+// against 0.235 ms); N = 3456: 28 x 0.87 against 22.  Where the round count does not grow (per-GPU batches of 1-2: 325
+// tiles of 256 and 390 of 192 are both two rounds) the whole step measured equal within noise (B = 1: 103.9 vs 104.6
+// ms, B = 2: 175.1 vs 174.7 ms, profiles/r04/).  So the tiling is NOT chosen by default: VDS_GEMM_W192_FACTOR=f
+// enables the cost model with f = time per unit of MFMA work relative to the 256-wide tile (measured 1.16),
+// vds_gemm_force_tile(192) / VDS_GEMM_TILE=192 force it (tests run it on every GEMM case).
 static bool prefer_w192(long M, long N) {
   static double f = -1.0;
   if (f < 0) {
     const char* e = getenv("VDS_GEMM_W192_FACTOR");
-    f = e ? atof(e) : 1.16;
+    f = e ? atof(e) : 0.0;
   }
+  if (f <= 0.0) return false;
   const long tm = (M + 255) / 256;
   const double c256 = (double)((tm * ((N + 255) / 256) + 255) / 256);
   const double c192 = (double)((tm * ((N + 191) / 192) + 255) / 256) * 0.75 * f;
