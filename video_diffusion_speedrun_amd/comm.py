@@ -112,7 +112,7 @@ def destroy():
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def all_gather(out: torch.Tensor, inp: torch.Tensor):

@@ -48,7 +48,7 @@ constexpr int TILE = 128 * ROWB;     // one streamed tile: 128 rows
 constexpr float P_SHIFT = 8.0f;      // P is held as P * 2^8
 constexpr float LOGDOM_BIAS = 56.0f - 0.344f;  // forward: e4m3 byte of 2^x = round(8 x + LOGDOM_BIAS) (attn8_fwd_kernel, P_BYTE)
 constexpr float BYTE_LIMIT = 126.4f;  // forward: raise the running maximum when a byte would exceed 0x7E (448; 0x7F is NaN)
-constexpr float SEED_HEADROOM = 4.0f; // forward: the first block's maximum + 4 seeds the running maximum
+constexpr float SEED_HEADROOM = 2.0f; // forward: the first block's maximum + 2 seeds the running maximum (round 4: was 4)
 
 struct Attn8P {
   int B, H, Lq, Lk, hd;
@@ -254,9 +254,20 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
   VDS_WAIT_VM(0);
   __syncthreads();
 
-  // seed the running maxima from the first 16-key block plus SEED_HEADROOM: the largest P of the first tiles is then
-  // ~2^(8 - headroom), 13+ binades above e4m3's smallest value, and the maximum is raised (and a tile recomputed)
-  // only when a later score exceeds the seed by more than headroom + 0.84 in the log2 domain
+  // seed the running maxima from MFMA block 0 of the first tile -- tile rows 0-3, 32-35, 64-67, 96-99 (the rows
+  // `fr.row<0>` addresses; keys 0-3 are register tokens, the typical attention sinks) -- plus SEED_HEADROOM: the largest
+  // P of the first tiles is then ~2^(8 - headroom), and the maximum is raised (and a tile recomputed) only when a later
+  // score exceeds the seed by more than headroom + 0.84 in the log2 domain.
+  // SUPPORTED DYNAMIC RANGE of a row: P is held as P * 2^8 relative to the running maximum m and leaves the log-domain
+  // pack as byte 0 below 2^-6.9, i.e. a key whose score lies more than 14.9 binades (10.3 nat) under m contributes
+  // nothing to O or to the LSE, and between 14 and 14.9 binades under m (bytes 1-7, e4m3's subnormals, where the
+  // log-domain byte is no longer the value's encoding) it is under-weighted by up to 30 %.  m is at most SEED_HEADROOM
+  // = 2 binades above the row's true maximum (when block 0 holds it and nothing ever raises m), so every key within 12
+  // binades (8.3 nat, a factor 4096) of the row maximum is represented with e4m3's relative precision; for comparison, e4m3 P relative to the row maximum itself (the usual fp8 flash-attention
+  // form) bottoms out at 9 binades.  (Round 3 used 4 binades of headroom -- fewer raises on random data, 10.9 binades
+  // of range; with the register tokens as sinks a diffuse 8k-key tail 11-12 binades under them is realistic.)
+  // tests/test_attn_fp8_gpu.py::test_attn_fp8_forward_sink_plus_diffuse_tail pins the in-range behaviour at the
+  // headline length (sinks 2^9 and 2^12 above an 8k-key tail) and records the error outside it.
   {
     const i32x8 kf = fr.row<0>(smem);
 #pragma unroll

@@ -20,7 +20,10 @@ f32 = torch.float32
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of torch's current HIP stream.  (`torch.cuda.current_stream().cuda_stream` builds a Stream object per
+    call: 2.65 us against 0.3 us for this form -- a third of the host cost of a small launch, and launch-bound
+    workloads (C1: ~1600 launches of a few microseconds per step) are host-bound; tools/bench_host_overhead.py)"""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
