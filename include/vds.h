@@ -80,10 +80,13 @@ int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);
 int vds_gemm_force_tile(int32_t tile);
 
 /* The same GEMM with OCP fp8 operands (BASELINE config 5; no reference counterpart -- the reference trains in
- * bf16): layout VDS_NT only, A[M,K] and B[N,K] one byte per element (a_fmt / b_fmt: 0 = e4m3fn, 1 = e5m2; B must
+ * bf16): layout VDS_NT: A[M,K] and B[N,K] one byte per element (a_fmt / b_fmt: 0 = e4m3fn, 1 = e5m2; B must
  * be e4m3fn), K, lda, ldb multiples of 16.  C = epilogue((sum_k A B) * *scale_a * *scale_b) with per-tensor
  * dequantisation factors read from device memory (NULL = 1).  Runs v_mfma_f32_16x16x128_f8f6f4 (2x the bf16
- * MFMA rate).  Input / weight gradients are NT products of the transposed copies written by vds_quant_fp8.
+ * MFMA rate).  Input gradients are NT products with the transposed WEIGHT copy written by vds_quant_fp8.
+ * layout VDS_TN (round 4; epilogue VDS_EPI_F32, a_fmt = 1 only): C[M,N] = sum_k A[k,m] B[k,n] with A [K,M] e5m2 and
+ * B [K,N] e4m3, both row-major, K, M, lda, ldb multiples of 16 -- the weight gradient dW = dy^T x contracted straight
+ * from the token-major fp8 copies (both operands k-major: ds_read_b64_tr_b8 fragments), split_k as vds_gemm_bf16.
  *
  * emit (may be NULL; VDS_EPI_BIAS_GELU / VDS_EPI_DGELU only): the epilogue also writes its result -- gelu(pre) resp.
  * acc * gelu'(aux), rounded to bf16 first -- as fp8 for the next GEMMs, so that no separate quantisation pass reads

@@ -3,13 +3,17 @@
 #     bash tools/collect_profiles.sh r02        (writes gpurun_out/prof_r02/..., summaries are then copied into profiles/)
 # Counter passes are separate runs (--pmc with --kernel-trace only), as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 PY=python3
 # 1. per-kernel time of the bench command itself
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o c3b --output-format csv -- $PY bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o c3b --output-format csv -- $PY bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/bench_under_rocprof.log" 2>&1
+# 1b. the same command with 4 more steps: the difference of the two kernel_stats tables = launches per train step (what
+#     is left of torch's own kernels -- fills, copies, RNG -- in the step, as opposed to model / optimizer construction)
+rocprofv3 --kernel-trace --stats -d "$OUT/stats7" -o c3b7 --output-format csv -- $PY bench.py --steps 7 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/bench7_under_rocprof.log" 2>&1
+find "$OUT/stats7" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c3b_7steps_kernel_stats.csv"
 # 2. HBM-side bytes of the attention kernels at the bench shape (B = 12): FETCH_SIZE and WRITE_SIZE cannot share a pass
 for c in FETCH_SIZE WRITE_SIZE; do
   B=12 REPS=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o x --output-format csv -- $PY tools/prof_attn.py > "$OUT/pmc_$c.log" 2>&1
