@@ -756,7 +756,10 @@ __device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigne
 // 128 k instead of 64, one v_mfma_f32_16x16x128_f8f6f4 replaces two 16x16x32 bf16 MFMAs in the same 32 cycles --
 // bytes staged, LDS reads and the phase schedule are identical, the contraction per K tile doubles.  The
 // addressing below counts in 2-byte units (p.K, lda, ldb = bytes / 2).
-template <int LAYOUT, int EPI, int FMT = 0, int WN = 256>
+#ifndef VDS_GEMM_NPH
+#define VDS_GEMM_NPH 2  // phases per K tile of the 256-wide tiling (4: the loop of rounds 1-3, for A/B builds)
+#endif
+template <int LAYOUT, int EPI, int FMT = 0, int WN = 256, int NPH = VDS_GEMM_NPH>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(FMT == 0 || (FMT != 3 && LAYOUT == VDS_NT) || (FMT == 3 && LAYOUT == VDS_TN && WN == 256),
@@ -881,7 +884,63 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
       }
   };
 
-  if constexpr (WN == 256) {
+  if constexpr (WN == 256 && NPH == 2) {
+  // ---- round 4 (default): TWO phases of 32 MFMAs per K tile -- quadrant row 0 <- A0, B0, B1; quadrant row 1 <- A1 with
+  // both B halves kept in registers -- i.e. 4 barriers per K tile instead of 8 and the same fragment registers.  Issue
+  // order per K tile: A0 B0 B1 | A1; A1(T+1) is issued in phase 0 of tile T, A0 B0 B1 of tile T+2 in phase 1; each wait
+  // leaves 8 pieces (four half-tiles) in flight and retires a half-tile one phase before it is read; a slot is
+  // re-staged one phase after its last read (the distances of the four-phase loop below, which NPH = 4 keeps for A/B:
+  // VDS_GEMM_PHASES=4).  Same-process A/B, B = 12 (profiles/r04/gemm_2phase_vs_4phase.log): qkv forward 0.705 -> 0.668
+  // ms, q_cross 0.252 -> 0.237, fc1 dgrad 0.945 -> 0.908, 8192^3 1.40 -> 1.50 PFLOP/s; results bit-identical.
+  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0);
+  issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1); issue(kt_begin + 1, 2, 1);
+  VDS_WAIT_VM(8);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
+  frag_t fa[4][KS], fb0[2][KS], fb1[2][KS];
+  auto quad = [&](int qa, int qb, frag_t (&fb)[2][KS]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[qa * 4 + i][qb * 2 + j] = mma(fa[i][ks], fb[j][ks], acc[qa * 4 + i][qb * 2 + j]);
+  };
+  auto k_tile = [&](int T, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    const char* buf = ring + par * BUF;
+    // ---- phase 0: quadrant row 0 <- A0, B0, B1 ----
+    read_a4(buf + SLOT_A0, fa);
+    read_b2(buf + SLOT_B0, fb0);
+    read_b2(buf + SLOT_B1, fb1);
+    issue(T + 1, 3, par ^ 1);
+    VDS_WAIT_LGKM0();
+    VDS_WAIT_VM(8);  // A1(T) landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    quad(0, 0, fb0);
+    quad(0, 1, fb1);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: quadrant row 1 <- A1 (B0, B1 in registers) ----
+    read_a4(buf + SLOT_A1, fa);
+    issue(T + 2, 0, par);
+    issue(T + 2, 1, par);
+    issue(T + 2, 2, par);
+    VDS_WAIT_LGKM0();
+    VDS_WAIT_VM(8);  // A0, B0, B1 of tile T+1 landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    quad(1, 1, fb1);
+    quad(1, 0, fb0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int T = kt_begin; T < kt_end; T += 2) {
+    k_tile(T, std::integral_constant<int, 0>{});
+    if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
+  }
+  } else if constexpr (WN == 256) {
   // ---- prologue: 7 half-tiles in flight, A0 / B0 of the first tile landed -------------------
   issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0);
   issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1); issue(kt_begin + 1, 2, 1);
@@ -1133,13 +1192,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   }
 }
 
-template <int LAYOUT, int EPI, int FMT = 0, int WN = 256>
+template <int LAYOUT, int EPI, int FMT = 0, int WN = 256, int NPH = VDS_GEMM_NPH>
 int launch(const GemmP& p, hipStream_t s) {
   constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
   constexpr int LDS_TOTAL = LDS_BYTES + (USE_LUT ? LUT_BYTES : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI, FMT, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI, FMT, WN, NPH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     attr_set = true;
   }
@@ -1151,7 +1210,7 @@ int launch(const GemmP& p, hipStream_t s) {
   vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : LAYOUT == VDS_NN ? VDS_PROF_GEMM_NN
                                                                                                        : VDS_PROF_GEMM_TN,
                     s, 2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
-  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT, WN>), grid, dim3(512), LDS_TOTAL, s, p);
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT, WN, NPH>), grid, dim3(512), LDS_TOTAL, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 }  // namespace big
@@ -1604,6 +1663,15 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     GOW(VDS_NN, VDS_EPI_STORE)
     GOW(VDS_NN, VDS_EPI_DGELU)
 #undef GOW
+  }
+  if (use_big && a->epilogue == VDS_EPI_STORE && a->layout != VDS_TN) {
+    const char* e = getenv("VDS_GEMM_PHASES");  // A/B knob, read per call: 4 = the four-phase K tile of rounds 1-3
+    if (e && atoi(e) == 4) {
+      p.tiles_m = tm;
+      p.tiles_n = tn;
+      return a->layout == VDS_NT ? big::launch<VDS_NT, VDS_EPI_STORE, 0, 256, 4>(p, s)
+                                 : big::launch<VDS_NN, VDS_EPI_STORE, 0, 256, 4>(p, s);
+    }
   }
   if (use_big) {
     p.tiles_m = tm;
