@@ -52,7 +52,7 @@ for name, N, K in (("qkv", 3 * D, D), ("proj", D, D), ("fc1", 4 * D, D), ("fc2",
     fl = 2 * Mx * N * K
     rows = (("NT fwd", lambda: ops.linear_fwd(x, w, None, out=y), (256, 2, 128, 0)),
             ("NN dgrad", lambda: ops.linear_dgrad(dy, w), (256, 2, 128, 0)),
-            ("TN wgrad", lambda: ops.linear_wgrad(dy, x, dW), (128, 2, 0)))
+            ("TN wgrad", lambda: ops.linear_wgrad(dy, x, dW), (128, 2, 256, 0)))
     for tag, fn, tiles in rows:
         res = ab({t: forced(t, fn) for t in tiles})
         print(f"{tag:9s} {name:6s} M{Mx} N{N} K{K:5d}  " +
