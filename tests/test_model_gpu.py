@@ -611,8 +611,16 @@ def test_graph_replay_with_fp8_keeps_rolling_the_amax_history(vds):
     assert gs.n_replays >= 3  # (fp8 delays the capture until the history is armed)
     used = seen[-1] > 0
     assert int(used.sum()) >= 10 * cfg.depth
-    # the inputs grow from step to step: every used row's scale source must have moved during the replays
-    moved = (seen[-1] != seen[-3]) | ~used
+    # the inputs grow from step to step: every used row's scale source must have moved during the replays (a bf16
+    # maximum can repeat by chance between two given steps: any change over the replayed steps counts).  Exempt: the
+    # weight rows (round 4: weights use delayed scaling too) of parameters the muP table barely trains -- context_kv is
+    # a constant class (lr x 0.01, train.py:287), its bf16 amax legitimately stands still -- they must only be recorded.
+    from video_diffusion_speedrun_amd import fp8 as F8
+    moved = (seen[-1] != seen[-3]) | (seen[-2] != seen[-4]) | (seen[-1] != seen[-2]) | ~used
+    for i in range(cfg.depth):
+        r = F8.ROWS * i + F8.ROW_W + 3  # context_kv.weight
+        assert float(seen[-1][r]) > 0
+        moved[r] = True
     assert bool(moved.all()), torch.nonzero(~moved).flatten().tolist()
 
 

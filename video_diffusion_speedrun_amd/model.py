@@ -345,7 +345,7 @@ class DiTBlock(nn.Module):
         if f8:
             if not pemit:
                 q_xn1 = F8.Q(xn1, F8.E4M3, True, save, hist, F8.ROWS * i + 2)
-            q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save, weight=True)
+            q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 0, weight=True)
             qkv = torch.empty(B * L, 3 * D, dtype=bf16, device=dev)
             F8.fwd(q_xn1, q_wqkv, qkv, Wo("qkv.bias"))
         else:
@@ -378,7 +378,7 @@ class DiTBlock(nn.Module):
         q_attn = q_wap = q_xn2 = q_wqc = q_wkv = q_catt = q_wcp = None
         if f8l:
             q_attn = F8.Q(attn, F8.E4M3, True, save, hist, R0 + F8.ROW_ATTN)
-            q_wap = F8.Q(W("attn_proj.weight"), F8.E4M3, True, save, weight=True)
+            q_wap = F8.Q(W("attn_proj.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 1, weight=True)
             y_sa, X1 = F8.fwd_gate_res(q_attn, q_wap, None, mod, 2 * D, X, L)
         else:
             y_sa, X1 = ops.linear_fwd_gate_res(attn, W("attn_proj.weight"), None, mod, 2 * D, X, L)
@@ -396,10 +396,10 @@ class DiTBlock(nn.Module):
             if f8c:
                 if q_xn2 is None:
                     q_xn2 = F8.Q(xn2, F8.E4M3, True, save, hist, R0 + F8.ROW_XN2)
-                q_wqc = F8.Q(W("q_cross.weight"), F8.E4M3, True, save, weight=True)
+                q_wqc = F8.Q(W("q_cross.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 2, weight=True)
                 qc = torch.empty(B * L, D, dtype=bf16, device=dev)
                 F8.fwd(q_xn2, q_wqc, qc, Wo("q_cross.bias"))
-                q_wkv = F8.Q(W("context_kv.weight"), F8.E4M3, True, save, weight=True)
+                q_wkv = F8.Q(W("context_kv.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 3, weight=True)
                 ckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
                 F8.fwd(q_ctx, q_wkv, ckv, Wo("context_kv.bias"))
             else:
@@ -426,7 +426,7 @@ class DiTBlock(nn.Module):
                         ops.absmax(t, fp8_hist.cur(R0 + F8.ROW_QC + j))
             if f8c:
                 q_catt = F8.Q(catt, F8.E4M3, True, save, hist, R0 + F8.ROW_CATT)
-                q_wcp = F8.Q(W("cross_proj.weight"), F8.E4M3, True, save, weight=True)
+                q_wcp = F8.Q(W("cross_proj.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 4, weight=True)
                 y_ca, X2 = F8.fwd_gate_res(q_catt, q_wcp, None, mod, 5 * D, X1, L)
             else:
                 y_ca, X2 = ops.linear_fwd_gate_res(catt, W("cross_proj.weight"), None, mod, 5 * D, X1, L)
@@ -443,14 +443,14 @@ class DiTBlock(nn.Module):
         if f8:
             if not pemit:
                 q_xn3 = F8.Q(xn3, F8.E4M3, True, save, hist, F8.ROWS * i + 3)
-            q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save, weight=True)
+            q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 5, weight=True)
             if emit:  # gelu(fc1) leaves the GEMM as fp8
                 hpre, q_hact = F8.fwd_gelu_emit(q_xn3, q_w1, W("mlp.0.bias"), hist.prev(F8.ROWS * i), hist.cur(F8.ROWS * i), save)
                 hact = None
             else:
                 hpre, hact = F8.fwd_gelu(q_xn3, q_w1, W("mlp.0.bias"))
                 q_hact = F8.Q(hact, F8.E4M3, True, save, hist, F8.ROWS * i)
-            q_w2 = F8.Q(W("mlp.2.weight"), F8.E4M3, True, save, weight=True)
+            q_w2 = F8.Q(W("mlp.2.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 6, weight=True)
             y_mlp, X3 = F8.fwd_gate_res(q_hact, q_w2, W("mlp.2.bias"), mod, 8 * D, X2, L)
         else:
             hpre, hact = ops.linear_fwd_gelu(xn3, W("mlp.0.weight"), W("mlp.0.bias"))
