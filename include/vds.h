@@ -401,7 +401,8 @@ int vds_cast_bf16_f32(const void* src, float* dst, int64_t n, vds_stream_t strea
  * deq: device float[8] = {s_q, s_k, s_v, s_do, E, -, -, -}: dequantisation factors (x = x_q * s) and the exponent E with
  * s_q s_k log2(e) / sqrt(head_dim) = 2^-E exactly (the kernels' block-scaled MFMAs rely on it), written by the same two
  * producers.
- * o: bf16, any strides (last dim contiguous); lse f32 [B,H,Lq]; dq, dk, dv: bf16 strided like attention's.
+ * o: bf16, any strides (last dim contiguous); lse f32 [B,H,Lq]; dq, dk, dv: bf16 strided like attention's.  o and dq
+ * are written with 16-byte stores: base 16-byte aligned, strides multiples of 8 elements (else VDS_ERR_ARG).
  * stats: the f32 [2,B,H,Lq] workspace vds_attn_fp8_delta filled (vds_attn_fp8_bwd_workspace_bytes).  head_dim 72. */
 typedef struct vds_attn_fp8_args {
   int32_t B, H, Lq, Lk, head_dim;
@@ -414,6 +415,14 @@ typedef struct vds_attn_fp8_args {
   void* dv; int64_t dv_sb, dv_sh, dv_sl;
   const float* stats;
   const float* deq;
+  /* round 4, optional (NULL = off): fp8 copies written by the kernels' epilogues in the layout of the following
+   * linear layer's operand -- token-major [B*Lq, H*head_dim] bytes, row stride *_ld bytes -- so that no quantisation
+   * pass reads the bf16 tensor back.  vds_attn_fp8_fwd: o_q = O as e4m3; vds_attn_fp8_bwd: dq_q = dQ as e5m2 (dq may
+   * then be NULL: no bf16 dQ is written).  Values are the bf16-rounded results scaled by fmax / *e_amax_prev (delayed
+   * scaling, saturating; 0 = unscaled), *e_dq_out = the dequantisation factor, *e_amax_cur = max(*e_amax_cur, max |x|). */
+  void* o_q; int64_t o_q_ld;
+  void* dq_q; int64_t dq_q_ld;
+  const float* e_amax_prev; float* e_amax_cur; float* e_dq_out;
 } vds_attn_fp8_args;
 int vds_attn_fp8_supported(int32_t head_dim); /* 1 / 0 */
 int vds_attn_fp8_fwd(const vds_attn_fp8_args* a, vds_stream_t stream);

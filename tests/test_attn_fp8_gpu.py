@@ -195,6 +195,55 @@ def test_attn_fp8_backward_vs_fp32_on_dequantised_operands(ops, parity_log, L, L
     assert figs["dk_rel"] <= 1.2e-1 and figs["dk_cos"] >= 0.993, figs
 
 
+@pytest.mark.parametrize("L,Lk", [(300, None), (1040, 512)], ids=["self_ragged300", "cross_Lq1040_Lk512"])
+@pytest.mark.parametrize("headroom", [1.0, 0.6, 0.0], ids=["amax_exact", "amax_stale_saturates", "no_history_unscaled"])
+def test_attn_fp8_epilogues_emit_the_quantised_copies_of_their_results(ops, L, Lk, headroom):
+    """round 4: O (e4m3) and dQ (e5m2) leave the attention kernels as the token-major fp8 operands of the next linear
+    layer.  They must be bit-identical to vds_quant_fp8 of the bf16 results with the same (previous-step) amax, record
+    the current amax, and leave the bf16 results untouched; dq=None writes the fp8 copy only."""
+    dev = torch.device("cuda")
+    B, H = 2, 3
+    (q8, k8, v8), deq, _ = make_qkv(B, H, L, 21, dev, Lk=Lk)
+    o0 = torch.empty(B * L, H * HD, dtype=bf16, device=dev)
+    lse = torch.empty(B, H, L, dtype=f32, device=dev)
+    assert ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(o0, B, L, H, HD), lse, HD) is None
+    prev = (o0.float().abs().max() * headroom).reshape(1)
+    cur = torch.zeros(1, dtype=f32, device=dev)
+    o1 = torch.empty_like(o0)
+    oq, s = ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(o1, B, L, H, HD), lse, HD, emit=(prev, cur))
+    want, _, ws = ops.quant_fp8(o0, 0, prev)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1)
+    assert torch.equal(oq.view(torch.uint8), want.view(torch.uint8))
+    assert s.item() == ws.item() and cur.item() == o0.float().abs().max().item()
+    if headroom == 0.6:
+        assert int((oq.view(torch.uint8) & 0x7f).max()) == 0x7e  # saturated at 448, never the NaN pattern
+    # backward: dQ as e5m2
+    g = torch.Generator().manual_seed(6)
+    do = (torch.randn(B * L, H * HD, generator=g) * 0.02).to(bf16).to(dev)
+    doq = torch.zeros(B, H, L, ROW, dtype=E5, device=dev)
+    stats = ops.attn_fp8_delta(o0, do, lse, doq, do.float().abs().max().reshape(1), torch.zeros(1, dtype=f32, device=dev),
+                               deq, B, H, L, HD)
+    Lkk = k8.shape[2]
+    dq0 = torch.empty(B * L, H * HD, dtype=bf16, device=dev)
+    dkv = [torch.empty(B * Lkk, H * HD, dtype=bf16, device=dev) for _ in range(4)]
+    hv = ops.heads_view
+    assert ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, hv(dq0, B, L, H, HD), hv(dkv[0], B, Lkk, H, HD),
+                            hv(dkv[1], B, Lkk, H, HD), HD) is None
+    prev = (dq0.float().abs().max() * headroom).reshape(1)
+    for with_bf16 in (True, False):
+        cur = torch.zeros(1, dtype=f32, device=dev)
+        dq1 = torch.full_like(dq0, 7.0)
+        dqq, s = ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, hv(dq1, B, L, H, HD) if with_bf16 else None,
+                                  hv(dkv[2], B, Lkk, H, HD), hv(dkv[3], B, Lkk, H, HD), HD, emit_dq=(prev, cur))
+        want, _, ws = ops.quant_fp8(dq0, 1, prev)
+        torch.cuda.synchronize()
+        assert torch.equal(dq1, dq0) if with_bf16 else bool((dq1 == 7.0).all())
+        assert torch.equal(dqq.view(torch.uint8), want.view(torch.uint8))
+        assert s.item() == ws.item() and cur.item() == dq0.float().abs().max().item()
+        assert torch.equal(dkv[0], dkv[2]) and torch.equal(dkv[1], dkv[3])
+
+
 @pytest.mark.parametrize("L,Lk", [(300, 300), (700, 300), (8208, 8208)],
                          ids=["ragged300", "cross_Lq700_Lk300", "headline_8208"])
 def test_attn_fp8_backward_is_finite_when_every_score_is_very_negative(ops, parity_log, L, Lk):

@@ -46,7 +46,9 @@ class Attn8Args(C.Structure):  # vds_attn_fp8_args
                 ("dq", c_vp), ("dq_sb", c_i64), ("dq_sh", c_i64), ("dq_sl", c_i64),
                 ("dk", c_vp), ("dk_sb", c_i64), ("dk_sh", c_i64), ("dk_sl", c_i64),
                 ("dv", c_vp), ("dv_sb", c_i64), ("dv_sh", c_i64), ("dv_sl", c_i64),
-                ("stats", c_vp), ("deq", c_vp)]
+                ("stats", c_vp), ("deq", c_vp),
+                ("o_q", c_vp), ("o_q_ld", c_i64), ("dq_q", c_vp), ("dq_q_ld", c_i64),
+                ("e_amax_prev", c_vp), ("e_amax_cur", c_vp), ("e_dq_out", c_vp)]
 
 
 class Fp8Out(C.Structure):  # vds_fp8_out

@@ -54,6 +54,8 @@ struct AttnP {
   // dkv_reduce_kernel sums into the bf16 outputs (run_bwd picks q_split; 1 = the kernel stores bf16 itself)
   int q_split;
   float* dkv_part;
+  // 16-byte row stores in the 16x16x32 kernels' epilogues (store_block_bf16_t): rows 16-byte aligned
+  int wide_o, wide_dq, wide_dkv;
 };
 
 // ---- LDS image (a): rows x HDP bf16, 8x32 sub-tiles of 512 B -------------------------------
@@ -1176,19 +1178,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int krow = key0 + cb * 16 + (lane & 15);
-    if (krow >= p.Lk) continue;
-    bf16_t* dkp = p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl;
-    bf16_t* dvp = p.dv + b * p.dv_sb + hh * p.dv_sh + (long)krow * p.dv_sl;
+    float vk[NDB][4], vv[NDB][4];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-      const int d = db * 16 + 4 * g;
-      if (d >= p.hd) continue;
-      const u32x2 wk = {pack_bf2(dk[db][cb][0] * p.scale, dk[db][cb][1] * p.scale),
-                        pack_bf2(dk[db][cb][2] * p.scale, dk[db][cb][3] * p.scale)};
-      const u32x2 wv = {pack_bf2(dv[db][cb][0], dv[db][cb][1]), pack_bf2(dv[db][cb][2], dv[db][cb][3])};
-      *reinterpret_cast<u32x2*>(dkp + d) = wk;
-      *reinterpret_cast<u32x2*>(dvp + d) = wv;
-    }
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { vk[db][e] = dk[db][cb][e]; vv[db][e] = dv[db][cb][e]; }
+    store_block_bf16_t(vk, p.scale, p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl, p.hd, g, krow < p.Lk, p.wide_dkv);
+    store_block_bf16_t(vv, 1.0f, p.dv + b * p.dv_sb + hh * p.dv_sh + (long)krow * p.dv_sl, p.hd, g, krow < p.Lk, p.wide_dkv);
   }
 }
 
@@ -1356,19 +1352,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
     const int qrow = qrow0 + 16 * cb;
     // the denominator is row head_dim (= 64 + 4*2 + 0: lanes g = 2, register 0 of block 4) of O^T
     const float lt = __shfl(o[NDB - 1][cb][0], (lane & 15) | 32, 64);
-    if (qrow < p.Lq) {
-      const float inv = 1.0f / lt;
-      bf16_t* orow = p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl;
+    float vo[NDB][4];
 #pragma unroll
-      for (int db = 0; db < NDB; ++db) {
-        const int d = db * 16 + 4 * g;
-        if (d < p.hd) {
-          const u32x2 w = {pack_bf2(o[db][cb][0] * inv, o[db][cb][1] * inv), pack_bf2(o[db][cb][2] * inv, o[db][cb][3] * inv)};
-          *reinterpret_cast<u32x2*>(orow + d) = w;
-        }
-      }
-      if (g == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m[cb] + __builtin_amdgcn_logf(lt)) * LN2;
-    }
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vo[db][e] = o[db][cb][e];
+    store_block_bf16_t(vo, 1.0f / lt, p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, p.hd, g, qrow < p.Lq, p.wide_o);
+    if (qrow < p.Lq && g == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m[cb] + __builtin_amdgcn_logf(lt)) * LN2;
   }
 }
 
@@ -1505,17 +1495,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int qrow = qrow0 + 16 * cb;
-    if (qrow >= p.Lq) continue;
-    bf16_t* dqp = p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl;
+    float vq[NDB][4];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-      const int d = db * 16 + 4 * g;
-      if (d >= p.hd) continue;
-      const u32x2 w = {pack_bf2(dq[db][cb][0] * p.scale, dq[db][cb][1] * p.scale),
-                       pack_bf2(dq[db][cb][2] * p.scale, dq[db][cb][3] * p.scale)};
-      *reinterpret_cast<u32x2*>(dqp + d) = w;
-    }
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vq[db][e] = dq[db][cb][e];
+    store_block_bf16_t(vq, p.scale, p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl, p.hd, g, qrow < p.Lq, p.wide_dq);
   }
+}
+
+bool rows16(const void* base, long sb, long sh, long sl) {
+  return base && ((uintptr_t)base % 16 == 0) && (sb % 8 == 0) && (sh % 8 == 0) && (sl % 8 == 0);
 }
 
 AttnP to_p(const vds_attn_args* a) {
@@ -1537,6 +1527,10 @@ AttnP to_p(const vds_attn_args* a) {
   p.kv_pad_ones = a->kv_pad_ones;
   p.q_split = 1;
   p.dkv_part = nullptr;
+  const bool wide_on = !(getenv("VDS_ATTN_WIDE_STORES") && getenv("VDS_ATTN_WIDE_STORES")[0] == '0');  // A/B knob
+  p.wide_o = wide_on && p.hd > 64 && rows16(p.o, p.o_sb, p.o_sh, p.o_sl);
+  p.wide_dq = wide_on && p.hd > 64 && rows16(p.dq, p.dq_sb, p.dq_sh, p.dq_sl);
+  p.wide_dkv = wide_on && p.hd > 64 && rows16(p.dk, p.dk_sb, p.dk_sh, p.dk_sl) && rows16(p.dv, p.dv_sb, p.dv_sh, p.dv_sl);
   return p;
 }
 

@@ -63,6 +63,13 @@ struct Attn8P {
   float scale;
   int n_rt;
   int tail_last;  // decode_block: partly filled last tiles after all full ones
+  // round 4: the forward output / the query gradient additionally (or, dQ: instead) as fp8, token-major [B*Lq, H*hd]
+  // bytes (the layout of the following linear layer's operand), scaled with the previous step's amax (saturating),
+  // current amax recorded, dequantisation factor written -- the separate quantisation pass over the bf16 tensor goes
+  unsigned char* oq; long oq_ld;    // forward: e4m3 copy of O (row stride oq_ld bytes); null = none
+  unsigned char* dqq; long dqq_ld;  // backward: e5m2 copy of dQ; null = none
+  const float* e_amax_prev; float* e_amax_cur; float* e_dq_out;
+  int wide_dkv;  // dK / dV rows 16-byte aligned: store_block_bf16_t's wide path
 };
 
 __device__ __forceinline__ int swz8(int row) { return ((row >> 1) & 3) | ((row >> 3) & 4); }
@@ -211,6 +218,52 @@ __device__ __forceinline__ void retire(float f) { asm volatile("" ::"v"(f)); }
 // as its e4m3 byte; when some byte of the wave would exceed 0x7E (wave-uniform, rare after the first tiles) the
 // running maxima m are raised to the tile's, O (whose row `hd` is the softmax denominator, from V's ones column) is
 // rescaled, and the tile's P is recomputed -- it has not entered O yet.
+// Store one 16-row block of a TRANSPOSED result tile (O^T, dQ^T: lane = (g, r) holds, for tile row r = lane & 15, the
+// columns 16 db + 4 g + 0..3 in v[db][0..3]) as a bf16 row (`row`, may be null) and / or as fp8 bytes (`row8`, may be
+// null; values = the bf16-rounded results * alpha, saturated).  The four g-lanes of a row first exchange their words
+// (row_transpose4) so that each lane owns 16 consecutive columns: 16-byte stores, a row's 64 / 128 bytes contiguous
+// per instruction, instead of 4- / 8-byte stores 16 / 32 bytes apart.  Returns max |bf16 value| of the valid rows.
+// All 64 lanes must call (cross-lane exchange); `valid` is uniform over the four lanes of a row.
+template <int HD, int EF, int NDB>
+__device__ __forceinline__ float store_block_t(const float (&v)[NDB][4], bf16_t* row, unsigned char* row8, bool emit8,
+                                               float alpha, int g, bool valid) {
+  static_assert(NDB == 5 && HD >= 64 && HD <= 80, "four full 16-column blocks and one partial");
+  constexpr float FMAX = EF == 0 ? 448.0f : 57344.0f;
+  unsigned lo[4], hi[4], q8[4] = {0u, 0u, 0u, 0u}, tlo, thi, t8 = 0u;
+  float emax = 0.f;
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) {
+    const unsigned a = pack_bf2(v[db][0], v[db][1]), b = pack_bf2(v[db][2], v[db][3]);
+    unsigned w8 = 0u;
+    if (emit8) {
+      float f[4] = {bflo(a), bfhi(a), bflo(b), bfhi(b)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (db < 4 || 4 * g + e < HD - 64) emax = fmaxf(emax, fabsf(f[e]));
+        f[e] = __builtin_amdgcn_fmed3f(f[e] * alpha, -FMAX, FMAX);
+      }
+      w8 = fp8_cvt4<EF>(f[0], f[1], f[2], f[3]);
+    }
+    if (db < 4) { lo[db] = a; hi[db] = b; q8[db] = w8; }
+    else { tlo = a; thi = b; t8 = w8; }
+  }
+  row_transpose4(lo);
+  row_transpose4(hi);
+  if (emit8) row_transpose4(q8);
+  if (!valid) return 0.f;
+  const bool tail = 4 * g < HD - 64;
+  if (row) {
+    *reinterpret_cast<u32x4*>(row + 16 * g) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+    *reinterpret_cast<u32x4*>(row + 16 * g + 8) = u32x4{lo[2], hi[2], lo[3], hi[3]};
+    if (tail) *reinterpret_cast<u32x2*>(row + 64 + 4 * g) = u32x2{tlo, thi};
+  }
+  if (emit8) {
+    *reinterpret_cast<u32x4*>(row8 + 16 * g) = u32x4{q8[0], q8[1], q8[2], q8[3]};
+    if (tail) *reinterpret_cast<unsigned*>(row8 + 64 + 4 * g) = t8;
+  }
+  return emax;
+}
+
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
   static_assert(HD == 72, "ones column of V at byte 72: row 72 of O^T = block 4, lanes g = 2, register 0");
@@ -403,24 +456,34 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
     kv_tile(j, std::integral_constant<int, 0>{}, std::true_type{});
   }
 
+  // fp8 emission (p.oq): the bf16-rounded outputs scaled by 448 / (previous amax), saturated, as e4m3 bytes of the
+  // token-major [B*Lq, H*hd] operand of the following projection; one filtered atomic max per wave records the amax
+  float e_alpha = 1.0f, e_max = 0.f;
+  if (p.oq) {
+    const float ap = *p.e_amax_prev;
+    e_alpha = ap > 0.f ? 448.0f / ap : 1.0f;
+    if (blockIdx.x == 0 && tid == 0) *p.e_dq_out = ap > 0.f ? ap / 448.0f : 1.0f;
+  }
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
     const int qrow = qrow0 + 16 * cb;
     // denominator: row HD of O^T (V's ones column) = block 4, lanes g = 2, register 0
     const float lt = __shfl(o[NDB - 1][cb][0], (lane & 15) | 32, 64);
-    if (qrow < p.Lq) {
-      const float inv = sv / lt;
-      bf16_t* orow = p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl;
+    const bool valid = qrow < p.Lq;
+    const float inv = sv / lt;
+    float vals[NDB][4];
 #pragma unroll
-      for (int db = 0; db < NDB; ++db) {
-        const int d = db * 16 + 4 * g;
-        if (d < HD) {
-          const u32x2 w = {pack_bf2(o[db][cb][0] * inv, o[db][cb][1] * inv), pack_bf2(o[db][cb][2] * inv, o[db][cb][3] * inv)};
-          *reinterpret_cast<u32x2*>(orow + d) = w;
-        }
-      }
-      if (g == 0) p.lse[head * p.Lq + qrow] = (m[cb] - P_SHIFT + __builtin_amdgcn_logf(lt)) * LN2;
-    }
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vals[db][e] = o[db][cb][e] * inv;
+    bf16_t* orow = p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl;
+    unsigned char* qrow8 = p.oq + ((long)b * p.Lq + qrow) * p.oq_ld + hh * HD;
+    e_max = fmaxf(e_max, store_block_t<HD, 0>(vals, orow, qrow8, p.oq != nullptr, e_alpha, g, valid));
+    if (valid && g == 0) p.lse[head * p.Lq + qrow] = (m[cb] - P_SHIFT + __builtin_amdgcn_logf(lt)) * LN2;
+  }
+  if (p.oq) {
+    e_max = wave_max(e_max);
+    if (lane == 0 && e_max > *p.e_amax_cur) atomicMax(reinterpret_cast<int*>(p.e_amax_cur), __float_as_int(e_max));
   }
 }
 
@@ -583,18 +646,13 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int krow = key0 + 16 * cb;
-    if (krow >= p.Lk) continue;
-    bf16_t* dkp = p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl;
-    bf16_t* dvp = p.dv + b * p.dv_sb + hh * p.dv_sh + (long)krow * p.dv_sl;
+    float vk[NDB][4], vv[NDB][4];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-      const int d = db * 16 + 4 * g;
-      if (d >= HD) continue;
-      const u32x2 wk = {pack_bf2(dk[db][cb][0] * fk, dk[db][cb][1] * fk), pack_bf2(dk[db][cb][2] * fk, dk[db][cb][3] * fk)};
-      const u32x2 wv = {pack_bf2(dv[db][cb][0] * fv, dv[db][cb][1] * fv), pack_bf2(dv[db][cb][2] * fv, dv[db][cb][3] * fv)};
-      *reinterpret_cast<u32x2*>(dkp + d) = wk;
-      *reinterpret_cast<u32x2*>(dvp + d) = wv;
-    }
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { vk[db][e] = dk[db][cb][e]; vv[db][e] = dv[db][cb][e]; }
+    store_block_bf16_t(vk, fk, p.dk + b * p.dk_sb + hh * p.dk_sh + (long)krow * p.dk_sl, HD, g, krow < p.Lk, p.wide_dkv);
+    store_block_bf16_t(vv, fv, p.dv + b * p.dv_sb + hh * p.dv_sh + (long)krow * p.dv_sl, HD, g, krow < p.Lk, p.wide_dkv);
   }
 }
 
@@ -758,18 +816,29 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
   else if (ncb == 1) run(std::integral_constant<int, 1>{});
   else run(std::integral_constant<int, 0>{});
   const float fq = p.scale * s_do * s_v * s_k;
+  // fp8 emission (p.dqq): dQ (rounded to bf16 first) as e5m2 bytes of the token-major [B*Lq, H*hd] operand of the
+  // q_cross weight- and input-gradient GEMMs; the bf16 store is skipped when the caller passes no dq
+  float e_alpha = 1.0f, e_max = 0.f;
+  if (p.dqq) {
+    const float ap = *p.e_amax_prev;
+    e_alpha = ap > 0.f ? 57344.0f / ap : 1.0f;
+    if (blockIdx.x == 0 && tid == 0) *p.e_dq_out = ap > 0.f ? ap / 57344.0f : 1.0f;
+  }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int qrow = qrow0 + 16 * cb;
-    if (qrow >= p.Lq) continue;
-    bf16_t* dqp = p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl;
+    float vals[NDB][4];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-      const int d = db * 16 + 4 * g;
-      if (d >= HD) continue;
-      const u32x2 w = {pack_bf2(dq[db][cb][0] * fq, dq[db][cb][1] * fq), pack_bf2(dq[db][cb][2] * fq, dq[db][cb][3] * fq)};
-      *reinterpret_cast<u32x2*>(dqp + d) = w;
-    }
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vals[db][e] = dq[db][cb][e] * fq;
+    bf16_t* dqp = p.dq ? p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl : nullptr;
+    unsigned char* q8p = p.dqq + ((long)b * p.Lq + qrow) * p.dqq_ld + hh * HD;
+    e_max = fmaxf(e_max, store_block_t<HD, 1>(vals, dqp, q8p, p.dqq != nullptr, e_alpha, g, qrow < p.Lq));
+  }
+  if (p.dqq) {
+    e_max = wave_max(e_max);
+    if (lane == 0 && e_max > *p.e_amax_cur) atomicMax(reinterpret_cast<int*>(p.e_amax_cur), __float_as_int(e_max));
   }
 }
 
@@ -1120,10 +1189,15 @@ void set_lds(K kern, int bytes) {
 bool args_ok(const vds_attn_fp8_args* a, bool bwd) {
   if (!a || !a->q || !a->k || !a->v || !a->deq || a->B <= 0 || a->H <= 0 || a->Lq <= 0 || a->Lk <= 0) return false;
   if ((long)a->Lq * ROWB > 0x7fffffffL || (long)a->Lk * ROWB > 0x7fffffffL) return false;
-  if (!bwd) return a->o && a->lse && (a->o_sb % 4 == 0) && (a->o_sh % 4 == 0) && (a->o_sl % 4 == 0);
-  return a->d_o && a->stats && a->dq && a->dk && a->dv && (a->dq_sl % 4 == 0) && (a->dk_sl % 4 == 0) &&
-         (a->dv_sl % 4 == 0) && (a->dq_sh % 4 == 0) && (a->dk_sh % 4 == 0) && (a->dv_sh % 4 == 0) &&
-         (a->dq_sb % 4 == 0) && (a->dk_sb % 4 == 0) && (a->dv_sb % 4 == 0);
+  if (!bwd) {
+    if (a->o_q && (!a->e_amax_prev || !a->e_amax_cur || !a->e_dq_out || (a->o_q_ld & 3))) return false;
+    return a->o && a->lse && (a->o_sb % 8 == 0) && (a->o_sh % 8 == 0) && (a->o_sl % 8 == 0) && ((uintptr_t)a->o % 16 == 0);
+  }
+  if (a->dq_q && (!a->e_amax_prev || !a->e_amax_cur || !a->e_dq_out || (a->dq_q_ld & 3))) return false;
+  // (dq: 16-byte stores -- strides in multiples of 8 elements, base 16-byte aligned)
+  if (a->dq && ((a->dq_sl % 8) || (a->dq_sh % 8) || (a->dq_sb % 8) || ((uintptr_t)a->dq % 16))) return false;
+  return a->d_o && a->stats && (a->dq || a->dq_q) && a->dk && a->dv && (a->dk_sl % 4 == 0) &&
+         (a->dv_sl % 4 == 0) && (a->dk_sh % 4 == 0) && (a->dv_sh % 4 == 0) && (a->dk_sb % 4 == 0) && (a->dv_sb % 4 == 0);
 }
 
 Attn8P to_p(const vds_attn_fp8_args* a) {
@@ -1141,6 +1215,13 @@ Attn8P to_p(const vds_attn_fp8_args* a) {
   p.scale = 1.0f / sqrtf((float)a->head_dim);
   p.n_rt = 0;
   p.tail_last = 0;
+  p.oq = (unsigned char*)a->o_q; p.oq_ld = a->o_q_ld;
+  p.dqq = (unsigned char*)a->dq_q; p.dqq_ld = a->dq_q_ld;
+  p.e_amax_prev = a->e_amax_prev; p.e_amax_cur = a->e_amax_cur; p.e_dq_out = a->e_dq_out;
+  auto rows16 = [](const void* base, long sb, long sh, long sl) {
+    return base && ((uintptr_t)base % 16 == 0) && (sb % 8 == 0) && (sh % 8 == 0) && (sl % 8 == 0);
+  };
+  p.wide_dkv = rows16(p.dk, p.dk_sb, p.dk_sh, p.dk_sl) && rows16(p.dv, p.dv_sb, p.dv_sh, p.dv_sl);
   return p;
 }
 
@@ -1155,6 +1236,7 @@ extern "C" int vds_attn_fp8_fwd(const vds_attn_fp8_args* a, vds_stream_t stream)
   static bool once = false;
   if (!once) { set_lds(attn8_fwd_kernel<72>, LDS); once = true; }
   Attn8P p = to_p(a);
+  p.dqq = nullptr;
   p.n_rt = cdiv(p.Lq, 256);
   p.tail_last = tail_last_for(p.Lq, 256);
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
@@ -1200,6 +1282,7 @@ extern "C" int vds_attn_fp8_bwd(const vds_attn_fp8_args* a, vds_stream_t stream)
     once = true;
   }
   Attn8P p = to_p(a);
+  p.oq = nullptr;
   hipStream_t s = (hipStream_t)stream;
   const double prod = 2.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;  // credit as in attention.hip: 2 + 2 products
   const double bytes = (double)p.B * p.H * ROWB * (2.0 * p.Lq + 2.0 * p.Lk);

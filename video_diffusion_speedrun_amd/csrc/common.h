@@ -85,6 +85,57 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return __builtin_fmaf(x * 0.39894228040143268f, e, cdf);
 }
 
+// ---- 4x4 transpose of one dword per lane between the four 16-lane rows of a wave (gfx950 v_permlane{32,16}_swap):
+// in: row g of the wave holds w[j]; out: row g holds in w[j] what row j held in w[g] (the lane within the row is kept).
+// Turns the "4 consecutive columns per lane, 4 lanes per matrix row" layout of a transposed MFMA result into 16
+// consecutive columns per lane, i.e. 16-byte stores that cover a matrix row contiguously.
+__device__ __forceinline__ void row_transpose4(unsigned (&w)[4]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {  // rows {2,3} of w[j] <-> rows {0,1} of w[j+2]
+    const auto r = __builtin_amdgcn_permlane32_swap(w[j], w[j + 2], false, false);
+    w[j] = r[0];
+    w[j + 2] = r[1];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j += 2) {  // odd rows of w[j] <-> even rows of w[j+1]
+    const auto r = __builtin_amdgcn_permlane16_swap(w[j], w[j + 1], false, false);
+    w[j] = r[0];
+    w[j + 1] = r[1];
+  }
+}
+
+// bf16 store of one 16-row block of a TRANSPOSED MFMA result (O^T, dQ^T, dK^T, dV^T of the attention kernels): lane
+// (g = lane >> 4, r = lane & 15) holds columns 16 db + 4 g + 0..3 of row r in v[db][0..3]; `row` = that row's address,
+// hd (64 < hd <= 80) columns exist.  wide (wave-uniform; needs 16-byte aligned rows): the four g-lanes of a row
+// exchange words so that each owns 16 consecutive columns and stores 2 x 16 bytes (a row's first 128 bytes
+// contiguous per instruction pair) instead of 8-byte stores 32 bytes apart -- the store tail of these kernels is
+// VMEM-issue-bound.  All 64 lanes must call; `valid` is uniform over the four lanes of a row.
+template <int NDB>
+__device__ __forceinline__ void store_block_bf16_t(const float (&v)[NDB][4], float mul, bf16_t* row, int hd, int g,
+                                                   bool valid, bool wide) {
+  static_assert(NDB == 5, "four full 16-column blocks and one partial");
+  unsigned lo[NDB], hi[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) {
+    lo[db] = pack_bf2(v[db][0] * mul, v[db][1] * mul);
+    hi[db] = pack_bf2(v[db][2] * mul, v[db][3] * mul);
+  }
+  if (wide) {
+    unsigned a[4] = {lo[0], lo[1], lo[2], lo[3]}, b[4] = {hi[0], hi[1], hi[2], hi[3]};
+    row_transpose4(a);
+    row_transpose4(b);
+    if (!valid) return;
+    *reinterpret_cast<u32x4*>(row + 16 * g) = u32x4{a[0], b[0], a[1], b[1]};
+    *reinterpret_cast<u32x4*>(row + 16 * g + 8) = u32x4{a[2], b[2], a[3], b[3]};
+    if (64 + 4 * g < hd) *reinterpret_cast<u32x2*>(row + 64 + 4 * g) = u32x2{lo[4], hi[4]};
+    return;
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+    if (db * 16 + 4 * g < hd) *reinterpret_cast<u32x2*>(row + db * 16 + 4 * g) = u32x2{lo[db], hi[db]};
+}
+
 // ---- OCP fp8 (e4m3fn = format 0, e5m2 = format 1): saturating casts of 4 / 8 scaled values -----------------
 __device__ __forceinline__ float fp8_fmax(int fmt) { return fmt == 0 ? 448.0f : 57344.0f; }
 template <int FMT>

@@ -37,6 +37,7 @@ from .params import FlatGroup
 
 _NO_EMIT = os.environ.get("VDS_FP8_NO_EMIT") == "1"  # experiments: quantise every fp8 operand in a separate pass
 _NO_PRODUCER_EMIT = os.environ.get("VDS_FP8_PRODUCER_EMIT") == "0"  # experiments: only the GEMM epilogues emit fp8
+_NO_ATTN_EMIT = os.environ.get("VDS_FP8_ATTN_EMIT") == "0"  # experiments: attention results quantised in a separate pass
 
 bf16, f32 = torch.bfloat16, torch.float32
 N_REG = 16  # register tokens (model.py:316,362,386)
@@ -357,7 +358,7 @@ class DiTBlock(nn.Module):
         # the previous step's amax; until a complete step has been recorded the bf16 kernels run and the amax is taken
         a8_on = use_fp8 and fp8_attn and ops.attn_fp8_supported(hd)
         a8 = a8_on and fp8_hist.ready
-        q = k = q8 = k8 = v8 = deq = None
+        q = k = q8 = k8 = v8 = deq = e_attn = None
         if a8:
             r0 = F8.ROWS * i + F8.ROW_Q
             deq = torch.empty(8, dtype=f32, device=dev)  # {s_q, s_k, s_v, s_do, E}: include/vds.h, vds_attn_fp8_args
@@ -365,7 +366,10 @@ class DiTBlock(nn.Module):
             q8, k8, v8, v = ops.qkv_rope_fwd_fp8(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None,
                                                  B, L, H, hd, hdp, fp8_hist.tab[r0:r0 + 3, 0], cur, 2, deq,
                                                  want_v=self.residual_v and v0 is None)
-            ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(attn, B, L, H, hd), lse1, hd)
+            # (the attn_proj operand leaves the attention epilogue as e4m3: no quantisation pass over `attn`)
+            e_attn = ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(attn, B, L, H, hd), lse1, hd,
+                                      emit=(hist.prev(R0 + F8.ROW_ATTN), hist.cur(R0 + F8.ROW_ATTN))
+                                      if (pemit and fp8_lin and not _NO_ATTN_EMIT) else None)
         else:
             q, k, v = ops.qkv_rope_fwd(qkv, cos, sin, v0 if mix else None, W("lambda_param") if mix else None, B, L, H,
                                        hd, hdp)
@@ -377,7 +381,8 @@ class DiTBlock(nn.Module):
         f8l = f8 and fp8_lin  # the 1152^2-class linears in fp8 too
         q_attn = q_wap = q_xn2 = q_wqc = q_wkv = q_catt = q_wcp = None
         if f8l:
-            q_attn = F8.Q(attn, F8.E4M3, True, save, hist, R0 + F8.ROW_ATTN)
+            q_attn = (F8.Q.from_rowmajor(*e_attn, save) if e_attn is not None else
+                      F8.Q(attn, F8.E4M3, True, save, hist, R0 + F8.ROW_ATTN))
             q_wap = F8.Q(W("attn_proj.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 1, weight=True)
             y_sa, X1 = F8.fwd_gate_res(q_attn, q_wap, None, mod, 2 * D, X, L)
         else:
@@ -409,7 +414,7 @@ class DiTBlock(nn.Module):
             lse2 = torch.empty(B, H, L, dtype=f32, device=dev)
             # fp8 cross-attention: the same kernels as the self-attention (Lk = context length), operands quantised by
             # vds_cross_qkv_fp8 with the previous step's amax; the bf16 kernels record the amax until a step is complete
-            qc8 = kc8 = vc8 = deqc = None
+            qc8 = kc8 = vc8 = deqc = e_catt = None
             c8_on = a8_on and fp8_attn >= 2 and Lc >= 4  # (vds_cross_qkv_fp8 works on tiles of 4 tokens)
             c8 = c8_on and fp8_hist.ready
             if c8:
@@ -417,7 +422,9 @@ class DiTBlock(nn.Module):
                 deqc = torch.empty(8, dtype=f32, device=dev)
                 cur = fp8_hist.tab[rc:rc + 3, 1] if save else fp8_hist.scratch(5)[0::2]
                 qc8, kc8, vc8 = ops.cross_qkv_fp8(qc, ckv, B, L, Lc, H, hd, fp8_hist.tab[rc:rc + 3, 0], cur, 2, deqc)
-                ops.attn_fp8_fwd(qc8, kc8, vc8, deqc, ops.heads_view(catt, B, L, H, hd), lse2, hd)
+                e_catt = ops.attn_fp8_fwd(qc8, kc8, vc8, deqc, ops.heads_view(catt, B, L, H, hd), lse2, hd,
+                                          emit=(hist.prev(R0 + F8.ROW_CATT), hist.cur(R0 + F8.ROW_CATT))
+                                          if (pemit and f8c and not _NO_ATTN_EMIT) else None)
             else:
                 ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), ops.heads_view(ckv, B, Lc, H, hd, 0),
                              ops.heads_view(ckv, B, Lc, H, hd, D), ops.heads_view(catt, B, L, H, hd), lse2)
@@ -425,7 +432,8 @@ class DiTBlock(nn.Module):
                     for j, t in enumerate((qc, ckv[:, :D], ckv[:, D:])):
                         ops.absmax(t, fp8_hist.cur(R0 + F8.ROW_QC + j))
             if f8c:
-                q_catt = F8.Q(catt, F8.E4M3, True, save, hist, R0 + F8.ROW_CATT)
+                q_catt = (F8.Q.from_rowmajor(*e_catt, save) if e_catt is not None else
+                          F8.Q(catt, F8.E4M3, True, save, hist, R0 + F8.ROW_CATT))
                 q_wcp = F8.Q(W("cross_proj.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 4, weight=True)
                 y_ca, X2 = F8.fwd_gate_res(q_catt, q_wcp, None, mod, 5 * D, X1, L)
             else:
@@ -555,16 +563,23 @@ class DiTBlock(nn.Module):
                 dy = ops.gate_bwd(dX2, bs.y_ca, mod, 5 * D, dmod, None, B, L)
                 ops.linear_wgrad(dy, bs.catt, Gr("cross_proj.weight"))
                 dcatt = ops.linear_dgrad(dy, W("cross_proj.weight"))
-            dqc = torch.empty(B * L, D, dtype=bf16, device=dev)
+            # fp8 cross-attention + fp8 q_cross: dQ leaves the attention kernel as e5m2 (and as bf16 only for a bias gradient)
+            emit_dqc = bs.c8 and bs.f8c and pemit and not _NO_ATTN_EMIT
+            need_dqc = not emit_dqc or G.has(pre + "q_cross.bias")
+            dqc = torch.empty(B * L, D, dtype=bf16, device=dev) if need_dqc else None
             dckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
+            e_dqc = None
             if bs.c8:
                 rd = R0 + F8.ROW_DOC
                 if getattr(sv, "doq", None) is None:  # one e5m2 dO buffer per backward pass; its pad bytes stay zero
                     sv.doq = torch.zeros(B, H, L, ops.FP8_ROW, dtype=torch.float8_e5m2, device=dev)
                 stats = ops.attn_fp8_delta(bs.catt, dcatt, bs.lse2, sv.doq, fp8_hist.prev(rd), fp8_hist.cur(rd), bs.deqc,
                                            B, H, L, hd)
-                ops.attn_fp8_bwd(bs.qc8, bs.kc8, bs.vc8, sv.doq, stats, bs.deqc, ops.heads_view(dqc, B, L, H, hd),
-                                 ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), hd)
+                e_dqc = ops.attn_fp8_bwd(bs.qc8, bs.kc8, bs.vc8, sv.doq, stats, bs.deqc,
+                                         ops.heads_view(dqc, B, L, H, hd) if need_dqc else None,
+                                         ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), hd,
+                                         emit_dq=(hist.prev(R0 + F8.ROW_DQC), hist.cur(R0 + F8.ROW_DQC))
+                                         if emit_dqc else None)
             else:
                 # (workspace sized by the library: statistics + the fp32 partials of its query-split dK/dV launch)
                 ops.attn_bwd(ops.heads_view(bs.qc, B, L, H, hd), ops.heads_view(bs.ckv, B, Lc, H, hd, 0),
@@ -580,7 +595,8 @@ class DiTBlock(nn.Module):
             if bs.f8c:
                 q_dckv = F8.Q(dckv, F8.E5M2, F8.TN, not F8.TN, hist, R0 + F8.ROW_DCKV)  # (a weight-gradient operand only)
                 F8.wgrad(q_dckv, q_ctx, Gr("context_kv.weight"))
-                q_dqc = F8.Q(dqc, F8.E5M2, True, True, hist, R0 + F8.ROW_DQC)
+                q_dqc = (F8.Q.from_rowmajor(*e_dqc, True) if e_dqc is not None else
+                         F8.Q(dqc, F8.E5M2, True, True, hist, R0 + F8.ROW_DQC))
                 F8.wgrad(q_dqc, bs.q_xn2, Gr("q_cross.weight"))
                 dxn = F8.dgrad(q_dqc, bs.q_wqc)
                 del q_dckv, q_dqc

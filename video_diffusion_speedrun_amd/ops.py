@@ -291,12 +291,22 @@ def _attn8_args(q8, k8, v8, deq, hd):
     return a
 
 
-def attn_fp8_fwd(q8, k8, v8, deq, o, lse, hd):
-    """fp8 self-attention forward: q8/k8/v8 from qkv_rope_fwd_fp8, o [B,H,Lq,hd] bf16 strided view, lse f32 [B,H,Lq]"""
+def attn_fp8_fwd(q8, k8, v8, deq, o, lse, hd, emit=None):
+    """fp8 self-attention forward: q8/k8/v8 from qkv_rope_fwd_fp8, o [B,H,Lq,hd] bf16 strided view, lse f32 [B,H,Lq].
+    emit = (amax_prev f32[1], amax_cur f32[1]): also returns (o as e4m3 [B*Lq, H*hd], dequantisation factor f32[1]),
+    written by the kernel's epilogue with the previous step's amax (the attn_proj / cross_proj operand)."""
     a = _attn8_args(q8, k8, v8, deq, hd)
     a.o, (a.o_sb, a.o_sh, a.o_sl) = _p(o), _st(o)
     a.lse = _p(lse)
+    out = None
+    if emit is not None:
+        oq = torch.empty(a.B * a.Lq, a.H * hd, dtype=fp8_dtypes[0], device=q8.device)
+        sc = torch.empty(1, dtype=f32, device=q8.device)
+        a.o_q, a.o_q_ld = _p(oq), oq.stride(0)
+        a.e_amax_prev, a.e_amax_cur, a.e_dq_out = _p(emit[0]), _p(emit[1]), _p(sc)
+        out = (oq, sc)
     check(_lib.load().vds_attn_fp8_fwd(C.byref(a), _stream()), f"vds_attn_fp8_fwd(B={a.B},H={a.H},Lq={a.Lq},Lk={a.Lk})")
+    return out
 
 
 def attn_fp8_delta(o2d, do2d, lse, doq, amax_prev, amax_cur, deq, B, H, L, hd):
@@ -310,13 +320,24 @@ def attn_fp8_delta(o2d, do2d, lse, doq, amax_prev, amax_cur, deq, B, H, L, hd):
     return stats
 
 
-def attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dq, dk, dv, hd):
+def attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dq, dk, dv, hd, emit_dq=None):
+    """dq / dk / dv: bf16 strided [B,H,L,hd] views.  emit_dq = (amax_prev, amax_cur): dQ additionally -- or, with
+    dq=None, only -- as e5m2 [B*Lq, H*hd] from the kernel's epilogue; returns (dq_q, dequantisation factor)."""
     a = _attn8_args(q8, k8, v8, deq, hd)
     a.d_o, a.stats = _p(doq), _p(stats)
-    a.dq, (a.dq_sb, a.dq_sh, a.dq_sl) = _p(dq), _st(dq)
+    out = None
+    if emit_dq is not None:
+        dqq = torch.empty(a.B * a.Lq, a.H * hd, dtype=fp8_dtypes[1], device=q8.device)
+        sc = torch.empty(1, dtype=f32, device=q8.device)
+        a.dq_q, a.dq_q_ld = _p(dqq), dqq.stride(0)
+        a.e_amax_prev, a.e_amax_cur, a.e_dq_out = _p(emit_dq[0]), _p(emit_dq[1]), _p(sc)
+        out = (dqq, sc)
+    if dq is not None:
+        a.dq, (a.dq_sb, a.dq_sh, a.dq_sl) = _p(dq), _st(dq)
     a.dk, (a.dk_sb, a.dk_sh, a.dk_sl) = _p(dk), _st(dk)
     a.dv, (a.dv_sb, a.dv_sh, a.dv_sl) = _p(dv), _st(dv)
     check(_lib.load().vds_attn_fp8_bwd(C.byref(a), _stream()), f"vds_attn_fp8_bwd(B={a.B},H={a.H},Lq={a.Lq},Lk={a.Lk})")
+    return out
 
 
 def attn_fp8_qk_factors(amax_q: float, amax_k: float, hd: int):
