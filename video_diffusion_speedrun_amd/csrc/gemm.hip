@@ -796,7 +796,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     kt_end = min(kt_total, kt_begin + per);
     if (kt_begin >= kt_end) return;
   }
-
   const srd_t ra = make_srd(p.A, p.a_bytes);
   const srd_t rb = make_srd(p.B, p.b_bytes);
   constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
@@ -1074,11 +1073,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
   }
   }
+  // ---- epilogue: two 64-row quadrant rows per wave through the wave's private staging area ----
+  // The aux tiles (residual / pre-activation) of BOTH quadrant rows are requested here, before the drain of the
+  // operand pipeline: one exposed HBM round trip per output tile instead of one per quadrant row (with one workgroup
+  // per CU nothing else hides it).  The drain waits for everything but these 16 loads (loads return in order).
+  u32x4 auxr2[2][8];
+#pragma unroll
+  for (int qa = 0; qa < 2; ++qa)
+    epilogue_prefetch<EPI, G::WCOLS>(p, m0 + wr * 128 + qa * 64, n0 + wc * G::WCOLS, lane, auxr2[qa]);
   if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
-  VDS_WAIT_VM(0);                              // the zero-fill tail DMAs target LDS the epilogue reuses
+  // the zero-fill tail DMAs target LDS the epilogue reuses
+  // (a wave whose sub-tile sticks out of the matrix may have issued fewer than 16: it drains everything)
+  const bool aux_all = (EPI == VDS_EPI_GATE_RES || EPI == VDS_EPI_DGELU) && m0 + wr * 128 + 128 <= p.M &&
+                       n0 + (wc + 1) * G::WCOLS <= p.N;
+  if (aux_all) VDS_WAIT_VM(16);
+  else VDS_WAIT_VM(0);
   __builtin_amdgcn_s_barrier();
 
-  // ---- epilogue: two 64-row quadrant rows per wave through the wave's private staging area ----
   float* stg = reinterpret_cast<float*>(ring) + wave * 64 * EPI_LD;
   float dq = 1.0f;
   if constexpr (FMT != 0) dq = (p.sa ? *p.sa : 1.0f) * (p.sb ? *p.sb : 1.0f);
@@ -1099,9 +1110,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   const char* lut = smem;
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa) {
-    u32x4 auxr[8];
+    const u32x4 (&auxr)[8] = auxr2[qa];
     const int row0 = m0 + wr * 128 + qa * 64, col0 = n0 + wc * WCOLS;
-    epilogue_prefetch<EPI, WCOLS>(p, row0, col0, lane, auxr);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
