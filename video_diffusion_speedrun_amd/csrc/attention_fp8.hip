@@ -49,6 +49,22 @@ constexpr float P_SHIFT = 8.0f;      // P is held as P * 2^8
 constexpr float LOGDOM_BIAS = 56.0f - 0.344f;  // forward: e4m3 byte of 2^x = round(8 x + LOGDOM_BIAS) (attn8_fwd_kernel, P_BYTE)
 constexpr float BYTE_LIMIT = 126.4f;  // forward: raise the running maximum when a byte would exceed 0x7E (448; 0x7F is NaN)
 constexpr float SEED_HEADROOM = 2.0f; // forward: the first block's maximum + 2 seeds the running maximum (round 4: was 4)
+// Backward (round 4): P = 2^x without v_exp_f32 (a quarter-rate instruction; the fp8 backward kernels are bound by the
+// VALU work between their MFMAs, profiles/r04_attn_fp8_b6_sq_counters.txt).  The S-type MFMA delivers
+// t = (x + 127 - PEXP_C) * 2^23 directly -- its block scale carries the 2^23, the per-query start value of the
+// accumulator the (127 - PEXP_C + 8 - lse2) * 2^23 -- and ONE v_cvt_u32_f32 turns t into the bit pattern of the float
+// 2^floor(x) * (1 + frac x): 2^x interpolated linearly between powers of two (Schraudolph).  (1 + f) / 2^f lies in
+// [1, 1.0615]; PEXP_C = 0.043 centres it: P is within a factor 2^(+-0.043) (+- 3 %) of the exact value, the same
+// approximation the forward kernel's log-domain byte makes, and small beside the e4m3 (P) / e5m2 (dS) roundings that
+// follow (relative steps 2^-3 / 2^-2).  t < 0 (x < -127) converts to 0; the accumulator's resolution at |t| ~ 2^30 is
+// 2^7, i.e. 2^-16 in x.  Building with -DVDS_ATTN8_EXACT_EXP=1 keeps v_exp_f32 (A/B builds; a run-time switch inside the
+// loops costs registers: 412 bytes of scratch per lane in the dK/dV kernel).
+#ifndef VDS_ATTN8_EXACT_EXP
+#define VDS_ATTN8_EXACT_EXP 0
+#endif
+constexpr bool EXACT_EXP = VDS_ATTN8_EXACT_EXP != 0;
+constexpr float PEXP_C = 0.043f;
+constexpr float PEXP_ONE = 8388608.0f;  // 2^23
 
 struct Attn8P {
   int B, H, Lq, Lk, hd;
@@ -58,7 +74,7 @@ struct Attn8P {
   bf16_t* dq; long dq_sb, dq_sh, dq_sl;
   bf16_t* dk; long dk_sb, dk_sh, dk_sl;
   bf16_t* dv; long dv_sb, dv_sh, dv_sl;
-  const float* stats;                    // backward: [2][B,H,Lq]: -delta / (256 s_do s_v), then 8 - lse log2(e)
+  const float* stats;                    // backward: [2][B,H,Lq]: -delta / (256 s_do s_v), then 8 - lse log2(e) as (. + 127 - PEXP_C) 2^23
   const float* deq;                      // {s_q, s_k, s_v, s_do, E}: x = x_q * s; s_q s_k log2(e) / sqrt(hd) = 2^-E
   float scale;
   int n_rt;
@@ -73,6 +89,11 @@ struct Attn8P {
 };
 
 __device__ __forceinline__ int swz8(int row) { return ((row >> 1) & 3) | ((row >> 3) & 4); }
+// t = (x + 127 - PEXP_C) * 2^23 -> the float 2^x (piecewise linear, see PEXP_C).  A plain conversion (one
+// v_cvt_u32_f32, which saturates: t < 0, i.e. x < -127, gives 0.0f), NOT inline asm: t is an MFMA result, and the
+// compiler only inserts the wait states between an MFMA and a VALU read of its result for instructions it can see
+// (an asm statement here returned garbage at random).
+__device__ __forceinline__ float pexp_bits(float t) { return __builtin_bit_cast(float, (unsigned)t); }
 
 // Per-lane LDS byte offsets of the fragment reads, relative to a tile's base: computed once per kernel so that every
 // read in the tile loops is `base VGPR + immediate` (tile / buffer / block offsets are compile-time constants).
@@ -534,7 +555,8 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
     vf[cb] = load_row32(rv, key0 + 16 * cb, g);
   }
   const float s_q = p.deq[0], s_v = p.deq[2], s_do = p.deq[3];
-  const int sc_s = __builtin_amdgcn_readfirstlane(127 - (int)p.deq[4]);  // S products: log2-domain exponents
+  // S products: log2-domain exponents (x 2^23: the bit pattern of 2^x, see PEXP_C)
+  const int sc_s = __builtin_amdgcn_readfirstlane(127 - (int)p.deq[4] + (EXACT_EXP ? 0 : 23));
   constexpr int SC_DP = 127 - 8;                                          // dP products: x 2^-8
   Frag8 fr;
   fr.init(lane);
@@ -601,12 +623,10 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
       }
 #pragma unroll
       for (int cb = 0; cb < NKB; ++cb) {
-        f32x4 pr, ds;
+        f32x4 pr;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pr[r] = __builtin_amdgcn_exp2f(s[cb][r]);  // 256 P
-          ds[r] = pr[r] * dp[cb][r];                 // P (dP - delta) / (s_do s_v): |.| <= 4032 (file header)
-        }
+        for (int r = 0; r < 4; ++r) pr[r] = EXACT_EXP ? __builtin_amdgcn_exp2f(s[cb][r]) : pexp_bits(s[cb][r]);  // 256 P
+        const f32x4 ds = pr * dp[cb];  // P (dP - delta) / (s_do s_v): |.| <= 4032 (file header); two v_pk_mul_f32
         pq[cb][i] = cvt4_e4m3(pr);
         dsq[cb][i] = cvt4_e5m2(ds);
       }
@@ -706,7 +726,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
     nl4[cb] = f32x4{nl, nl, nl, nl};
   }
   const float s_k = p.deq[1], s_v = p.deq[2], s_do = p.deq[3];
-  const int sc_s = __builtin_amdgcn_readfirstlane(127 - (int)p.deq[4]);
+  const int sc_s = __builtin_amdgcn_readfirstlane(127 - (int)p.deq[4] + (EXACT_EXP ? 0 : 23));
   constexpr int SC_DP = 127 - 8;
   Frag8 fr;
   fr.init(lane);
@@ -771,7 +791,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
         f32x4 ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          ds[r] = __builtin_amdgcn_exp2f(s[cb][r]) * dp[cb][r];  // P (dP - delta) / (s_do s_v)
+          ds[r] = (EXACT_EXP ? __builtin_amdgcn_exp2f(s[cb][r]) : pexp_bits(s[cb][r])) * dp[cb][r];  // P (dP - delta) / (s_do s_v)
           if constexpr (ragged) {
             if (4 * i + r >= key_lim) ds[r] = 0.f;  // accumulator register r of block i = tile row 32 g + 4 i + r
           }
@@ -844,7 +864,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
 
 // ===================================== preprocess ===========================================
 // delta preprocess of the fp8 backward: one wave per token of the token-major O / dO ([B*Lq, H*hd] bf16, what the
-// model passes).  Per head:  stats[0][b,h,q] = -rowsum(dO o O) / (256 s_do s_v),  stats[1][b,h,q] = 8 - lse log2(e);
+// model passes).  Per head:  stats[0][b,h,q] = -rowsum(dO o O) / (256 s_do s_v),  stats[1][b,h,q] = (8 - lse log2(e) + 127 - 0.043) 2^23 (the exponent's start value: PEXP_C);
 // dO leaves as e5m2 rows [B,H,Lq,128] (bytes [hd,128) are never written: the buffer is zeroed once by its owner),
 // scaled so that the previous step's amax lands on DO_TARGET; the current amax is recorded (delayed scaling).
 constexpr float DO_TARGET = 0.0625f;  // dO_q in [2^-16, 2^-4]: dS_q = 256 P dP' then stays below the e5m2 maximum
@@ -908,7 +928,8 @@ __global__ __launch_bounds__(256) void attn8_delta_kernel(const bf16_t* o, long 
     const long rows = (long)B * H * Lq;
     const long row = ((long)b * H + lane) * Lq + q;
     stats[row] = -acc / (s_do * deq[2] * 256.0f);
-    stats[rows + row] = P_SHIFT - lse[row] * LOG2E;
+    const float nl = P_SHIFT - lse[row] * LOG2E;  // the exponent's per-query addend: 8 - lse2 ...
+    stats[rows + row] = EXACT_EXP ? nl : (nl + (127.0f - PEXP_C)) * PEXP_ONE;  // ... in the form the S-type MFMA starts from
   }
   amax = wave_max(amax);
   if (lane == 0 && amax > *amax_cur) atomicMax(reinterpret_cast<int*>(amax_cur), __float_as_int(amax));
