@@ -247,6 +247,37 @@ def test_attn_fp8_epilogues_emit_the_quantised_copies_of_their_results(ops, L, L
         assert torch.equal(dkv[0], dkv[2]) and torch.equal(dkv[1], dkv[3])
 
 
+def test_attn_fp8_row_alignment_contract(ops):
+    """round 4: O and dQ are written with 16-byte stores (rows must be 16-byte aligned: VDS_ERR_ARG otherwise); dK / dV
+    keep an 8-byte path for rows that are not, which must write the same bits as the 16-byte path"""
+    dev = torch.device("cuda")
+    B, H, L = 1, 2, 300
+    (q8, k8, v8), deq, _ = make_qkv(B, H, L, 31, dev)
+    o = torch.empty(B * L, H * HD, dtype=bf16, device=dev)
+    lse = torch.empty(B, H, L, dtype=f32, device=dev)
+    ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(o, B, L, H, HD), lse, HD)
+    obad = torch.empty(B * L, H * HD + 8, dtype=bf16, device=dev)[:, 4:4 + H * HD]  # rows 8 bytes off a 16-byte boundary
+    with pytest.raises(RuntimeError):
+        ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(obad, B, L, H, HD), lse, HD)
+    do = (torch.randn(B * L, H * HD, generator=torch.Generator().manual_seed(3)) * 0.02).to(bf16).to(dev)
+    doq = torch.zeros(B, H, L, ROW, dtype=E5, device=dev)
+    stats = ops.attn_fp8_delta(o, do, lse, doq, do.float().abs().max().reshape(1), torch.zeros(1, dtype=f32, device=dev),
+                               deq, B, H, L, HD)
+    out = {}
+    for name, off, wid in (("wide", 0, HDP), ("narrow", 4, 100)):
+        dq = torch.empty(B, H, L, HDP, dtype=bf16, device=dev)
+        kv = [torch.full((B, H, L, wid), 3.0, dtype=bf16, device=dev) for _ in range(2)]
+        ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dq[..., :HD], kv[0][..., off:off + HD], kv[1][..., off:off + HD], HD)
+        torch.cuda.synchronize()
+        out[name] = [t[..., off:off + HD].clone() for t in kv]
+        if off:
+            assert all(bool((t[..., :off] == 3.0).all()) and bool((t[..., off + HD:] == 3.0).all()) for t in kv)
+    assert torch.equal(out["wide"][0], out["narrow"][0]) and torch.equal(out["wide"][1], out["narrow"][1])
+    with pytest.raises(RuntimeError):
+        dqbad = torch.empty(B, H, L, 100, dtype=bf16, device=dev)[..., 4:4 + HD]
+        ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dqbad, kv[0][..., :HD], kv[1][..., :HD], HD)
+
+
 @pytest.mark.parametrize("L,Lk", [(300, 300), (700, 300), (8208, 8208)],
                          ids=["ragged300", "cross_Lq700_Lk300", "headline_8208"])
 def test_attn_fp8_backward_is_finite_when_every_score_is_very_negative(ops, parity_log, L, Lk):

@@ -671,6 +671,56 @@ def test_attention_ones_columns_mfma_shape_variants(ops, variant, Lq, Lk):
     assert dq[..., hd + 2:].abs().max().item() == 0 and dk[..., hd:].abs().max().item() == 0
 
 
+def test_attention_16x16_epilogues_wide_and_narrow_row_stores_agree(ops):
+    """round 4: the 16x16x32 kernels store O / dQ / dK / dV rows with 16-byte stores after a lane-row transpose when the
+    rows are 16-byte aligned, and keep the 8-byte stores otherwise (the C ABI only asks for 8-byte alignment).  Both
+    paths must write the same bits, and nothing outside the head's columns."""
+    B, H, hd, hdp, Lq, Lk = 2, 2, 72, 96, 700, 515
+    q, k, v = gen(B, H, Lq, hd, seed=71), gen(B, H, Lk, hd, seed=72), gen(B, H, Lk, hd, seed=73)
+    do = gen(B, Lq, H * hd, seed=74).reshape(B * Lq, H * hd).cuda()
+
+    def padk(t, cols):
+        out = torch.zeros(*t.shape[:-1], hdp, dtype=bf16)
+        out[..., :hd] = t
+        for c in cols:
+            out[..., c] = 1
+        return out.cuda()
+    kd, vd = padk(k, [hd, hd + 1]), padk(v, [hd, hd + 4])
+    res = {}
+    prev = ops.attn_set_variant(7)
+    try:
+        for name, off, wid in (("wide", 0, hdp), ("narrow", 4, 100)):
+            qd = padk(q, [])  # (the backward annotates q's pad columns: a fresh copy per run)
+            obuf = torch.full((B * Lq, H * hd + 2 * off), 3.0, dtype=bf16, device="cuda")
+            ov = ops.heads_view(obuf[:, off:off + H * hd], B, Lq, H, hd)
+            lse = torch.zeros(B, H, Lq, dtype=f32, device="cuda")
+            bufs = [torch.full((B, H, L, wid), 3.0, dtype=bf16, device="cuda") for L in (Lq, Lk, Lk)]
+            dq, dk, dv = (t[..., off:off + hd] for t in bufs)
+            assert (ov.data_ptr() % 16 == 0) == (name == "wide") and (dq.data_ptr() % 16 == 0) == (name == "wide")
+            ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ov, lse, kv_pad_ones=True)
+            # (the backward reads O from the aligned copy in both runs: the delta preprocess picks its access width --
+            # and with it its summation order -- by O's strides, which is not what this test is about)
+            o_al = obuf[:, off:off + H * hd].contiguous()
+            ops.attn_bwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o_al, B, Lq, H, hd), lse,
+                         ops.heads_view(do, B, Lq, H, hd), dq, dk, dv, None, kv_pad_ones=True)
+            torch.cuda.synchronize()
+            res[name] = (o_al, dq.clone(), dk.clone(), dv.clone())
+            if off:  # the columns around the head's 72 stay untouched
+                assert bool((obuf[:, :off] == 3.0).all()) and bool((obuf[:, off + H * hd:] == 3.0).all())
+                for t in bufs:
+                    assert bool((t[..., :off] == 3.0).all()) and bool((t[..., off + hd:] == 3.0).all())
+    finally:
+        ops.attn_set_variant(prev)
+    for a, b, n in zip(res["wide"], res["narrow"], ("o", "dq", "dk", "dv")):
+        bad = (a != b)
+        assert torch.equal(a, b), (n, int(bad.sum()), bad.nonzero()[:6].tolist())
+    o_ref, _, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, do.cpu().reshape(B, Lq, H, hd).permute(0, 2, 1, 3))
+    close("w.o", res["wide"][0].view(B, Lq, H, hd).permute(0, 2, 1, 3), o_ref, 1e-2)
+    close("w.dq", res["wide"][1], dq_ref, 1e-2)
+    close("w.dk", res["wide"][2], dk_ref, 1e-2)
+    close("w.dv", res["wide"][3], dv_ref, 1e-2)
+
+
 def test_small_linear_batched_equals_per_set(ops):
     """the adaLN linears of all blocks in one launch (vds_small_linear_*_batched, device pointer tables) give the same
     outputs, weight / bias gradients and accumulated input gradient as one launch per block"""
