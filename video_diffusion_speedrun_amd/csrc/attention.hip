@@ -1138,11 +1138,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
 #pragma unroll
         for (int cb = 0; cb < NKB; ++cb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(s[rb][cb][r]);  // S came out of the MFMA as log2 P
-            s[rb][cb][r] = pr;
-            dp[rb][cb][r] *= pr;  // dS (unscaled)
-          }
+          for (int r = 0; r < 4; ++r) s[rb][cb][r] = __builtin_amdgcn_exp2f(s[rb][cb][r]);  // S came out of the MFMA as log2 P
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NKB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dp[rb][cb][r] *= s[rb][cb][r];  // dS (unscaled)
       bf16x8 pf[2], df[2];
 #pragma unroll
       for (int cb = 0; cb < NKB; ++cb) {
@@ -1468,7 +1470,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[rb][cb][r] = __builtin_amdgcn_exp2f(s[rb][cb][r]) * dp[rb][cb][r];  // dS^T (unscaled)
+          for (int r = 0; r < 4; ++r) s[rb][cb][r] = __builtin_amdgcn_exp2f(s[rb][cb][r]);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[rb][cb][r] *= dp[rb][cb][r];  // dS^T (unscaled)
       bf16x8 df[2];
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) df[cb] = pack2(s[0][cb], s[1][cb]);

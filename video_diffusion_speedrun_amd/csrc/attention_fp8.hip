@@ -626,7 +626,9 @@ __global__ __launch_bounds__(256, 2) void attn8_bwd_dkv_kernel(Attn8P p) {
         f32x4 pr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) pr[r] = EXACT_EXP ? __builtin_amdgcn_exp2f(s[cb][r]) : pexp_bits(s[cb][r]);  // 256 P
-        const f32x4 ds = pr * dp[cb];  // P (dP - delta) / (s_do s_v): |.| <= 4032 (file header); two v_pk_mul_f32
+        f32x4 ds;  // P (dP - delta) / (s_do s_v): |.| <= 4032 (file header).  (Scalar multiplies: v_pk_mul_f32 measured slower.)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = pr[r] * dp[cb][r];
         pq[cb][i] = cvt4_e4m3(pr);
         dsq[cb][i] = cvt4_e5m2(ds);
       }
