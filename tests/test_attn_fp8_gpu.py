@@ -421,8 +421,9 @@ def test_fp8_attention_step_close_to_oracle(parity_log, cross):
     DiT.enable_fp8() with the self-attention products on the fp8 MFMA (head_dim 72): one pass records the amax
     history (bf16 attention kernels), the second pass over the same inputs quantises q / k / v / dO with it and runs
     the fp8 kernels (asserted by launch count).  Against the fp32 CPU oracle of the same step -- stated tolerance:
-    output within 2.5e-2 relative, loss within 1e-2, every parameter gradient cosine >= 0.98 and relative error
-    <= 0.2 (e4m3 P, e5m2 dS / dO carry 3 / 2 mantissa bits; measured figures go to parity_report.jsonl)."""
+    output within 2.5e-2 relative, loss within 1e-2, every parameter gradient cosine >= 0.988 and relative error
+    <= 0.16 (e4m3 P, e5m2 dS / dO carry 3 / 2 mantissa bits; measured worst at this small shape 0.9922 / 0.124, both
+    on a cross-attention weight; measured figures go to parity_report.jsonl)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import dit_oracle as O
@@ -474,4 +475,4 @@ def test_fp8_attention_step_close_to_oracle(parity_log, cross):
             worst_e = (e, k)
     parity_log("fp8_attention_step" + ("_cross" if cross else ""), out_rel=e_out, loss_rel=e_loss, worst_cos=worst_c, worst_rel=worst_e)
     assert e_out <= 2.5e-2 and e_loss <= 1e-2, (e_out, e_loss)
-    assert worst_c[0] >= 0.98 and worst_e[0] <= 0.2, (worst_c, worst_e)
+    assert worst_c[0] >= 0.988 and worst_e[0] <= 0.16, (worst_c, worst_e)

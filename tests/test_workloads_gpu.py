@@ -26,7 +26,7 @@ bf16, f32 = torch.bfloat16, torch.float32
 GRAD_COS, GRAD_REL = 0.9995, 2e-2
 # fp8 linears + fp8 self-attention (e4m3 / e5m2 operands, P and dS included): test_model_gpu.py::test_fp8_step_close_to_oracle,
 # test_attn_fp8_gpu.py::test_fp8_attention_step_close_to_oracle
-FP8_GRAD_COS, FP8_GRAD_REL = 0.98, 0.2
+FP8_GRAD_COS, FP8_GRAD_REL = 0.995, 0.11  # round 4: measured worst at the headline shape 0.9975 / 7.8e-2 (was 0.98 / 0.2)
 
 
 @pytest.fixture(scope="module")
