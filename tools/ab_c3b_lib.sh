@@ -6,5 +6,5 @@ for v in new other; do
   if [ $v = other ]; then export VDS_LIB_PATH=$PWD/$1; else unset VDS_LIB_PATH; fi
   python bench.py --steps $S --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' > $O/c3b_${v}_$r.json
   python -c "
-import json; d=json.load(open('$O/c3b_${v}_$r.json')); k=d['kernel_breakdown_ms']; print('$v', round(d['value'],3), round(d['ms_per_step'],1), round(d['ms_per_step_median'],1), {n:v for n,v in k.items() if 'attn' in n and 'plain' not in n})"
+import json,sys; d=json.load(open('$O/c3b_${v}_$r.json')); k=d['kernel_breakdown_ms']; print('$v', round(d['value'],3), round(d['ms_per_step'],1), round(d['ms_per_step_median'],1), {n:v for n,v in k.items() if (sys.argv[1] in n) or n=='_sum'})" "${3:-attn_}"
 done; done

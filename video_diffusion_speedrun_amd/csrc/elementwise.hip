@@ -10,6 +10,22 @@
 #include "../../include/vds.h"
 
 namespace {
+// streaming accesses of the row kernels below (each activation-sized tensor is read / written once per launch), with
+// the non-temporal hint where bit WHICH of VDS_EW_NT is set: 1 = rmsnorm_mod_bwd loads, 2 = its store, 4 = gate_bwd,
+// 8 = rmsnorm_mod_fwd, 16 = qkv_rope_bwd_tok loads (same-box A/B: DESIGN.md Appendix A)
+#ifndef VDS_EW_NT
+#define VDS_EW_NT 3
+#endif
+template <int WHICH>
+__device__ __forceinline__ u32x4 ld_stream(const bf16_t* p) {
+  if constexpr ((VDS_EW_NT & WHICH) != 0) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  else return *reinterpret_cast<const u32x4*>(p);
+}
+template <int WHICH>
+__device__ __forceinline__ void st_stream(bf16_t* p, u32x4 v) {
+  if constexpr ((VDS_EW_NT & WHICH) != 0) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+  else *reinterpret_cast<u32x4*>(p) = v;
+}
 
 __device__ __forceinline__ void unpack8(const u32x4& u, float (&f)[8]) {
 #pragma unroll
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
     const int c = lane + 64 * i;
     raw[i] = u32x4{0u, 0u, 0u, 0u};
     if (c < nch) {
-      raw[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
+      raw[i] = ld_stream<8>(x + row * ldx + c * 8);
       float v[8];
       unpack8(raw[i], v);
 #pragma unroll
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
         o[e] = xn * (1.0f + sc[e]) + sh[e];
       }
       if constexpr (QF >= 0) *reinterpret_cast<u32x2*>(qo.q + row * qo.ldq + c * 8) = qs.cvt(o);
-      else *reinterpret_cast<u32x4*>(y + row * ldy + c * 8) = pack8(o);
+      else st_stream<8>(y + row * ldy + c * 8, pack8(o));
     }
   }
   if constexpr (QF >= 0) qs.finish();
@@ -185,9 +201,9 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
-        pdy[i] = *reinterpret_cast<const u32x4*>(dy + row * lddy + c * 8);
-        px[i] = *reinterpret_cast<const u32x4*>(x + row * ldx + c * 8);
-        pres[i] = dres ? *reinterpret_cast<const u32x4*>(dres + row * lddres + c * 8) : u32x4{0u, 0u, 0u, 0u};
+        pdy[i] = ld_stream<1>(dy + row * lddy + c * 8);
+        px[i] = ld_stream<1>(x + row * ldx + c * 8);
+        pres[i] = dres ? ld_stream<1>(dres + row * lddres + c * 8) : u32x4{0u, 0u, 0u, 0u};
       } else {
         pdy[i] = u32x4{0u, 0u, 0u, 0u};
         px[i] = u32x4{0u, 0u, 0u, 0u};
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
           if constexpr (HAS_W) g *= wv[i][e];
           o[e] += r * (g - xv[e] * r * dot);
         }
-        *reinterpret_cast<u32x4*>(dx + row * lddx + c * 8) = pack8(o);
+        st_stream<2>(dx + row * lddx + c * 8, pack8(o));
       }
     }
   }
@@ -291,8 +307,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
       const int c = lane + 64 * i;
       if (c < nch) {
         float d[8], yv[8], o[8];
-        unpack8(*reinterpret_cast<const u32x4*>(dxn + row * lddxn + c * 8), d);
-        unpack8(*reinterpret_cast<const u32x4*>(y + row * ldy + c * 8), yv);
+        unpack8(ld_stream<4>(dxn + row * lddxn + c * 8), d);
+        unpack8(ld_stream<4>(y + row * ldy + c * 8), yv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           a_g[i][e] += d[e] * yv[e];
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
           a_b[i][e] += o[e];
         }
         if constexpr (QF >= 0) *reinterpret_cast<u32x2*>(qo.q + row * qo.ldq + c * 8) = qs.cvt(o);
-        else *reinterpret_cast<u32x4*>(dy + row * lddy + c * 8) = pack8(o);
+        else st_stream<4>(dy + row * lddy + c * 8, pack8(o));
       }
     }
   }
@@ -633,8 +649,8 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
       if (c < nch) {
         const int hh = c / cph, j = c % cph;
         const long so = (((long)b * H + hh) * L + l) * hdp + 8 * j;
-        rq[i] = *reinterpret_cast<const u32x4*>(dq + so);
-        rk[i] = *reinterpret_cast<const u32x4*>(dk + so);
+        rq[i] = ld_stream<16>(dq + so);
+        rk[i] = ld_stream<16>(dk + so);
         *reinterpret_cast<u32x4*>(wq + c * 16) = rq[i];
         *reinterpret_cast<u32x4*>(wk + c * 16) = rk[i];
       }
@@ -684,7 +700,7 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
         *reinterpret_cast<u32x4*>(dst + D + c * 8) = pack8(ok_);
       }
       float g[8];
-      unpack8(*reinterpret_cast<const u32x4*>(dv + so), g);
+      unpack8(ld_stream<16>(dv + so), g);
       if (mix) {
         float vr[8], vz[8], a[8];
         unpack8(*reinterpret_cast<const u32x4*>(qkv_raw + tok * 3 * D + 2 * D + c * 8), vr);
