@@ -92,6 +92,9 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+#ifndef VDS_DELTA_NT
+#define VDS_DELTA_NT 1  // delta preprocess: non-temporal loads of O / dO (6.7 -> 6.3 ms per step; 0 = plain loads)
+#endif
 #ifdef VDS_ATTN_PRIO
 #define PRIO_HI() __builtin_amdgcn_s_setprio(1)
 #define PRIO_LO() __builtin_amdgcn_s_setprio(0)
@@ -667,8 +670,13 @@ __global__ __launch_bounds__(256) void attn_delta_tokmajor_kernel(AttnP p) {
   for (int i = 0; i < 3; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
+#if VDS_DELTA_NT  // non-temporal loads of O (saved by the forward pass) and dO: read once
+      const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(o + c * 8));
+      const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(d + c * 8));
+#else
       const u32x4 a = *reinterpret_cast<const u32x4*>(o + c * 8);
       const u32x4 g = *reinterpret_cast<const u32x4*>(d + c * 8);
+#endif
       float acc = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc += bflo(a[e]) * bflo(g[e]) + bfhi(a[e]) * bfhi(g[e]);

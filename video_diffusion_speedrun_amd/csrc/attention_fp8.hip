@@ -891,8 +891,8 @@ __global__ __launch_bounds__(256) void attn8_delta_kernel(const bf16_t* o, long 
   for (int i = 0; i < 3; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(orow + c * 8);
-      const u32x4 gq = *reinterpret_cast<const u32x4*>(drow + c * 8);
+      const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(orow + c * 8));  // read once
+      const u32x4 gq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(drow + c * 8));
       float acc = 0.f;
       float f[8];
 #pragma unroll

@@ -12,9 +12,9 @@
 namespace {
 // streaming accesses of the row kernels below (each activation-sized tensor is read / written once per launch), with
 // the non-temporal hint where bit WHICH of VDS_EW_NT is set: 1 = rmsnorm_mod_bwd loads, 2 = its store, 4 = gate_bwd,
-// 8 = rmsnorm_mod_fwd, 16 = qkv_rope_bwd_tok loads (same-box A/B: DESIGN.md Appendix A)
+// 8 = rmsnorm_mod_fwd, 16 = qkv_rope_bwd_tok loads, 32 = gate_bwd's saved y (same-box A/B: DESIGN.md Appendix A)
 #ifndef VDS_EW_NT
-#define VDS_EW_NT 3
+#define VDS_EW_NT 35
 #endif
 template <int WHICH>
 __device__ __forceinline__ u32x4 ld_stream(const bf16_t* p) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
       if (c < nch) {
         float d[8], yv[8], o[8];
         unpack8(ld_stream<4>(dxn + row * lddxn + c * 8), d);
-        unpack8(ld_stream<4>(y + row * ldy + c * 8), yv);
+        unpack8(ld_stream<32>(y + row * ldy + c * 8), yv);  // (the saved forward result: bit 32)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           a_g[i][e] += d[e] * yv[e];
