@@ -26,6 +26,9 @@
 #include <mutex>
 #include <type_traits>
 
+#ifndef VDS_GEMM_AUX_NT
+#define VDS_GEMM_AUX_NT 1  // aux tiles with the non-temporal hint (NT + NN GEMM classes -1.2 ms per step; 0 = plain loads)
+#endif
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -220,8 +223,13 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmP& p, int row0, int 
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const long grow = row0 + it * 8 + rin;
+#if VDS_GEMM_AUX_NT  // the aux tile (residual / pre-activation) is read exactly once per launch
+      auxr[it] = (grow < p.M && cok) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol))
+                                     : u32x4{0u, 0u, 0u, 0u};
+#else
       auxr[it] = (grow < p.M && cok) ? *reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol)
                                      : u32x4{0u, 0u, 0u, 0u};
+#endif
     }
   }
 }
