@@ -1,9 +1,11 @@
 #!/bin/bash
-# the round's closing evidence on ONE box: full GPU suite, one bench line per workload, rocprof passes, fp8 soaks
+# the round's closing evidence on ONE box: full GPU suite, one bench line per workload, rocprof passes (SOAK=1: + fp8 soaks)
 mkdir -p gpurun_out/r04final
 python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > gpurun_out/r04final/gpu_suite.log; cat gpurun_out/r04final/gpu_suite.log
 bash tools/r04_final_benches.sh 2>&1 | tee gpurun_out/r04final/final_benches_summary.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 bash tools/collect_profiles.sh r04 > gpurun_out/r04final/collect_profiles.log 2>&1; tail -5 gpurun_out/r04final/collect_profiles.log
+if [ "${SOAK:-0}" = 1 ]; then
 WORKLOAD=c3b B=4 STEPS=200 MODES=bf16,fp8x python tools/soak.py > gpurun_out/r04final/soak200.json 2> gpurun_out/r04final/soak200.err; tail -c 400 gpurun_out/r04final/soak200.json
 WORKLOAD=c3b B=4 STEPS=1000 MODES=bf16,fp8x python tools/soak.py > gpurun_out/r04final/soak1000.json 2> gpurun_out/r04final/soak1000.err; tail -c 400 gpurun_out/r04final/soak1000.json
+fi
