@@ -744,6 +744,37 @@ def test_small_linear_batched_equals_per_set(ops):
     close("batched.dx", dx, dx_ref, 1e-5)
 
 
+@pytest.mark.parametrize("M", [3, 12, 16])
+@pytest.mark.parametrize("act", [0, 1])
+def test_small_linear_batched_streaming_kernels_vs_fp32(ops, M, act):
+    """round 4: at adaLN sizes (N >= 1024) the batched forward runs on the MFMA (x as a bf16 hi + lo pair from LDS, W
+    streamed once), dW in 64 x 128 tiles, dx with its dy slices staged in LDS (several slices per workgroup here);
+    against fp64 torch on the same bf16 weights: y, dW, dbias, dx within 1e-4 / 1e-5"""
+    nb, N, K = 3, 2080, 288
+    x = gen(M, K, seed=150, dtype=f32).cuda()
+    Ws = [gen(N, K, seed=151 + i, scale=0.1).cuda() for i in range(nb)]
+    bs = [gen(N, seed=161 + i, scale=0.1).cuda() for i in range(nb)]
+    y = ops.small_linear_fwd_batched(x, ops.ptr_table(Ws), ops.ptr_table(bs), nb, N, act)
+    dy = gen(nb, M, N, seed=170, dtype=f32).cuda()
+    dWs = [torch.full((N, K), 7.0, dtype=f32, device="cuda") for _ in range(nb)]  # (written, not accumulated)
+    dbs = [torch.full((N,), 7.0, dtype=f32, device="cuda") for _ in range(nb)]
+    dx = torch.zeros(M, K, dtype=f32, device="cuda")
+    ops.small_linear_bwd_batched(dy, x, ops.ptr_table(Ws), ops.ptr_table(dWs), ops.ptr_table(dbs), dx, act)
+    xr = x.double().cpu().requires_grad_(True)
+    xa = torch.nn.functional.silu(xr) if act else xr
+    tot = 0.0
+    for i in range(nb):
+        Wd = Ws[i].double().cpu().requires_grad_(True)
+        yr = xa @ Wd.t() + bs[i].double().cpu()
+        close(f"sl.y{i}", y[i], yr.detach(), 1e-4)
+        (g,) = torch.autograd.grad((yr * dy[i].double().cpu()).sum(), Wd, retain_graph=True)
+        close(f"sl.dW{i}", dWs[i], g, 1e-4)
+        close(f"sl.db{i}", dbs[i], dy[i].double().cpu().sum(0), 1e-5)
+        tot = tot + (yr * dy[i].double().cpu()).sum()
+    tot.backward()
+    close("sl.dx", dx, xr.grad, 1e-4)
+
+
 def test_gemm_nn_dgelu_with_fused_bias_gradient(ops, tile):
     """dx = (dy W) * gelu'(pre) with colsum[k] += sum_m dx[m,k] from the same call (the fc1 bias gradient,
     model.py:84): fused in the 256^2 kernel's epilogue, a follow-up pass for the other tilings; M ragged, N ragged

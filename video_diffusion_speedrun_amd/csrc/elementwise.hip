@@ -844,11 +844,68 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* dy, c
 // chunk tid%8).  Every thread streams one 16-byte piece of W per row step (32 rows per step, unrolled), the 32 row
 // lanes are summed with lane exchanges + 4 KB of LDS, and only the n-ranges meet in atomics (dx accumulates the
 // modulation gradients of every block anyway).  W is read exactly once at full HBM request parallelism.
+// dW / dbias, batched form (round 4): tile = 64 rows of dW x 128 columns per workgroup; the tile's slices of x (SiLU
+// applied once) and dy sit in LDS, a thread owns 4 rows x 8 columns and reads them with 16-byte LDS accesses instead of
+// 60 loads through L1 per 128 bytes written; dW leaves with non-temporal stores (read next by the optimizer).
+template <int MB>
+__global__ __launch_bounds__(256) void small_linear_dw_tile_kernel(const float* dy, const float* x, int M, int N, int K,
+                                                                   int act_in, SLBatch bt) {
+  __shared__ __attribute__((aligned(16))) float xs[MB][128];
+  __shared__ __attribute__((aligned(16))) float dys[MB][64];
+  float* dW = bt.dW[blockIdx.z];
+  float* dbias = bt.dbias ? bt.dbias[blockIdx.z] : nullptr;
+  dy += (long)blockIdx.z * bt.y_stride;
+  const int tid = threadIdx.x;
+  const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 64;
+  for (int i = tid; i < MB * 128; i += 256) {
+    const int b = i >> 7, k = k0 + (i & 127);
+    float v = (b < M && k < K) ? x[(long)b * K + k] : 0.f;
+    xs[b][i & 127] = act_in ? silu_f(v) : v;
+  }
+  for (int i = tid; i < MB * 64; i += 256) {
+    const int b = i >> 6, n = n0 + (i & 63);
+    dys[b][i & 63] = (b < M && n < N) ? dy[(long)b * N + n] : 0.f;
+  }
+  __syncthreads();
+  const int c = tid & 15, ng = tid >> 4;  // 8 columns k0 + 8c .., 4 rows n0 + 4 ng ..
+  float acc[4][8], sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(&xs[b][8 * c]), x1 = *reinterpret_cast<const f32x4*>(&xs[b][8 * c + 4]);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(&dys[b][4 * ng]);
+    const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sb[i] += g[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[i][e] += g[i] * xv[e];
+    }
+  }
+  const int k = k0 + 8 * c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + 4 * ng + i;
+    if (n >= N || k >= K) continue;
+    float* o = dW + (long)n * K + k;
+    __builtin_nontemporal_store(f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]}, reinterpret_cast<f32x4*>(o));
+    __builtin_nontemporal_store(f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]}, reinterpret_cast<f32x4*>(o + 4));
+    if (blockIdx.x == 0 && c == 0 && dbias) dbias[n] = sb[i];
+  }
+}
+
+// dx.  round 4: the workgroup's slice of dy is staged in LDS TRANSPOSED ([row n][16 samples]: three ds_read_b128 per W
+// chunk instead of 12 scalar loads through L1) and W is read with the non-temporal hint (once per pass).
+constexpr int SL_DX_ROWS = 384;  // rows of W per workgroup at most (the host picks the row split accordingly)
 template <int MB>
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* dy, const float* x, const bf16_t* W,
                                                               float* dx, int M, int N, int K, int act_in,
                                                               int rows_per_block, SLBatch bt) {
   __shared__ float red[4][8][MB][8];
+  __shared__ __attribute__((aligned(16))) float dyt[SL_DX_ROWS][MB];
   if (bt.W) {
     W = (const bf16_t*)bt.W[blockIdx.z];
     dy += (long)blockIdx.z * bt.y_stride;
@@ -857,26 +914,37 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* dy, c
   const int c = tid & 7, r = tid >> 3;
   const int kc = K >> 3, cg = blockIdx.x * 8 + c;
   const bool live = cg < kc;
-  const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+  const int n_lo = blockIdx.y * rows_per_block, n_hi = min(N, n_lo + rows_per_block);
   float acc[MB][8];
 #pragma unroll
   for (int b = 0; b < MB; ++b)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[b][e] = 0.f;
   const bf16_t* wp = W + (long)cg * 8;
-#pragma unroll 4
-  for (int n = n0 + r; n < n1; n += 32) {
-    float wv[8];
-    u32x4 raw = u32x4{0, 0, 0, 0};
-    if (live) raw = *reinterpret_cast<const u32x4*>(wp + (long)n * K);
-    unpack8(raw, wv);
+  for (int n0 = n_lo; n0 < n_hi; n0 += SL_DX_ROWS) {  // the workgroup's rows in LDS-sized slices
+    const int n1 = min(n_hi, n0 + SL_DX_ROWS);
+    __syncthreads();  // (the previous slice has been consumed)
 #pragma unroll
     for (int b = 0; b < MB; ++b)
-      if (b < M) {
-        const float g = dy[(long)b * N + n];
+      for (int j = tid; j < n1 - n0; j += 256) dyt[j][b] = b < M ? dy[(long)b * N + n0 + j] : 0.f;
+    __syncthreads();
+#pragma unroll 4
+    for (int n = n0 + r; n < n1; n += 32) {
+      float wv[8];
+      u32x4 raw = u32x4{0, 0, 0, 0};
+      if (live) raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (long)n * K));
+      unpack8(raw, wv);
+      float g[MB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[b][e] += g * wv[e];
+      for (int q = 0; q < MB / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(&dyt[n - n0][4 * q]);
+        g[4 * q] = t[0]; g[4 * q + 1] = t[1]; g[4 * q + 2] = t[2]; g[4 * q + 3] = t[3];
       }
+#pragma unroll
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[b][e] += g[b] * wv[e];
+    }
   }
   // sum the 8 row lanes of this wave (lanes differing in bits 3..5), then the 4 waves through LDS
 #pragma unroll
@@ -1435,6 +1503,84 @@ extern "C" int vds_small_linear_bwd(const float* dy, const float* x, const void*
 }
 
 // the batched forms: nb weight sets (device pointer tables) applied to one shared input of M <= 16 rows
+// ---- round 4: the batched adaLN linears as streaming kernels -----------------------------------------------------
+// The 28 x [9D, D] modulation weights (669 MB at DiT-XL) are read once per pass against a 12-row input: the kernels
+// above re-read x (forward: 6 bytes of x through L1 per byte of W, SiLU recomputed per wave) resp. dy (12 scalar loads
+// per 16 bytes of W) and ran at 0.7 / 0.34 TB/s.  Here the small operand lives in LDS and W streams past it once.
+//
+// forward on v_mfma_f32_16x16x32_bf16: y^T[n, m] = sum_k W[n, k] x[m, k].  A = 16 rows of W straight from global memory
+// (lane (r = l & 15, g = l >> 4) loads the 16 bytes k0 + 8g .. + 7 of row n0 + r: its MFMA fragment), B = x^T from LDS as
+// a bf16 (hi, lo) pair -- x = hi + lo to 2^-17, two MFMAs per K step -- so the fp32 input keeps its precision.  One wave =
+// 16 output columns; the accumulator lane (c, g) holds y[m = c][n0 + 4g .. + 3]: one 16-byte store.
+typedef __attribute__((ext_vector_type(8))) __bf16 sl_bf16x8;
+__global__ __launch_bounds__(256) void small_linear_fwd_mfma_kernel(const float* x, float* y, int M, int N, int K,
+                                                                    int act_in, SLBatch bt) {
+  extern __shared__ __attribute__((aligned(16))) char sl_smem[];
+  const bf16_t* W = (const bf16_t*)bt.W[blockIdx.z];
+  const bf16_t* bias = bt.bias ? (const bf16_t*)bt.bias[blockIdx.z] : nullptr;
+  y += (long)blockIdx.z * bt.y_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ldx = K * 2 + 16;  // bytes per staged row (+16: rows 4 banks apart, conflict-free ds_read_b128)
+  char* xhi = sl_smem;
+  char* xlo = sl_smem + 16 * ldx;
+  for (int i = tid; i < 16 * (K >> 2); i += 256) {  // 4 consecutive k per thread
+    const int m = i / (K >> 2), k4 = (i % (K >> 2)) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m < M) v = *reinterpret_cast<const f32x4*>(x + (long)m * K + k4);
+    u32x2 h, l;
+    float hf[4], lf[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = act_in ? silu_f(v[e]) : v[e];
+      hf[e] = bf2f(f2bf(a));
+      lf[e] = a - hf[e];
+    }
+    h = u32x2{pack_bf2(hf[0], hf[1]), pack_bf2(hf[2], hf[3])};
+    l = u32x2{pack_bf2(lf[0], lf[1]), pack_bf2(lf[2], lf[3])};
+    *reinterpret_cast<u32x2*>(xhi + m * ldx + k4 * 2) = h;
+    *reinterpret_cast<u32x2*>(xlo + m * ldx + k4 * 2) = l;
+  }
+  __syncthreads();
+  const int n0 = (blockIdx.x * 4 + wave) * 16;
+  if (n0 >= N) return;
+  const int r = lane & 15, g = lane >> 4;
+  const bf16_t* wrow = W + (long)min(n0 + r, N - 1) * K + 8 * g;
+  const char* bh = xhi + r * ldx + 16 * g;
+  const char* bl = xlo + r * ldx + 16 * g;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nks = K >> 5;
+  constexpr int U = 6;  // K steps whose W loads are in flight together
+  int ks = 0;
+  for (; ks + U <= nks; ks += U) {
+    u32x4 a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (ks + u) * 32));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const sl_bf16x8 av = __builtin_bit_cast(sl_bf16x8, a[u]);
+      const sl_bf16x8 h = *reinterpret_cast<const sl_bf16x8*>(bh + (ks + u) * 64);
+      const sl_bf16x8 l = *reinterpret_cast<const sl_bf16x8*>(bl + (ks + u) * 64);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, h, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, l, acc, 0, 0, 0);
+    }
+  }
+  for (; ks < nks; ++ks) {
+    const sl_bf16x8 av = __builtin_bit_cast(sl_bf16x8, *reinterpret_cast<const u32x4*>(wrow + ks * 32));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, *reinterpret_cast<const sl_bf16x8*>(bh + ks * 64), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, *reinterpret_cast<const sl_bf16x8*>(bl + ks * 64), acc, 0, 0, 0);
+  }
+  // accumulator: column j = lane & 15 = m, rows 4 g + e = output columns n0 + 4 g + e
+  const int m = r, nn = n0 + 4 * g;
+  if (m < M && nn < N) {
+    f32x4 o = acc;
+    if (bias) {
+      const u32x2 bv = *reinterpret_cast<const u32x2*>(bias + nn);
+      o[0] += bflo(bv[0]); o[1] += bfhi(bv[0]); o[2] += bflo(bv[1]); o[3] += bfhi(bv[1]);
+    }
+    *reinterpret_cast<f32x4*>(y + (long)m * N + nn) = o;
+  }
+}
+
 extern "C" int vds_small_linear_fwd_batched(const float* x, const void* const* W_ptrs, const void* const* bias_ptrs,
                                             float* y, int64_t y_stride, int32_t nb, int32_t M, int32_t N, int32_t K,
                                             int32_t act_in, vds_stream_t stream) {
@@ -1442,6 +1588,22 @@ extern "C" int vds_small_linear_fwd_batched(const float* x, const void* const* W
   const dim3 grid((N + 15) / 16, 1, nb);
   const SLBatch bt{W_ptrs, bias_ptrs, nullptr, nullptr, (long)y_stride};
   hipStream_t s = (hipStream_t)stream;
+  static int mfma_on = -1;  // VDS_ADALN_MFMA=0: the row kernels below (A/B)
+  if (mfma_on < 0) {
+    const char* e = getenv("VDS_ADALN_MFMA");
+    mfma_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  const size_t lds = (size_t)2 * 16 * (K * 2 + 16);
+  if (mfma_on && (K & 31) == 0 && (N & 15) == 0 && lds <= 160 * 1024 && N >= 1024) {  // (small N: the row kernel's finer grid)
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_linear_fwd_mfma_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(small_linear_fwd_mfma_kernel, dim3((N / 16 + 3) / 4, 1, nb), dim3(256), lds, s, x, y, M, N, K, act_in, bt);
+    return ok();
+  }
   if (M <= 4) hipLaunchKernelGGL(small_linear_fwd_kernel<4>, grid, dim3(256), 0, s, x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, y, M, N, K, act_in, bt);
   else if (M <= 8) hipLaunchKernelGGL(small_linear_fwd_kernel<8>, grid, dim3(256), 0, s, x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, y, M, N, K, act_in, bt);
   else hipLaunchKernelGGL(small_linear_fwd_kernel<16>, grid, dim3(256), 0, s, x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, y, M, N, K, act_in, bt);
@@ -1454,15 +1616,18 @@ extern "C" int vds_small_linear_bwd_batched(const float* dy, int64_t dy_stride, 
   if (!dy || !x || nb < 1 || M < 1 || M > 16 || (K & 7)) return VDS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (dW_ptrs) {
-    const long n = (long)((N + 3) / 4) * (K >> 3);
     const SLBatch bt{nullptr, nullptr, dW_ptrs, dbias_ptrs, (long)dy_stride};
-    hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((n + 255) / 256), 1, nb), dim3(256), 0, s, dy, x,
-                       (float*)nullptr, (float*)nullptr, M, N, K, act_in, bt);
+    const dim3 tg((K + 127) / 128, (N + 63) / 64, nb);
+    if (M <= 4) hipLaunchKernelGGL(small_linear_dw_tile_kernel<4>, tg, dim3(256), 0, s, dy, x, M, N, K, act_in, bt);
+    else if (M <= 8) hipLaunchKernelGGL(small_linear_dw_tile_kernel<8>, tg, dim3(256), 0, s, dy, x, M, N, K, act_in, bt);
+    else hipLaunchKernelGGL(small_linear_dw_tile_kernel<16>, tg, dim3(256), 0, s, dy, x, M, N, K, act_in, bt);
   }
   if (dx) {
     if (!W_ptrs) return VDS_ERR_ARG;
     const int gx = ((K >> 3) + 7) / 8;
-    int ny = max(1, min((N + 31) / 32, (512 + gx - 1) / gx));
+    // row split: enough workgroups over all sets for ~8 per CU, each with several LDS slices of rows (the epilogue --
+    // a 3-level reduction and 8 x M x 8 atomics -- is paid once per workgroup)
+    int ny = max(1, min((N + 31) / 32, (2048 + gx * nb - 1) / (gx * nb)));
     const int rows = ((N + ny - 1) / ny + 31) / 32 * 32;
     ny = (N + rows - 1) / rows;
     const dim3 grid(gx, ny, nb);
