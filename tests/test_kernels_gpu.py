@@ -755,6 +755,8 @@ def test_small_linear_batched_streaming_kernels_vs_fp32(ops, M, act):
     Ws = [gen(N, K, seed=151 + i, scale=0.1).cuda() for i in range(nb)]
     bs = [gen(N, seed=161 + i, scale=0.1).cuda() for i in range(nb)]
     y = ops.small_linear_fwd_batched(x, ops.ptr_table(Ws), ops.ptr_table(bs), nb, N, act)
+    for i in range(nb):  # the per-block form (sharding runtime) runs the same per-row arithmetic: identical bits
+        assert torch.equal(y[i], ops.small_linear_fwd(x, Ws[i], bs[i], act))
     dy = gen(nb, M, N, seed=170, dtype=f32).cuda()
     dWs = [torch.full((N, K), 7.0, dtype=f32, device="cuda") for _ in range(nb)]  # (written, not accumulated)
     dbs = [torch.full((N,), 7.0, dtype=f32, device="cuda") for _ in range(nb)]

@@ -794,6 +794,7 @@ def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch, W, prefetch):
 
     ref = build(vds, cfg, P)
     opt, loss_ref = step(ref, slice(0, 4))
+    want_g = [g.gfull.clone() for g in ref._groups]  # the full-batch gradient of every flat group (world 1: gshard = gfull)
     opt.step()
     want = ref.full_state_dict()
 
@@ -808,15 +809,22 @@ def test_two_emulated_ranks_on_one_gpu(vds, monkeypatch, W, prefetch):
     torch.cuda.synchronize()  # rank 0's gradient shards were completed while rank 1 ran its backward
     assert all(len(d) == W for d in pending.values()) and len(pending) == 1 + cfg.depth
     assert abs(sum(losses) / W - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    # the reduce-scattered gradient shards = the full-batch gradient (fp32 sums in another order: 1e-5) ...
+    for gi in range(len(want_g)):
+        gs = torch.cat([m._groups[gi].gshard for m in reps])
+        assert rel(gs[:want_g[gi].numel()], want_g[gi]) <= 1e-5, (gi, rel(gs[:want_g[gi].numel()], want_g[gi]))
     for o in opts:
         o.step()
     torch.cuda.synchronize()
+    # ... and the stepped parameters agree.  (2e-4: the FIRST AdamW step is g / (|g| + eps), which turns the 1e-7 order
+    # differences of the gradients into visible ones wherever |g| is near eps; 1e-4 failed once in five full-suite runs
+    # at 1.06e-4 on one tensor.  The gradient check above is the tight one.)
     for gi, grp0 in enumerate(reps[0]._groups):
         flat = torch.cat([m._groups[gi].master for m in reps])
         for n in grp0.names:
             o0 = grp0.offsets[n]
             got = flat[o0:o0 + want[n].numel()].view(want[n].shape)
-            assert rel(got, want[n]) <= 1e-4, (n, rel(got, want[n]))
+            assert rel(got, want[n]) <= 2e-4, (n, rel(got, want[n]))
     # every parameter of a sharded replica is this rank's 1-D piece, and the pieces tile the tensor
     others = [dict(m.named_parameters()) for m in reps[1:]]
     for n, p0 in reps[0].named_parameters():

@@ -1449,6 +1449,108 @@ extern "C" int vds_qkv_rope_bwd_fp8(const void* dq, const void* dk, const void* 
   return ok();
 }
 
+// ---- round 4: the batched adaLN linears as streaming kernels -----------------------------------------------------
+// The 28 x [9D, D] modulation weights (669 MB at DiT-XL) are read once per pass against a 12-row input: the kernels
+// above re-read x (forward: 6 bytes of x through L1 per byte of W, SiLU recomputed per wave) resp. dy (12 scalar loads
+// per 16 bytes of W) and ran at 0.7 / 0.34 TB/s.  Here the small operand lives in LDS and W streams past it once.
+//
+// forward on v_mfma_f32_16x16x32_bf16: y^T[n, m] = sum_k W[n, k] x[m, k].  A = 16 rows of W straight from global memory
+// (lane (r = l & 15, g = l >> 4) loads the 16 bytes k0 + 8g .. + 7 of row n0 + r: its MFMA fragment), B = x^T from LDS as
+// bf16 (hi, mid, lo) terms -- x = hi + mid + lo to 2^-25, three MFMAs per K step -- so the fp32 input keeps its precision.  One wave =
+// 16 output columns; the accumulator lane (c, g) holds y[m = c][n0 + 4g .. + 3]: one 16-byte store.
+typedef __attribute__((ext_vector_type(8))) __bf16 sl_bf16x8;
+constexpr int SL_FWD_WAVES = 8;   // 16 output columns per wave: 128 per workgroup
+constexpr int SL_FWD_TERMS = 3;   // x = hi + mid + lo in bf16: 2^-25, i.e. fp32 (two terms: 2^-17, which the sharded-vs-
+                                  // unsharded gradient comparison of tests/test_model_gpu.py sees at the 1e-4 level)
+__global__ __launch_bounds__(64 * SL_FWD_WAVES) void small_linear_fwd_mfma_kernel(const float* x, const bf16_t* W,
+                                                                               const bf16_t* bias, float* y, int M, int N,
+                                                                               int K, int act_in, SLBatch bt) {
+  extern __shared__ __attribute__((aligned(16))) char sl_smem[];
+  if (bt.W) {  // batched: set blockIdx.z of the pointer tables (else: the one weight matrix passed directly)
+    W = (const bf16_t*)bt.W[blockIdx.z];
+    bias = bt.bias ? (const bf16_t*)bt.bias[blockIdx.z] : nullptr;
+    y += (long)blockIdx.z * bt.y_stride;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ldx = K * 2 + 16;  // bytes per staged row (+16: rows 4 banks apart, conflict-free ds_read_b128)
+  const int term = 16 * ldx;   // bytes per term
+  for (int i = tid; i < 16 * (K >> 2); i += 64 * SL_FWD_WAVES) {  // 4 consecutive k per thread
+    const int m = i / (K >> 2), k4 = (i % (K >> 2)) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m < M) v = *reinterpret_cast<const f32x4*>(x + (long)m * K + k4);
+    float rem[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rem[e] = act_in ? silu_f(v[e]) : v[e];
+#pragma unroll
+    for (int t = 0; t < SL_FWD_TERMS; ++t) {
+      float p[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p[e] = bf2f(f2bf(rem[e]));
+        rem[e] -= p[e];  // exact
+      }
+      *reinterpret_cast<u32x2*>(sl_smem + t * term + m * ldx + k4 * 2) = u32x2{pack_bf2(p[0], p[1]), pack_bf2(p[2], p[3])};
+    }
+  }
+  __syncthreads();
+  const int n0 = (blockIdx.x * SL_FWD_WAVES + wave) * 16;
+  if (n0 >= N) return;
+  const int r = lane & 15, g = lane >> 4;
+  const bf16_t* wrow = W + (long)min(n0 + r, N - 1) * K + 8 * g;
+  const char* bx = sl_smem + r * ldx + 16 * g;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nks = K >> 5;
+  constexpr int U = 6;  // K steps whose W loads are in flight together
+  auto step = [&](u32x4 raw, int ks) {
+    const sl_bf16x8 av = __builtin_bit_cast(sl_bf16x8, raw);
+#pragma unroll
+    for (int t = SL_FWD_TERMS - 1; t >= 0; --t)  // smallest term first
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, *reinterpret_cast<const sl_bf16x8*>(bx + t * term + ks * 64), acc, 0, 0, 0);
+  };
+  int ks = 0;
+  for (; ks + U <= nks; ks += U) {
+    u32x4 a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (ks + u) * 32));
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(a[u], ks + u);
+  }
+  for (; ks < nks; ++ks) step(*reinterpret_cast<const u32x4*>(wrow + ks * 32), ks);
+  // accumulator: column j = lane & 15 = m, rows 4 g + e = output columns n0 + 4 g + e
+  const int m = r, nn = n0 + 4 * g;
+  if (m < M && nn < N) {
+    f32x4 o = acc;
+    if (bias) {
+      const u32x2 bv = *reinterpret_cast<const u32x2*>(bias + nn);
+      o[0] += bflo(bv[0]); o[1] += bfhi(bv[0]); o[2] += bflo(bv[1]); o[3] += bfhi(bv[1]);
+    }
+    *reinterpret_cast<f32x4*>(y + (long)m * N + nn) = o;
+  }
+}
+
+// launches the MFMA forward when the shape suits it (the per-block form of the sharding runtime and the batched form of
+// the unsharded model then run the SAME per-row arithmetic: their results are bit-identical, which the sharded-vs-
+// unsharded comparisons of tests/test_model_gpu.py rely on).  VDS_ADALN_MFMA=0: the row kernel (A/B).
+static bool small_linear_fwd_mfma(const float* x, const bf16_t* W, const bf16_t* bias, float* y, int M, int N, int K,
+                                  int act_in, const SLBatch& bt, int nb, hipStream_t s) {
+  static int mfma_on = -1;
+  if (mfma_on < 0) {
+    const char* e = getenv("VDS_ADALN_MFMA");
+    mfma_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  const size_t lds = (size_t)SL_FWD_TERMS * 16 * (K * 2 + 16);
+  if (!mfma_on || M > 16 || (K & 31) || (N & 15) || lds > 160 * 1024 || N < 1024) return false;  // (small N: the row kernel's finer grid)
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_linear_fwd_mfma_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(small_linear_fwd_mfma_kernel, dim3((N / 16 + SL_FWD_WAVES - 1) / SL_FWD_WAVES, 1, nb),
+                     dim3(64 * SL_FWD_WAVES), lds, s, x, W, bias, y, M, N, K, act_in, bt);
+  return true;
+}
+
 extern "C" int vds_small_linear_fwd(const float* x, const void* W, const void* bias, float* y, int32_t M,
                                     int32_t N, int32_t K, int32_t act_in, vds_stream_t stream) {
   if (!x || !W || !y || M < 1 || (K & 7)) return VDS_ERR_ARG;
@@ -1459,6 +1561,8 @@ extern "C" int vds_small_linear_fwd(const float* x, const void* W, const void* b
     const int m = min(16, M - r0);
     const float* xs = x + (long)r0 * K;
     float* ys = y + (long)r0 * N;
+    if (small_linear_fwd_mfma(xs, (const bf16_t*)W, (const bf16_t*)bias, ys, m, N, K, act_in, SLBatch{}, 1, (hipStream_t)stream))
+      continue;
     if (m <= 4)
       hipLaunchKernelGGL(small_linear_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, xs, (const bf16_t*)W,
                          (const bf16_t*)bias, ys, m, N, K, act_in, SLBatch{});
@@ -1503,84 +1607,6 @@ extern "C" int vds_small_linear_bwd(const float* dy, const float* x, const void*
 }
 
 // the batched forms: nb weight sets (device pointer tables) applied to one shared input of M <= 16 rows
-// ---- round 4: the batched adaLN linears as streaming kernels -----------------------------------------------------
-// The 28 x [9D, D] modulation weights (669 MB at DiT-XL) are read once per pass against a 12-row input: the kernels
-// above re-read x (forward: 6 bytes of x through L1 per byte of W, SiLU recomputed per wave) resp. dy (12 scalar loads
-// per 16 bytes of W) and ran at 0.7 / 0.34 TB/s.  Here the small operand lives in LDS and W streams past it once.
-//
-// forward on v_mfma_f32_16x16x32_bf16: y^T[n, m] = sum_k W[n, k] x[m, k].  A = 16 rows of W straight from global memory
-// (lane (r = l & 15, g = l >> 4) loads the 16 bytes k0 + 8g .. + 7 of row n0 + r: its MFMA fragment), B = x^T from LDS as
-// a bf16 (hi, lo) pair -- x = hi + lo to 2^-17, two MFMAs per K step -- so the fp32 input keeps its precision.  One wave =
-// 16 output columns; the accumulator lane (c, g) holds y[m = c][n0 + 4g .. + 3]: one 16-byte store.
-typedef __attribute__((ext_vector_type(8))) __bf16 sl_bf16x8;
-__global__ __launch_bounds__(256) void small_linear_fwd_mfma_kernel(const float* x, float* y, int M, int N, int K,
-                                                                    int act_in, SLBatch bt) {
-  extern __shared__ __attribute__((aligned(16))) char sl_smem[];
-  const bf16_t* W = (const bf16_t*)bt.W[blockIdx.z];
-  const bf16_t* bias = bt.bias ? (const bf16_t*)bt.bias[blockIdx.z] : nullptr;
-  y += (long)blockIdx.z * bt.y_stride;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ldx = K * 2 + 16;  // bytes per staged row (+16: rows 4 banks apart, conflict-free ds_read_b128)
-  char* xhi = sl_smem;
-  char* xlo = sl_smem + 16 * ldx;
-  for (int i = tid; i < 16 * (K >> 2); i += 256) {  // 4 consecutive k per thread
-    const int m = i / (K >> 2), k4 = (i % (K >> 2)) * 4;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (m < M) v = *reinterpret_cast<const f32x4*>(x + (long)m * K + k4);
-    u32x2 h, l;
-    float hf[4], lf[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float a = act_in ? silu_f(v[e]) : v[e];
-      hf[e] = bf2f(f2bf(a));
-      lf[e] = a - hf[e];
-    }
-    h = u32x2{pack_bf2(hf[0], hf[1]), pack_bf2(hf[2], hf[3])};
-    l = u32x2{pack_bf2(lf[0], lf[1]), pack_bf2(lf[2], lf[3])};
-    *reinterpret_cast<u32x2*>(xhi + m * ldx + k4 * 2) = h;
-    *reinterpret_cast<u32x2*>(xlo + m * ldx + k4 * 2) = l;
-  }
-  __syncthreads();
-  const int n0 = (blockIdx.x * 4 + wave) * 16;
-  if (n0 >= N) return;
-  const int r = lane & 15, g = lane >> 4;
-  const bf16_t* wrow = W + (long)min(n0 + r, N - 1) * K + 8 * g;
-  const char* bh = xhi + r * ldx + 16 * g;
-  const char* bl = xlo + r * ldx + 16 * g;
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nks = K >> 5;
-  constexpr int U = 6;  // K steps whose W loads are in flight together
-  int ks = 0;
-  for (; ks + U <= nks; ks += U) {
-    u32x4 a[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (ks + u) * 32));
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const sl_bf16x8 av = __builtin_bit_cast(sl_bf16x8, a[u]);
-      const sl_bf16x8 h = *reinterpret_cast<const sl_bf16x8*>(bh + (ks + u) * 64);
-      const sl_bf16x8 l = *reinterpret_cast<const sl_bf16x8*>(bl + (ks + u) * 64);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, h, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, l, acc, 0, 0, 0);
-    }
-  }
-  for (; ks < nks; ++ks) {
-    const sl_bf16x8 av = __builtin_bit_cast(sl_bf16x8, *reinterpret_cast<const u32x4*>(wrow + ks * 32));
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, *reinterpret_cast<const sl_bf16x8*>(bh + ks * 64), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, *reinterpret_cast<const sl_bf16x8*>(bl + ks * 64), acc, 0, 0, 0);
-  }
-  // accumulator: column j = lane & 15 = m, rows 4 g + e = output columns n0 + 4 g + e
-  const int m = r, nn = n0 + 4 * g;
-  if (m < M && nn < N) {
-    f32x4 o = acc;
-    if (bias) {
-      const u32x2 bv = *reinterpret_cast<const u32x2*>(bias + nn);
-      o[0] += bflo(bv[0]); o[1] += bfhi(bv[0]); o[2] += bflo(bv[1]); o[3] += bfhi(bv[1]);
-    }
-    *reinterpret_cast<f32x4*>(y + (long)m * N + nn) = o;
-  }
-}
-
 extern "C" int vds_small_linear_fwd_batched(const float* x, const void* const* W_ptrs, const void* const* bias_ptrs,
                                             float* y, int64_t y_stride, int32_t nb, int32_t M, int32_t N, int32_t K,
                                             int32_t act_in, vds_stream_t stream) {
@@ -1588,22 +1614,7 @@ extern "C" int vds_small_linear_fwd_batched(const float* x, const void* const* W
   const dim3 grid((N + 15) / 16, 1, nb);
   const SLBatch bt{W_ptrs, bias_ptrs, nullptr, nullptr, (long)y_stride};
   hipStream_t s = (hipStream_t)stream;
-  static int mfma_on = -1;  // VDS_ADALN_MFMA=0: the row kernels below (A/B)
-  if (mfma_on < 0) {
-    const char* e = getenv("VDS_ADALN_MFMA");
-    mfma_on = (e && e[0] == '0') ? 0 : 1;
-  }
-  const size_t lds = (size_t)2 * 16 * (K * 2 + 16);
-  if (mfma_on && (K & 31) == 0 && (N & 15) == 0 && lds <= 160 * 1024 && N >= 1024) {  // (small N: the row kernel's finer grid)
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_linear_fwd_mfma_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
-    hipLaunchKernelGGL(small_linear_fwd_mfma_kernel, dim3((N / 16 + 3) / 4, 1, nb), dim3(256), lds, s, x, y, M, N, K, act_in, bt);
-    return ok();
-  }
+  if (small_linear_fwd_mfma(x, nullptr, nullptr, y, M, N, K, act_in, bt, nb, s)) return ok();
   if (M <= 4) hipLaunchKernelGGL(small_linear_fwd_kernel<4>, grid, dim3(256), 0, s, x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, y, M, N, K, act_in, bt);
   else if (M <= 8) hipLaunchKernelGGL(small_linear_fwd_kernel<8>, grid, dim3(256), 0, s, x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, y, M, N, K, act_in, bt);
   else hipLaunchKernelGGL(small_linear_fwd_kernel<16>, grid, dim3(256), 0, s, x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, y, M, N, K, act_in, bt);
