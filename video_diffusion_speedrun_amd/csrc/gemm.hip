@@ -854,7 +854,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // pins the 128 zeroing moves HERE, before the pipeline fill below: hipcc otherwise sinks them behind the first
+      // vmcnt wait + barrier, onto the critical path of every tile (the wait hides them for free): fp8 NT + dgrad per
+      // block 4.13 -> 4.03 ms, bf16 unchanged.  (Not in the 192-wide tiling nor in the TN kernels: there the pin costs
+      // registers -- 85-104 spilled VGPRs, 7.9 -> 12.8 ms per block resp. the fp8 weight-gradient GEMMs 2.5x slower.)
+      if constexpr (WN == 256 && LAYOUT != VDS_TN) asm volatile("" : "+v"(acc[i][j]));
+    }
 
   constexpr int KS = FMT == 0 ? 2 : 1;  // MFMA k-steps per K tile
   using frag_t = std::conditional_t<FMT == 0, bf16x8, i32x8>;
