@@ -401,8 +401,10 @@ int vds_cast_bf16_f32(const void* src, float* dst, int64_t n, vds_stream_t strea
  * deq: device float[8] = {s_q, s_k, s_v, s_do, E, -, -, -}: dequantisation factors (x = x_q * s) and the exponent E with
  * s_q s_k log2(e) / sqrt(head_dim) = 2^-E exactly (the kernels' block-scaled MFMAs rely on it), written by the same two
  * producers.
- * o: bf16, any strides (last dim contiguous); lse f32 [B,H,Lq]; dq, dk, dv: bf16 strided like attention's.  o and dq
- * are written with 16-byte stores: base 16-byte aligned, strides multiples of 8 elements (else VDS_ERR_ARG).
+ * o: bf16, last dim contiguous; lse f32 [B,H,Lq]; dq, dk, dv: bf16 strided like attention's.  Alignment contract of the
+ * bf16 outputs (o, dq, dk, dv): strides multiples of 4 elements and 8-byte aligned bases (else VDS_ERR_ARG); when the
+ * strides are multiples of 8 elements on a 16-byte aligned base the rows leave with 16-byte stores (faster; same bits).
+ * The fp8 outputs o_q / dq_q (below): base and row stride multiples of 8 bytes (else VDS_ERR_ARG).
  * stats: the f32 [2,B,H,Lq] workspace vds_attn_fp8_delta filled (vds_attn_fp8_bwd_workspace_bytes).  head_dim 72. */
 typedef struct vds_attn_fp8_args {
   int32_t B, H, Lq, Lk, head_dim;

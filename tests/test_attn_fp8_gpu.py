@@ -248,15 +248,24 @@ def test_attn_fp8_epilogues_emit_the_quantised_copies_of_their_results(ops, L, L
 
 
 def test_attn_fp8_row_alignment_contract(ops):
-    """round 4: O and dQ are written with 16-byte stores (rows must be 16-byte aligned: VDS_ERR_ARG otherwise); dK / dV
-    keep an 8-byte path for rows that are not, which must write the same bits as the 16-byte path"""
+    """bf16 O / dQ / dK / dV rows that are 16-byte aligned leave with 16-byte stores (round 4); rows that are only 8-byte
+    aligned (the contract before round 4: strides in multiples of 4 elements) take an 8-byte path that must write the
+    same bits and nothing outside the rows (round 5, ADVICE r4: the 16-byte requirement had become an ABI change);
+    anything less aligned is VDS_ERR_ARG, as is an fp8 output row that is not 8-byte aligned."""
     dev = torch.device("cuda")
     B, H, L = 1, 2, 300
     (q8, k8, v8), deq, _ = make_qkv(B, H, L, 31, dev)
     o = torch.empty(B * L, H * HD, dtype=bf16, device=dev)
     lse = torch.empty(B, H, L, dtype=f32, device=dev)
     ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(o, B, L, H, HD), lse, HD)
-    obad = torch.empty(B * L, H * HD + 8, dtype=bf16, device=dev)[:, 4:4 + H * HD]  # rows 8 bytes off a 16-byte boundary
+    ofull = torch.full((B * L, H * HD + 8), 5.0, dtype=bf16, device=dev)
+    onar = ofull[:, 4:4 + H * HD]  # rows 8 bytes off a 16-byte boundary
+    lse2 = torch.empty_like(lse)
+    ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(onar, B, L, H, HD), lse2, HD)
+    torch.cuda.synchronize()
+    assert torch.equal(onar, o) and torch.equal(lse, lse2)
+    assert bool((ofull[:, :4] == 5.0).all()) and bool((ofull[:, 4 + H * HD:] == 5.0).all())
+    obad = torch.empty(B * L, H * HD + 8, dtype=bf16, device=dev)[:, 2:2 + H * HD]  # 4 bytes off: refused
     with pytest.raises(RuntimeError):
         ops.attn_fp8_fwd(q8, k8, v8, deq, ops.heads_view(obad, B, L, H, HD), lse, HD)
     do = (torch.randn(B * L, H * HD, generator=torch.Generator().manual_seed(3)) * 0.02).to(bf16).to(dev)
@@ -265,17 +274,17 @@ def test_attn_fp8_row_alignment_contract(ops):
                                deq, B, H, L, HD)
     out = {}
     for name, off, wid in (("wide", 0, HDP), ("narrow", 4, 100)):
-        dq = torch.empty(B, H, L, HDP, dtype=bf16, device=dev)
-        kv = [torch.full((B, H, L, wid), 3.0, dtype=bf16, device=dev) for _ in range(2)]
-        ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dq[..., :HD], kv[0][..., off:off + HD], kv[1][..., off:off + HD], HD)
+        bufs = [torch.full((B, H, L, wid), 3.0, dtype=bf16, device=dev) for _ in range(3)]
+        ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, *[t[..., off:off + HD] for t in bufs], HD)
         torch.cuda.synchronize()
-        out[name] = [t[..., off:off + HD].clone() for t in kv]
+        out[name] = [t[..., off:off + HD].clone() for t in bufs]
         if off:
-            assert all(bool((t[..., :off] == 3.0).all()) and bool((t[..., off + HD:] == 3.0).all()) for t in kv)
-    assert torch.equal(out["wide"][0], out["narrow"][0]) and torch.equal(out["wide"][1], out["narrow"][1])
+            assert all(bool((t[..., :off] == 3.0).all()) and bool((t[..., off + HD:] == 3.0).all()) for t in bufs)
+    for a, b in zip(out["wide"], out["narrow"]):
+        assert torch.equal(a, b)
     with pytest.raises(RuntimeError):
-        dqbad = torch.empty(B, H, L, 100, dtype=bf16, device=dev)[..., 4:4 + HD]
-        ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dqbad, kv[0][..., :HD], kv[1][..., :HD], HD)
+        dqbad = torch.empty(B, H, L, 100, dtype=bf16, device=dev)[..., 2:2 + HD]
+        ops.attn_fp8_bwd(q8, k8, v8, doq, stats, deq, dqbad, bufs[1][..., :HD], bufs[2][..., :HD], HD)
 
 
 @pytest.mark.parametrize("L,Lk", [(300, 300), (700, 300), (8208, 8208)],

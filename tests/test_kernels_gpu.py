@@ -789,3 +789,45 @@ def test_gemm_nn_dgelu_with_fused_bias_gradient(ops, tile):
     O.gelu_erf(p).backward(dy.float() @ w.float())
     close("dgelu+colsum.dx", dx, p.grad, 5e-3)
     close("dgelu+colsum.cs", cs - 0.5, dx.float().sum(0), 2e-3)   # sums of the bf16-rounded result
+
+
+@pytest.mark.parametrize("N", [1152, 384, 1096, 72])
+def test_gemm_narrow_last_tile_column_is_bit_identical(ops, N, monkeypatch):
+    """round 5: on the 256^2 kernel a last tile column that holds at most 128 columns runs the 256 x 128 body (wave tile
+    128 x 32, B staged as one half-tile, 32 MFMAs per wave and K tile).  Same products in the same k order: every fused
+    epilogue must give the bits of the full-width body (VDS_GEMM_NARROW=0), and the reference values."""
+    B, L, K = 3, 1500, 328  # 4500 rows = 17.6 row tiles, K = 5.1 K tiles
+    M = B * L
+    x, w, b = gen(M, K, seed=41), gen(N, K, seed=42, scale=0.05), gen(N, seed=43, scale=0.3)
+    res, mod = gen(M, N, seed=44), gen(B, 3 * N, seed=45, dtype=f32)
+    dy, w2, pre = gen(M, K, seed=46), gen(K, N, seed=47, scale=0.05), gen(M, N, seed=48)
+
+    def run():
+        out = {}
+        out["store"] = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
+        out["pre"], out["act"] = ops.linear_fwd_gelu(x.cuda(), w.cuda(), b.cuda())
+        out["y"], out["xn"] = ops.linear_fwd_gate_res(x.cuda(), w.cuda(), b.cuda(), mod.cuda(), 2 * N, res.cuda(), L)
+        out["nn"] = ops.linear_dgrad(dy.cuda(), w2.cuda())
+        cs = torch.zeros(N, dtype=f32, device="cuda")
+        out["dgelu"] = ops.linear_dgrad(dy.cuda(), w2.cuda(), pre.cuda(), colsum=cs)
+        out["cs"] = cs
+        torch.cuda.synchronize()
+        return out
+
+    ops.gemm_force_tile(256)
+    try:
+        got = run()
+        monkeypatch.setenv("VDS_GEMM_NARROW", "0")
+        ref = run()
+    finally:
+        ops.gemm_force_tile(0)
+    for k in got:
+        if k == "cs":  # fp32 atomics across workgroups: order-dependent in the last bits
+            close("narrow.cs", got[k], ref[k], 1e-5)
+        else:
+            assert torch.equal(got[k], ref[k]), k
+    yr = x.float() @ w.float().t() + b.float()
+    close("narrow.store", got["store"], yr, 4e-3)
+    close("narrow.act", got["act"], O.gelu_erf(yr), 5e-3)
+    close("narrow.xn", got["xn"], res.float() + yr * mod[:, 2 * N:].repeat_interleave(L, dim=0), 4e-3)
+    close("narrow.nn", got["nn"], dy.float() @ w2.float(), 4e-3)

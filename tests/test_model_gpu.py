@@ -982,3 +982,74 @@ def test_per_gpu_batch_above_16(vds):
     for k, p in m.named_parameters():
         if Pg[k].grad is not None and not k.endswith("lambda_param") and float(Pg[k].grad.abs().max()) > 0:
             assert cosine(p.grad, Pg[k].grad) >= GRAD_COS and rel(p.grad, Pg[k].grad) <= GRAD_REL, k
+
+
+def test_fp8_weight_history_follows_weights_replaced_in_process(vds, monkeypatch):
+    """the seven block weights are quantised with the amax of the PREVIOUS step.  Weights replaced in
+    process must not be clipped at the old amax.  (a) load_state_dict of a checkpoint with 10x larger block weights into
+    an armed model: its next step equals the step of a fresh model given the same weights (which measures every amax
+    itself).  (b) an in-place write through the parameters (an EMA swap): the next TRAINING step measures the weights'
+    own amax again (7 absmax passes per block), also when an evaluation forward ran in between, and the step after it
+    is back on the history."""
+    from video_diffusion_speedrun_amd import ops
+    cfg = O.DiTConfig(in_channels=16, hidden_size=144, depth=2, num_heads=2, cross_attn_input_size=64,
+                      residual_v=True, train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=61, randomize_zero_init=True, init_std_factor=1.0)
+    big = {k: (w * 10.0 if (k.startswith("blocks.") and k.endswith("weight") and w.dim() == 2) else w.clone())
+           for k, w in P.items()}
+    g = torch.Generator().manual_seed(62)
+    lat = (2, 16, 4, 8, 8)
+    x = torch.randn(*lat, generator=g).to(bf16).cuda()
+    ctx = torch.randn(2, 16, 64, generator=g).to(bf16).cuda()
+    t = torch.tensor([0.3, 0.8]).to(bf16).cuda()
+    v = torch.randn(*lat, generator=g).to(bf16).cuda()
+    start = (1, 2, 3)
+    calls = [0]
+    real_absmax = ops.absmax
+
+    def counting_absmax(*a, **k):
+        calls[0] += 1
+        return real_absmax(*a, **k)
+
+    monkeypatch.setattr(ops, "absmax", counting_absmax)
+
+    def step(m):
+        m.zero_grad()
+        calls[0] = 0
+        out = m(x, ctx, t, rope_start=start)
+        loss, _ = vds["train"].flow_loss(out, v)
+        loss.backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, calls[0]
+
+    fresh = build(vds, cfg, big).enable_fp8(attention=False)
+    o_ref, g_ref, _ = step(fresh)
+    # (a)
+    m = build(vds, cfg, P).enable_fp8(attention=False)
+    step(m)
+    step(m)
+    assert m._fp8_hist.ready  # delayed scaling armed on the small weights
+    m.load_state_dict(big, strict=True)
+    assert not m._fp8_hist.ready
+    o, gr, _ = step(m)
+    assert rel(o, o_ref) <= 1e-6, rel(o, o_ref)
+    for k in g_ref:
+        if float(g_ref[k].abs().max()) > 0:
+            assert rel(gr[k], g_ref[k]) <= 1e-4, (k, rel(gr[k], g_ref[k]))
+    # (b)
+    m = build(vds, cfg, P).enable_fp8(attention=False)
+    opt = vds["optim"].MuAdamW(m.get_mup_setup(1e-4, 0.0, ["patch_proj", "context_kv", "positional_embedding"])[0])
+    for _ in range(3):
+        _, _, n_steady = step(m)
+        opt.step()
+    assert m._fp8_hist.ready
+    _, _, n_steady = step(m)  # weights written by the fused optimizer only: the history is trusted
+    opt.step()
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            p.mul_(1.25)
+        m(x, ctx, t, rope_start=start)  # an evaluation forward in between must not consume the mark
+    _, _, n_moved = step(m)
+    assert n_moved == n_steady + 7 * cfg.depth, (n_steady, n_moved)
+    opt.step()
+    _, _, n_after = step(m)
+    assert n_after == n_steady, (n_steady, n_after)

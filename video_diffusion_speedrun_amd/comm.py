@@ -111,8 +111,13 @@ def destroy():
         _state.update(group=None, active=False, rank=0, world=1)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # private: resolved once, public fallback below
+
+
 def _stream() -> int:
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def all_gather(out: torch.Tensor, inp: torch.Tensor):

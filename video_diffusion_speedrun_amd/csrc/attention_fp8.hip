@@ -86,6 +86,7 @@ struct Attn8P {
   unsigned char* dqq; long dqq_ld;  // backward: e5m2 copy of dQ; null = none
   const float* e_amax_prev; float* e_amax_cur; float* e_dq_out;
   int wide_dkv;  // dK / dV rows 16-byte aligned: store_block_bf16_t's wide path
+  int wide_o, wide_dq;  // same for the bf16 O / dQ rows (store_block_t)
 };
 
 __device__ __forceinline__ int swz8(int row) { return ((row >> 1) & 3) | ((row >> 3) & 4); }
@@ -247,7 +248,7 @@ __device__ __forceinline__ void retire(float f) { asm volatile("" ::"v"(f)); }
 // All 64 lanes must call (cross-lane exchange); `valid` is uniform over the four lanes of a row.
 template <int HD, int EF, int NDB>
 __device__ __forceinline__ float store_block_t(const float (&v)[NDB][4], bf16_t* row, unsigned char* row8, bool emit8,
-                                               float alpha, int g, bool valid) {
+                                               float alpha, int g, bool valid, bool wide = true) {
   static_assert(NDB == 5 && HD >= 64 && HD <= 80, "four full 16-column blocks and one partial");
   constexpr float FMAX = EF == 0 ? 448.0f : 57344.0f;
   unsigned lo[4], hi[4], q8[4] = {0u, 0u, 0u, 0u}, tlo, thi, t8 = 0u;
@@ -268,12 +269,20 @@ __device__ __forceinline__ float store_block_t(const float (&v)[NDB][4], bf16_t*
     if (db < 4) { lo[db] = a; hi[db] = b; q8[db] = w8; }
     else { tlo = a; thi = b; t8 = w8; }
   }
+  // `wide` (wave-uniform): the bf16 rows are 16-byte aligned (strides in multiples of 8 elements, 16-byte aligned base).
+  // Otherwise (8-byte aligned rows: the contract before round 4) the bf16 words leave as 8-byte pieces, untransposed.
+  if (row && !wide && valid) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db) *reinterpret_cast<u32x2*>(row + db * 16 + 4 * g) = u32x2{lo[db], hi[db]};
+  }
   row_transpose4(lo);
   row_transpose4(hi);
   if (emit8) row_transpose4(q8);
   if (!valid) return 0.f;
   const bool tail = 4 * g < HD - 64;
-  if (row) {
+  if (row && !wide) {
+    if (tail) *reinterpret_cast<u32x2*>(row + 64 + 4 * g) = u32x2{tlo, thi};
+  } else if (row) {
     *reinterpret_cast<u32x4*>(row + 16 * g) = u32x4{lo[0], hi[0], lo[1], hi[1]};
     *reinterpret_cast<u32x4*>(row + 16 * g + 8) = u32x4{lo[2], hi[2], lo[3], hi[3]};
     if (tail) *reinterpret_cast<u32x2*>(row + 64 + 4 * g) = u32x2{tlo, thi};
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn8_fwd_kernel(Attn8P p) {
       for (int e = 0; e < 4; ++e) vals[db][e] = o[db][cb][e] * inv;
     bf16_t* orow = p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl;
     unsigned char* qrow8 = p.oq + ((long)b * p.Lq + qrow) * p.oq_ld + hh * HD;
-    e_max = fmaxf(e_max, store_block_t<HD, 0>(vals, orow, qrow8, p.oq != nullptr, e_alpha, g, valid));
+    e_max = fmaxf(e_max, store_block_t<HD, 0>(vals, orow, qrow8, p.oq != nullptr, e_alpha, g, valid, p.wide_o != 0));
     if (valid && g == 0) p.lse[head * p.Lq + qrow] = (m[cb] - P_SHIFT + __builtin_amdgcn_logf(lt)) * LN2;
   }
   if (p.oq) {
@@ -856,7 +865,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void attn8_bwd_dq_kerne
       for (int e = 0; e < 4; ++e) vals[db][e] = dq[db][cb][e] * fq;
     bf16_t* dqp = p.dq ? p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_sl : nullptr;
     unsigned char* q8p = p.dqq + ((long)b * p.Lq + qrow) * p.dqq_ld + hh * HD;
-    e_max = fmaxf(e_max, store_block_t<HD, 1>(vals, dqp, q8p, p.dqq != nullptr, e_alpha, g, qrow < p.Lq));
+    e_max = fmaxf(e_max, store_block_t<HD, 1>(vals, dqp, q8p, p.dqq != nullptr, e_alpha, g, qrow < p.Lq, p.wide_dq != 0));
   }
   if (p.dqq) {
     e_max = wave_max(e_max);
@@ -952,9 +961,10 @@ __device__ __forceinline__ void qk_scales(const float* amax_prev, int stride, in
   const float cl = LOG2E / sqrtf((float)hd);
   int e = 1;
   if (aq > 0.f) (void)frexpf(448.0f * alpha_k / (cl * aq), &e);  // x = f 2^e, f in [0.5, 1): floor(log2 x) = e - 1
-  // the kernels pass 127 - E and 127 + 3 - E as E8M0 scale bytes: E is kept in [-120, 120] (extreme amax products
-  // only; alpha_q follows E, so q merely leaves its top binade there instead of wrapping the byte)
-  e = e - 1 < -120 ? -119 : e - 1 > 120 ? 121 : e;
+  // the kernels pass 127 - E, 127 + 3 - E and (backward, bit-pattern exp2: round 4) 127 + 23 - E as E8M0 scale bytes
+  // (255 = NaN, larger values wrap): E is kept in [-104, 120] (extreme amax products only; alpha_q follows E, so q merely
+  // leaves its top binade there instead of wrapping the byte)
+  e = e - 1 < -104 ? -103 : e - 1 > 120 ? 121 : e;
   E = (float)(e - 1);
   alpha_q = cl * exp2f(E) / alpha_k;
 }
@@ -1212,13 +1222,16 @@ void set_lds(K kern, int bytes) {
 bool args_ok(const vds_attn_fp8_args* a, bool bwd) {
   if (!a || !a->q || !a->k || !a->v || !a->deq || a->B <= 0 || a->H <= 0 || a->Lq <= 0 || a->Lk <= 0) return false;
   if ((long)a->Lq * ROWB > 0x7fffffffL || (long)a->Lk * ROWB > 0x7fffffffL) return false;
+  // fp8 rows (o_q / dq_q): 16-byte stores at byte offset head * head_dim + 16 g of a row -- 8-byte aligned for odd heads
+  // (head_dim 72): base and row stride must be multiples of 8 bytes (the hardware's unaligned global stores take the rest).
+  // bf16 rows (o / dq): strides in multiples of 4 elements and an 8-byte aligned base (8-byte stores); when they are
+  // multiples of 8 elements on a 16-byte aligned base the kernels take the 16-byte row stores (wide_o / wide_dq).
   if (!bwd) {
-    if (a->o_q && (!a->e_amax_prev || !a->e_amax_cur || !a->e_dq_out || (a->o_q_ld & 3))) return false;
-    return a->o && a->lse && (a->o_sb % 8 == 0) && (a->o_sh % 8 == 0) && (a->o_sl % 8 == 0) && ((uintptr_t)a->o % 16 == 0);
+    if (a->o_q && (!a->e_amax_prev || !a->e_amax_cur || !a->e_dq_out || (a->o_q_ld & 7) || ((uintptr_t)a->o_q & 7))) return false;
+    return a->o && a->lse && (a->o_sb % 4 == 0) && (a->o_sh % 4 == 0) && (a->o_sl % 4 == 0) && ((uintptr_t)a->o % 8 == 0);
   }
-  if (a->dq_q && (!a->e_amax_prev || !a->e_amax_cur || !a->e_dq_out || (a->dq_q_ld & 3))) return false;
-  // (dq: 16-byte stores -- strides in multiples of 8 elements, base 16-byte aligned)
-  if (a->dq && ((a->dq_sl % 8) || (a->dq_sh % 8) || (a->dq_sb % 8) || ((uintptr_t)a->dq % 16))) return false;
+  if (a->dq_q && (!a->e_amax_prev || !a->e_amax_cur || !a->e_dq_out || (a->dq_q_ld & 7) || ((uintptr_t)a->dq_q & 7))) return false;
+  if (a->dq && ((a->dq_sl % 4) || (a->dq_sh % 4) || (a->dq_sb % 4) || ((uintptr_t)a->dq % 8))) return false;
   return a->d_o && a->stats && (a->dq || a->dq_q) && a->dk && a->dv && (a->dk_sl % 4 == 0) &&
          (a->dv_sl % 4 == 0) && (a->dk_sh % 4 == 0) && (a->dv_sh % 4 == 0) && (a->dk_sb % 4 == 0) && (a->dv_sb % 4 == 0);
 }
@@ -1245,6 +1258,8 @@ Attn8P to_p(const vds_attn_fp8_args* a) {
     return base && ((uintptr_t)base % 16 == 0) && (sb % 8 == 0) && (sh % 8 == 0) && (sl % 8 == 0);
   };
   p.wide_dkv = rows16(p.dk, p.dk_sb, p.dk_sh, p.dk_sl) && rows16(p.dv, p.dv_sb, p.dv_sh, p.dv_sl);
+  p.wide_o = rows16(p.o, p.o_sb, p.o_sh, p.o_sl);
+  p.wide_dq = rows16(p.dq, p.dq_sb, p.dq_sh, p.dq_sl);
   return p;
 }
 

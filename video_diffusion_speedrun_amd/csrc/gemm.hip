@@ -54,6 +54,7 @@ struct GemmP {
   int tiles_m, tiles_n;
   int group_m;
   int joint_xcd;   // split-K launches: XCD-aware order over the joint (split, tile) list
+  int narrow;      // 256^2 kernel: the last tile column holds <= 128 columns and runs the 256 x 128 body (round 5)
   const float* sa; const float* sb;  // fp8 path: per-tensor dequantisation factors (device), else unused
   double prof_k;                      // contraction length in elements (profiler flop count)
   // fp8 path, optional: the epilogue also emits its result (gelu output / gelu' product) as fp8 (vds_fp8_out)
@@ -653,6 +654,14 @@ template <int WN> struct Geo;
 template <> struct Geo<256> {
   static constexpr int BN = 256, WCOLS = 64, NJ = 4, A0 = 0, A1 = HALF, B0 = 2 * HALF, B1 = 3 * HALF, BUF = 4 * HALF;
 };
+// WN = 128 (round 5): the body of a LAST tile column that holds at most 128 columns (N = 1152 = 4.5 x 256: the fifth column
+// of every DiT-XL N = 1152 linear).  A wave owns 128 x 32 outputs; B is staged as B0 only (the 128 columns, wave column w
+// = columns 32 w .. 32 w + 31), a K tile is two phases of 16 MFMAs (A0 B0 | A1, B0 from registers): 6 instead of 8 DMA pieces
+// and 32 instead of 64 MFMAs per wave and K tile.  Not a launch geometry: big::gemm_kernel<.., 256> branches into it per
+// workgroup (GemmP::narrow), the grid and the tile order stay those of the 256-wide tiling.
+template <> struct Geo<128> {
+  static constexpr int BN = 128, WCOLS = 32, NJ = 2, A0 = 0, A1 = HALF, B0 = 2 * HALF, B1 = 3 * HALF, BUF = 4 * HALF;
+};
 template <> struct Geo<192> {
   static constexpr int BN = 192, WCOLS = 48, NJ = 3, A0 = 0, A1 = HALF, B0 = 2 * HALF, B1 = 3 * HALF, BUF = 3 * HALF + HALF / 2;
 };
@@ -767,43 +776,21 @@ __device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigne
 #ifndef VDS_GEMM_NPH
 #define VDS_GEMM_NPH 2  // phases per K tile of the 256-wide tiling (4: the loop of rounds 1-3, for A/B builds)
 #endif
-template <int LAYOUT, int EPI, int FMT = 0, int WN = 256, int NPH = VDS_GEMM_NPH>
-__global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(FMT == 0 || (FMT != 3 && LAYOUT == VDS_NT) || (FMT == 3 && LAYOUT == VDS_TN && WN == 256),
+// One output tile: rows m0 .. m0 + 255, columns n0 .. n0 + BN - 1, K tiles kt_begin .. kt_end - 1.
+template <int LAYOUT, int EPI, int FMT, int WN, int NPH>
+__device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int m0, const int n0, const int kt_begin,
+                                          const int kt_end) {
+  static_assert(FMT == 0 || (FMT != 3 && LAYOUT == VDS_NT) || (FMT == 3 && LAYOUT == VDS_TN && WN != 192),
                 "fp8 operands: k-contiguous (FMT 1 / 2, NT) or both k-major (FMT 3, TN: the weight gradient)");
   using G = Geo<WN>;
-  constexpr int BN = G::BN, WCOLS = G::WCOLS, NJ = G::NJ, BUF = G::BUF;
+  constexpr int WCOLS = G::WCOLS, NJ = G::NJ, BUF = G::BUF;
   constexpr int SLOT_A0 = G::A0, SLOT_A1 = G::A1, SLOT_B0 = G::B0, SLOT_B1 = G::B1;
-  constexpr int NPB1 = WN == 256 ? 2 : 1;  // 1-KiB pieces per wave of the B1 half / quarter tile
+  constexpr int NPB1 = WN == 192 ? 1 : 2;  // 1-KiB pieces per wave of the B1 half / quarter tile
   constexpr bool A_KM = (LAYOUT == VDS_TN);
   constexpr bool B_KM = (LAYOUT != VDS_NT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-
-  // ---- tile id: XCD-aware + grouped order (as the 128^2 kernel) ---------------------------
-  const int nwg = p.tiles_m * p.tiles_n;
-  int pid = blockIdx.x;
-  {
-    int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
-    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int group = p.group_m * p.tiles_n;
-  const int first_m = (pid / group) * p.group_m;
-  const int gsz = min(p.tiles_m - first_m, p.group_m);
-  const int tile_m = first_m + (pid % group) % gsz;
-  const int tile_n = (pid % group) / gsz;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int kt_total = (p.K + BK - 1) / BK;
-  int kt_begin = 0, kt_end = kt_total;
-  if (p.split_k > 1) {
-    int per = (kt_total + p.split_k - 1) / p.split_k;
-    kt_begin = blockIdx.y * per;
-    kt_end = min(kt_total, kt_begin + per);
-    if (kt_begin >= kt_end) return;
-  }
   const srd_t ra = make_srd(p.A, p.a_bytes);
   const srd_t rb = make_srd(p.B, p.b_bytes);
   constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
@@ -821,13 +808,19 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   if constexpr (FMT == 3) {  // (p.lda / p.ldb count 2-byte units, origins are byte columns)
     half_offsets_km8<64, 128, 0>(va[0], ca[0], wave, lane, 2 * p.lda, m0);
     half_offsets_km8<64, 128, 64>(va[1], ca[1], wave, lane, 2 * p.lda, m0);
-    half_offsets_km8<32, 64, 0>(vb0, cb0, wave, lane, 2 * p.ldb, n0);
-    half_offsets_km8<32, 64, 32>(vb1, cb1, wave, lane, 2 * p.ldb, n0);
+    if constexpr (WN == 128) {
+      half_offsets_km8<32, 32, 0>(vb0, cb0, wave, lane, 2 * p.ldb, n0);
+    } else {
+      half_offsets_km8<32, 64, 0>(vb0, cb0, wave, lane, 2 * p.ldb, n0);
+      half_offsets_km8<32, 64, 32>(vb1, cb1, wave, lane, 2 * p.ldb, n0);
+    }
   } else {
   half_offsets<A_KM, 64, 128, 0, 2>(va[0], ca[0], wave, lane, p.lda, m0);
   half_offsets<A_KM, 64, 128, 64, 2>(va[1], ca[1], wave, lane, p.lda, m0);
   }
   if constexpr (FMT == 3) {
+  } else if constexpr (WN == 128) {
+    half_offsets<B_KM, 32, 32, 0, 2>(vb0, cb0, wave, lane, p.ldb, n0);
   } else if constexpr (WN == 256) {
     half_offsets<B_KM, 32, 64, 0, 2>(vb0, cb0, wave, lane, p.ldb, n0);
     half_offsets<B_KM, 32, 64, 32, 2>(vb1, cb1, wave, lane, p.ldb, n0);
@@ -847,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     if (which == 0) issue_half<A_KM>(ra, buf + SLOT_A0, va[0], ca[0], (unsigned)T * a_step, krem, wave);
     else if (which == 3) issue_half<A_KM>(ra, buf + SLOT_A1, va[1], ca[1], (unsigned)T * a_step, krem, wave);
     else if (which == 1) issue_half<B_KM>(rb, buf + SLOT_B0, vb0, cb0, (unsigned)T * b_step, krem, wave);
-    else issue_half<B_KM, NPB1>(rb, buf + SLOT_B1, vb1, cb1, (unsigned)T * b_step, krem, wave);
+    else if constexpr (WN != 128) issue_half<B_KM, NPB1>(rb, buf + SLOT_B1, vb1, cb1, (unsigned)T * b_step, krem, wave);
   };
 
   f32x4 acc[8][NJ];
@@ -860,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
       // vmcnt wait + barrier, onto the critical path of every tile (the wait hides them for free): fp8 NT + dgrad per
       // block 4.13 -> 4.03 ms, bf16 unchanged.  (Not in the 192-wide tiling nor in the TN kernels: there the pin costs
       // registers -- 85-104 spilled VGPRs, 7.9 -> 12.8 ms per block resp. the fp8 weight-gradient GEMMs 2.5x slower.)
-      if constexpr (WN == 256 && LAYOUT != VDS_TN) asm volatile("" : "+v"(acc[i][j]));
+      if constexpr (WN != 192 && LAYOUT != VDS_TN) asm volatile("" : "+v"(acc[i][j]));
     }
 
   constexpr int KS = FMT == 0 ? 2 : 1;  // MFMA k-steps per K tile
@@ -947,6 +940,51 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     __builtin_amdgcn_s_setprio(1);
     quad(1, 1, fb1);
     quad(1, 0, fb0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int T = kt_begin; T < kt_end; T += 2) {
+    k_tile(T, std::integral_constant<int, 0>{});
+    if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
+  }
+  } else if constexpr (WN == 128) {
+  // ---- narrow last tile column: A0 B0 | A1 per K tile (6 pieces per wave), two phases of 16 MFMAs; the waits leave 6
+  // pieces (three half-tiles) in flight; retire / re-stage distances as in the two-phase loop above
+  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 3, 0);
+  issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1);
+  VDS_WAIT_VM(6);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
+  frag_t fa[4][KS], fb0[2][KS];
+  auto quad = [&](int qa) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[qa * 4 + i][j] = mma(fa[i][ks], fb0[j][ks], acc[qa * 4 + i][j]);
+  };
+  auto k_tile = [&](int T, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    const char* buf = ring + par * BUF;
+    read_a4(buf + SLOT_A0, fa);
+    read_b2(buf + SLOT_B0, fb0);
+    issue(T + 1, 3, par ^ 1);
+    VDS_WAIT_LGKM0();
+    VDS_WAIT_VM(6);  // A1(T) landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    quad(0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    read_a4(buf + SLOT_A1, fa);
+    issue(T + 2, 0, par);
+    issue(T + 2, 1, par);
+    VDS_WAIT_LGKM0();
+    VDS_WAIT_VM(6);  // A0, B0 of tile T+1 landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    quad(1);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
   };
@@ -1215,6 +1253,40 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
       }
     }
   }
+}
+
+template <int LAYOUT, int EPI, int FMT = 0, int WN = 256, int NPH = VDS_GEMM_NPH>
+__global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // ---- tile id: XCD-aware + grouped order (as the 128^2 kernel) ---------------------------
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int group = p.group_m * p.tiles_n;
+  const int first_m = (pid / group) * p.group_m;
+  const int gsz = min(p.tiles_m - first_m, p.group_m);
+  const int tile_m = first_m + (pid % group) % gsz;
+  const int tile_n = (pid % group) / gsz;
+  const int m0 = tile_m * BM, n0 = tile_n * Geo<WN>::BN;
+
+  const int kt_total = (p.K + BK - 1) / BK;
+  int kt_begin = 0, kt_end = kt_total;
+  if (p.split_k > 1) {
+    int per = (kt_total + p.split_k - 1) / p.split_k;
+    kt_begin = blockIdx.y * per;
+    kt_end = min(kt_total, kt_begin + per);
+    if (kt_begin >= kt_end) return;
+  }
+  if constexpr (WN == 256 && NPH == 2) {
+    if (p.narrow && tile_n == p.tiles_n - 1) {
+      gemm_tile<LAYOUT, EPI, FMT, 128, NPH>(p, smem, m0, n0, kt_begin, kt_end);
+      return;
+    }
+  }
+  gemm_tile<LAYOUT, EPI, FMT, WN, NPH>(p, smem, m0, n0, kt_begin, kt_end);
 }
 
 template <int LAYOUT, int EPI, int FMT = 0, int WN = 256, int NPH = VDS_GEMM_NPH>
@@ -1494,6 +1566,15 @@ static bool prefer_w192(long M, long N) {
   return c192 < c256;
 }
 
+// 256-wide tiling: the last tile column runs the 256 x 128 body when it holds at most 128 columns (VDS_GEMM_NARROW=0: off,
+// read per call for same-process A/B)
+static int narrow_last_column(long N) {
+  const char* e = getenv("VDS_GEMM_NARROW");
+  if (e && atoi(e) == 0) return 0;
+  const long rem = N % 256;
+  return rem > 0 && rem <= 128;
+}
+
 extern "C" int vds_gemm_force_tile(int32_t tile) {
   const int prev = g_force_tile < 0 ? 0 : g_force_tile;
   if (tile != 0 && tile != 128 && tile != 256 && tile != 2 && tile != 192) return VDS_ERR_ARG;
@@ -1524,6 +1605,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   p.prof_k = a->K;
   p.e_q = p.e_qt = nullptr; p.e_ldq = p.e_ldqt = 0;
   p.e_amax_in = nullptr; p.e_amax_out = p.e_dq_out = p.e_colsum = nullptr; p.e_fmt = 0;
+  p.narrow = 0;
   if (a->colsum && !(a->epilogue == VDS_EPI_DGELU && a->C)) return VDS_ERR_ARG;
   p.tiles_m = cdiv(a->M, BM);
   p.tiles_n = cdiv(a->N, BN);
@@ -1701,6 +1783,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   if (use_big) {
     p.tiles_m = tm;
     p.tiles_n = tn;
+    p.narrow = narrow_last_column(a->N);
     p.e_colsum = a->colsum;  // DGELU only (checked above): column sums of the result in the epilogue
 #define GOB(L, E) if (a->layout == L && a->epilogue == E) return big::launch<L, E>(p, s);
     GOB(VDS_NT, VDS_EPI_STORE)
@@ -1760,6 +1843,7 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   p.b_bytes = (unsigned)bbytes;
   p.group_m = 4;
   p.joint_xcd = 0;
+  p.narrow = narrow_last_column(a->N);
   p.e_q = p.e_qt = nullptr; p.e_ldq = p.e_ldqt = 0;
   p.e_amax_in = nullptr; p.e_amax_out = p.e_dq_out = p.e_colsum = nullptr; p.e_fmt = 0;
   if (emit) {

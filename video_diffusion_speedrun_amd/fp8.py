@@ -67,18 +67,22 @@ class Q:
     __slots__ = ("q", "t", "s", "rows", "cols")
 
     def __init__(self, x: torch.Tensor = None, fmt: int = 0, rowmajor: bool = True, transposed: bool = False,
-                 hist: "AmaxHistory" = None, row: int = 0, weight: bool = False):
+                 hist: "AmaxHistory" = None, row: int = 0, weight: bool = False, remeasure: bool = False):
         """hist / row: this tensor's slot in the delayed-scaling table.  With a history the single quantisation pass
         scales by the previous step's amax and records the current one; without (first step, weights, inference)
         the tensor's own amax is computed first (and recorded, so that the next step has a history).
         transposed: the tensor is also a weight-gradient operand; with TN (default) that needs the row-major copy
-        only, except for weights (`weight=True`), whose transposed copy feeds the input-gradient GEMM."""
+        only, except for weights (`weight=True`), whose transposed copy feeds the input-gradient GEMM.
+        remeasure: ignore the history for this tensor this time (its own amax, two passes) but still record: weights
+        whose bf16 compute copy had to be re-cast, i.e. that were written by something else than the fused optimizer
+        since the last step (load_state_dict, an EMA swap, a foreign optimizer) -- their recorded amax describes the old
+        values and a larger tensor would be clipped at it."""
         if x is None:
             return
         if TN and transposed and not weight:
             rowmajor, transposed = True, False
         self.rows, self.cols = x.shape
-        if hist is not None and hist.ready:
+        if hist is not None and hist.ready and not remeasure:
             self.q, self.t, self.s = ops.quant_fp8(x, fmt, hist.prev(row), rowmajor, transposed, amax_out=hist.cur(row))
             return
         amax = ops.absmax(x)
@@ -152,6 +156,18 @@ class AmaxHistory:
             if self._bwd_seen:
                 self.ready = True
         self._fwd_seen, self._bwd_seen = True, False
+
+    def reset(self):
+        """Forget every recorded amax and disarm delayed scaling: the next training step quantises each tensor by its
+        OWN amax again (two passes), and delayed scaling re-arms after that step's backward.  Called when parameter
+        memory is replaced wholesale (DiT.load_state_dict / invalidate_compute_copy): since round 4 the weights are
+        scaled by the previous step's amax too, and a checkpoint whose weights are larger than the ones the history was
+        recorded on would otherwise be saturated at the old amax for one optimizer step, silently."""
+        self.tab[:, 1].zero_()  # (the previous-step column is kept: a captured HIP graph may still read it)
+        if self.part_tab is not None:
+            self.part_tab.zero_()
+        self.ready = False
+        self._fwd_seen = self._bwd_seen = False
 
     def scratch(self, n: int):
         """n zeroed floats for a producer's amax record that nobody reads (no-grad forwards)"""

@@ -327,6 +327,7 @@ class DiTBlock(nn.Module):
         Wo = lambda n: G.w(pre + n) if G.has(pre + n) else None
         dev = X.device
         R0 = F8.ROWS * i
+        moved = bool(getattr(G, "recast", True))  # fp8: this group's weights changed outside the fused optimizer
         if mod is None:  # (DiT.forward computes the modulation of all blocks in one batched launch and passes it in)
             mod = ops.small_linear_fwd(cvec, W("adaLN_modulation.1.weight"), W("adaLN_modulation.1.bias"), 1)
         # --- self attention (model.py:122-139)
@@ -346,7 +347,7 @@ class DiTBlock(nn.Module):
         if f8:
             if not pemit:
                 q_xn1 = F8.Q(xn1, F8.E4M3, True, save, hist, F8.ROWS * i + 2)
-            q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 0, weight=True)
+            q_wqkv = F8.Q(W("qkv.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 0, weight=True, remeasure=moved)
             qkv = torch.empty(B * L, 3 * D, dtype=bf16, device=dev)
             F8.fwd(q_xn1, q_wqkv, qkv, Wo("qkv.bias"))
         else:
@@ -383,7 +384,7 @@ class DiTBlock(nn.Module):
         if f8l:
             q_attn = (F8.Q.from_rowmajor(*e_attn, save) if e_attn is not None else
                       F8.Q(attn, F8.E4M3, True, save, hist, R0 + F8.ROW_ATTN))
-            q_wap = F8.Q(W("attn_proj.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 1, weight=True)
+            q_wap = F8.Q(W("attn_proj.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 1, weight=True, remeasure=moved)
             y_sa, X1 = F8.fwd_gate_res(q_attn, q_wap, None, mod, 2 * D, X, L)
         else:
             y_sa, X1 = ops.linear_fwd_gate_res(attn, W("attn_proj.weight"), None, mod, 2 * D, X, L)
@@ -401,10 +402,10 @@ class DiTBlock(nn.Module):
             if f8c:
                 if q_xn2 is None:
                     q_xn2 = F8.Q(xn2, F8.E4M3, True, save, hist, R0 + F8.ROW_XN2)
-                q_wqc = F8.Q(W("q_cross.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 2, weight=True)
+                q_wqc = F8.Q(W("q_cross.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 2, weight=True, remeasure=moved)
                 qc = torch.empty(B * L, D, dtype=bf16, device=dev)
                 F8.fwd(q_xn2, q_wqc, qc, Wo("q_cross.bias"))
-                q_wkv = F8.Q(W("context_kv.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 3, weight=True)
+                q_wkv = F8.Q(W("context_kv.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 3, weight=True, remeasure=moved)
                 ckv = torch.empty(B * Lc, 2 * D, dtype=bf16, device=dev)
                 F8.fwd(q_ctx, q_wkv, ckv, Wo("context_kv.bias"))
             else:
@@ -434,7 +435,7 @@ class DiTBlock(nn.Module):
             if f8c:
                 q_catt = (F8.Q.from_rowmajor(*e_catt, save) if e_catt is not None else
                           F8.Q(catt, F8.E4M3, True, save, hist, R0 + F8.ROW_CATT))
-                q_wcp = F8.Q(W("cross_proj.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 4, weight=True)
+                q_wcp = F8.Q(W("cross_proj.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 4, weight=True, remeasure=moved)
                 y_ca, X2 = F8.fwd_gate_res(q_catt, q_wcp, None, mod, 5 * D, X1, L)
             else:
                 y_ca, X2 = ops.linear_fwd_gate_res(catt, W("cross_proj.weight"), None, mod, 5 * D, X1, L)
@@ -451,15 +452,17 @@ class DiTBlock(nn.Module):
         if f8:
             if not pemit:
                 q_xn3 = F8.Q(xn3, F8.E4M3, True, save, hist, F8.ROWS * i + 3)
-            q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 5, weight=True)
+            q_w1 = F8.Q(W("mlp.0.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 5, weight=True, remeasure=moved)
             if emit:  # gelu(fc1) leaves the GEMM as fp8
                 hpre, q_hact = F8.fwd_gelu_emit(q_xn3, q_w1, W("mlp.0.bias"), hist.prev(F8.ROWS * i), hist.cur(F8.ROWS * i), save)
                 hact = None
             else:
                 hpre, hact = F8.fwd_gelu(q_xn3, q_w1, W("mlp.0.bias"))
                 q_hact = F8.Q(hact, F8.E4M3, True, save, hist, F8.ROWS * i)
-            q_w2 = F8.Q(W("mlp.2.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 6, weight=True)
+            q_w2 = F8.Q(W("mlp.2.weight"), F8.E4M3, True, save, hist, R0 + F8.ROW_W + 6, weight=True, remeasure=moved)
             y_mlp, X3 = F8.fwd_gate_res(q_hact, q_w2, W("mlp.2.bias"), mod, 8 * D, X2, L)
+            if hist is not None:
+                G.recast = False  # every weight of the block has recorded its current amax
         else:
             hpre, hact = ops.linear_fwd_gelu(xn3, W("mlp.0.weight"), W("mlp.0.bias"))
             y_mlp, X3 = ops.linear_fwd_gate_res(hact, W("mlp.2.weight"), W("mlp.2.bias"), mod, 8 * D, X2, L)
@@ -1037,6 +1040,10 @@ class DiT(nn.Module):
         writing parameter memory some other way (`p.data.xxx_()`, raw pointers, custom kernels)."""
         for g in self._groups or []:
             g.invalidate_shadow()
+        # fp8: the weights' delayed-scaling history describes the OLD values (a larger checkpoint would be clipped at the
+        # old amax for a step): re-measure everything on the next step
+        if getattr(self, "_fp8_hist", None) is not None:
+            self._fp8_hist.reset()
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         r = super().load_state_dict(state_dict, strict=strict, assign=assign)

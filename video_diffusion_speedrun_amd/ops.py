@@ -19,11 +19,17 @@ bf16 = torch.bfloat16
 f32 = torch.float32
 
 
+# private torch entry point (resolved once; a torch version without it falls back to the public, slower form)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
     """raw handle of torch's current HIP stream.  (`torch.cuda.current_stream().cuda_stream` builds a Stream object per
     call: 2.65 us against 0.3 us for this form -- a third of the host cost of a small launch, and launch-bound
     workloads (C1: ~1600 launches of a few microseconds per step) are host-bound; tools/bench_host_overhead.py)"""
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:

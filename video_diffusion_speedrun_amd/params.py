@@ -162,6 +162,9 @@ class FlatGroup:
             return False
         cast_fn(self.master, self.shadow)
         self.mark_shadow_fresh()
+        # the parameters were written by something else than the fused optimizer: the fp8 path re-measures the weights'
+        # amax instead of trusting its history (sticky: cleared by the training forward that did so, model.py)
+        self.recast = True
         return True
 
     # ---- per-step operations ------------------------------------------------------------
