@@ -67,7 +67,7 @@ import torch.distributed as dist
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_JSON = "r04_traffic.json"  # committed rocprofv3 PMC pass of the dominant kernel (tools/collect_profiles.sh)
+TRAFFIC_JSON = "r05_traffic.json"  # committed rocprofv3 PMC passes over whole train steps, per kernel class (tools/collect_profiles.sh)
 FP8_CLASSES = ("gemm_fp8", "attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq")
 # What a dense bf16 MFMA stream reaches on THIS chip on random data: a bare v_mfma_f32_16x16x32_bf16 loop, all operands in
 # registers, no LDS / memory traffic, runs 1.79-1.84 PFLOP/s at the board's power limit (tools/mfma_power.hip,
@@ -208,6 +208,38 @@ def cpu_baseline_c1():
             "sample": "the whole DiT-S model: 3 steps of fwd+bwd+AdamW per dtype, first one dropped", **out}
 
 
+def cpu_baseline_c2():
+    """BASELINE.md section 4 / SURVEY 8(d): config C2 (DiT-B/2, latents [16,16,32,32], pt = 1 -> 4096+16 tokens, context
+    [512,4096]), ONE measured step on the host cores: the whole 12-block model, B=1, fp32, forward + backward + AdamW
+    (4.78 TFLOP; no warm-up step: one step is the bounded sample)."""
+    from oracle import dit_oracle as O
+    n_threads = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(n_threads)
+    kw, lat = WORKLOADS["c2"][0], WORKLOADS["c2"][1]
+    cfg = O.DiTConfig(in_channels=16, patch_size=2, time_patch_size=kw["time_patch_size"], hidden_size=kw["hidden_size"],
+                      depth=kw["depth"], num_heads=kw["num_heads"], cross_attn_input_size=CC, residual_v=True,
+                      train_bias_and_rms=False)
+    P = O.init_params(cfg, seed=0, randomize_zero_init=True, init_std_factor=0.1)
+    table = O.mup_settings(O.param_shapes(cfg), 1e-4, 0.1, ["patch_proj", "context_kv", "positional_embedding"])
+    g = torch.Generator().manual_seed(1)
+    x, ctx = torch.randn(1, *lat, generator=g), torch.randn(1, LC, CC, generator=g)
+    z, n = torch.randn(1, generator=g), torch.randn(1, *lat, generator=g)
+    Pg = {k: w.clone().requires_grad_(True) for k, w in P.items()}
+    t0 = time.perf_counter()
+    loss = O.train_forward(Pg, cfg, x, ctx, z, n, (0, 0, 0), compute_dtype=torch.float32)
+    loss.backward()
+    with torch.no_grad():
+        for k, w in Pg.items():
+            if w.grad is not None:
+                O.adamw_step(w, w.grad, torch.zeros_like(w), torch.zeros_like(w), 1, table[k]["lr"], table[k]["wd"])
+    dt = time.perf_counter() - t0
+    fl = step_flops(kw, lat)
+    return {"workload": WORKLOADS["c2"][3] + ", B=1 (BASELINE.json configs[1])", "cores": n_threads, "kind": "port",
+            "sample": "the whole DiT-B model, ONE measured step (fwd+bwd+AdamW), fp32, no warm-up",
+            "samples_per_s": round(1.0 / dt, 5), "ms_per_step": round(dt * 1e3, 1), "TFLOP/s": round(fl / dt / 1e12, 3),
+            "loss": round(float(loss.detach()), 5)}
+
+
 def measure(one_step, steps, warmup, world, kw, args, fs=None, graphed=None):
     """W untimed warm-up steps (the last one ranks the kernel classes by time with HIP events around every launch),
     then exactly K steps between barrier + synchronize with events around the dominant class only.
@@ -273,19 +305,23 @@ def roofline_of(dominant, dom, workload, B):
     # separate --pmc passes), so the figure is the committed pass of this kernel at this workload and batch,
     # stamped with the commit and kernel symbol it was taken on; null when there is none
     traffic, traffic_src = None, None
-    for tjname in (TRAFFIC_JSON, "r03_traffic.json"):
+    for tjname in (TRAFFIC_JSON, "r04_traffic.json"):
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", tjname)))
-            # (the file holds the self-attention kernels at the C3b / C5 shape, bf16 and fp8)
-            if workload in (tj["workload"], "c5") and tj["per_gpu_batch"] == B and dominant in tj["kernels"]:
-                k = tj["kernels"][dominant]
+            # round 5: one section per workload ("c3b", "c5"), every kernel class of the step, averaged over the class's
+            # launches of a profiled train step; round 4's file: the self-attention kernels only, one section
+            sec = tj["workloads"][workload] if "workloads" in tj else (tj if workload in (tj["workload"], "c5") else None)
+            if sec is not None and sec["per_gpu_batch"] == B and dominant in sec["kernels"]:
+                k = sec["kernels"][dominant]
                 traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
-                traffic_src = f"profiles/{tjname}: rocprofv3 PMC pass of {k['symbol']} at commit {tj['commit']}"
+                traffic_src = (f"profiles/{tjname}: rocprofv3 PMC passes ({k.get('launches_averaged', 1)} launches of "
+                               f"{k['symbol']}) at commit {tj['commit']}")
                 break
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, TypeError):
             pass
     out = {"bound": "mfma" if mfma_bound else "hbm", "achieved": ach, "peak": peak, "unit": unit,
            "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+           "algorithmic_bytes": dom["bytes"] / dom["launches"],
            "kernel": dominant, "launches": dom["launches"], "avg_ms": dom["ms"] / dom["launches"]}
     if mfma_bound:
         ceil = PRACTICAL_BF16_TFLOPS * (2.0 if fp8 else 1.0)
@@ -327,6 +363,25 @@ def secondary_c5(model, one_step, kw, args, B, flops):
            "finite": math.isfinite(loss_val)}
     if r["dom"]:
         out["roofline"] = roofline_of(r["dominant"], r["dom"], "c5", B)
+    if r["breakdown"]:
+        bd = r["breakdown"]
+        out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(bd.items(), key=lambda kv: -kv[1]["ms"])}
+        out["kernel_breakdown_ms"]["_sum"] = round(sum(v["ms"] for v in bd.values()), 3)
+        out["kernel_rates"] = rates_of(bd)
+    return out
+
+
+def small_batch_leg(make_step, kw, args, flops, latent_shape, device, gen, B=2):
+    """SURVEY 8(d) names B=2 for C3b (report 1, 2, 4): the same model, optimizer and schedule on a per-GPU batch of 2 in
+    the same run (2 untimed steps -- the second one ranks the kernel classes -- then 6 timed ones, about 1.5 s)."""
+    batch = {"latent": torch.randn(B, *latent_shape, device=device, generator=gen).to(torch.bfloat16),
+             "context": torch.randn(B, LC, CC, device=device, generator=gen).to(torch.bfloat16), "prompt": [""] * B}
+    steps, warmup = 6, 2
+    r = measure(make_step(batch), steps, warmup, 1, kw, args)
+    value = B * steps / r["dt"]
+    out = {"per_gpu_batch": B, "value": value, "unit": "samples/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": r["dt"] / steps * 1e3, "ms_per_step_median": r["median_ms"],
+           "mfma_util_step": value * flops / (PEAK_BF16_TFLOPS * 1e12), "loss": float(r["loss"].item())}
     if r["breakdown"]:
         bd = r["breakdown"]
         out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(bd.items(), key=lambda kv: -kv[1]["ms"])}
@@ -444,6 +499,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="c3b on 1 GPU: skip the `secondary` measurement (the same model and batch with DiT.enable_fp8() = "
                          "BASELINE config 5)")
+    ap.add_argument("--no-small-batch", action="store_true",
+                    help="c3b on 1 GPU: skip the `small_batch` measurement (the same model at a per-GPU batch of 2, the batch "
+                         "SURVEY 8(d) names)")
     ap.add_argument("--no-fp8-cross-attention", action="store_true",
                     help="c5: keep the cross-attention products in bf16 (fp8 self-attention only)")
     args = ap.parse_args()
@@ -500,8 +558,10 @@ def main():
              "context": torch.randn(B, LC, CC, device=device, generator=gen).to(torch.bfloat16),
              "prompt": [""] * B}
 
-    def one_step():
-        return train_step(model, opt, sched, batch, device, generator=gen)
+    def make_step(bt):
+        return lambda: train_step(model, opt, sched, bt, device, generator=gen)
+
+    one_step = make_step(batch)
 
     graphed = None
     if args.graph:  # whole-step HIP-graph replay (graph.py); world_size 1 only
@@ -581,7 +641,12 @@ def main():
                     rate = (f"{v['flops'] / v['ms'] / 1e9:8.1f} TFLOP/s" if v["flops"] > 0 else
                             f"{v['bytes'] / v['ms'] / 1e6:8.1f} GB/s")
                     print(f"[bench] {k:16s} {v['launches']:5d} launches {v['ms']:9.3f} ms  {rate}", file=sys.stderr)
-        # the two companion legs must never cost the headline its JSON line: a failure is reported in their place
+        # the companion legs must never cost the headline its JSON line: a failure is reported in their place
+        if world == 1 and args.workload == "c3b" and graphed is None and fs is None and not args.no_small_batch:
+            try:  # (before the secondary: that one switches the model to fp8)
+                out["small_batch"] = small_batch_leg(make_step, kw, args, flops, latent_shape, device, gen)
+            except Exception as e:  # noqa: BLE001
+                out["small_batch"] = {"error": f"{type(e).__name__}: {e}"[:500]}
         if world == 1 and args.workload == "c3b" and graphed is None and fs is None and not args.no_secondary:
             try:
                 out["secondary"] = secondary_c5(model, one_step, kw, args, B, flops)
@@ -591,6 +656,7 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(kw, latent_shape, flops)
                 out["cpu_baseline"]["c1_measured"] = cpu_baseline_c1()
+                out["cpu_baseline"]["c2_measured"] = cpu_baseline_c2()
             except Exception as e:  # noqa: BLE001
                 out.setdefault("cpu_baseline", {})["error"] = f"{type(e).__name__}: {e}"[:500]
         print(json.dumps(out), flush=True)

@@ -636,10 +636,14 @@ def test_graph_replay_rejects_other_shapes(vds):
         gs.step({"latent": torch.randn(2, 16, 4, 8, 16).cuda(), "context": torch.randn(2, 16, 64).cuda()})
 
 
-@pytest.mark.parametrize("D,H", [(128, 4), (512, 16), (192, 2)], ids=["hd32", "hd32_reference_smoke_width", "hd96"])
+@pytest.mark.parametrize("D,H", [(128, 4), (512, 16), (192, 2), (96, 2), (160, 2), (224, 2), (80, 2), (208, 2)],
+                         ids=["hd32", "hd32_reference_smoke_width", "hd96", "hd48_on_64", "hd80_on_96x80", "hd112_on_128",
+                              "hd40_on_64", "hd104_on_128"])
 def test_head_dim_32_and_96_vs_oracle(vds, D, H):
-    """head_dim 32 (the reference's own smoke test builds width 512 with its default 16 heads, model.py:545-565) and
-    head_dim 96 (no padding at all): forward, loss and every gradient against the fp32 oracle"""
+    """head_dim 32 (the reference's own smoke test builds width 512 with its default 16 heads, model.py:545-565),
+    head_dim 96 (no padding at all) and -- round 5 -- head dims that have no kernel instance of their own and run on the
+    next one with their rows' tails fetched as zeros (48 / 40 -> 64, 80 -> 96 x 80, 112 / 104 -> 128; the reference takes
+    any hidden_size // num_heads, model.py:57): forward, loss and every gradient against the fp32 oracle"""
     cfg = O.DiTConfig(in_channels=16, hidden_size=D, depth=2, num_heads=H, cross_attn_input_size=64,
                       residual_v=True, train_bias_and_rms=True)
     P = O.init_params(cfg, seed=41, randomize_zero_init=True, init_std_factor=1.0)
@@ -670,7 +674,9 @@ def test_head_dim_32_and_96_vs_oracle(vds, D, H):
             bad.append((k, c, e))
     assert not bad, bad
     with pytest.raises(ValueError, match="no attention kernel instance"):
-        vds["model"].DiT(in_channels=16, hidden_size=160, depth=1, num_heads=4)  # head_dim 40: stated, not silent
+        vds["model"].DiT(in_channels=16, hidden_size=272, depth=1, num_heads=2)  # head_dim 136 > 128: stated, not silent
+    with pytest.raises(ValueError, match="no attention kernel instance"):
+        vds["model"].DiT(in_channels=16, hidden_size=200, depth=1, num_heads=4)  # head_dim 50: no RoPE table either
 
 
 @pytest.mark.parametrize("D,H,lat", [(144, 2, (2, 16, 4, 8, 8)), (256, 4, (2, 16, 4, 16, 16))])

@@ -3,7 +3,7 @@
 #     bash tools/collect_profiles.sh r02        (writes gpurun_out/prof_r02/..., summaries are then copied into profiles/)
 # Counter passes are separate runs (--pmc with --kernel-trace only), as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -16,11 +16,19 @@ if ! head -c 4 "$PY" | grep -q ELF; then
   exit 2
 fi
 # 1. per-kernel time of the bench command itself
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o c3b --output-format csv -- $PY bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/bench_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o c3b --output-format csv -- $PY bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-small-batch > "$OUT/bench_under_rocprof.log" 2>&1
 # 1b. the same command with 4 more steps: the difference of the two kernel_stats tables = launches per train step (what
 #     is left of torch's own kernels -- fills, copies, RNG -- in the step, as opposed to model / optimizer construction)
-rocprofv3 --kernel-trace --stats -d "$OUT/stats7" -o c3b7 --output-format csv -- $PY bench.py --steps 7 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/bench7_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/stats7" -o c3b7 --output-format csv -- $PY bench.py --steps 7 --warmup 1 --no-cpu-baseline --no-secondary --no-small-batch > "$OUT/bench7_under_rocprof.log" 2>&1
 find "$OUT/stats7" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/c3b_7steps_kernel_stats.csv"
+# 1c. (round 5) HBM-side bytes of EVERY kernel class of the step: the bench command itself under the two PMC passes
+#     (FETCH_SIZE and WRITE_SIZE cannot share a pass), bf16 (c3b) and fp8 (c5) -> profiles/${TAG}_traffic.json, the file
+#     bench.py's roofline.traffic reads (per-launch mean over the class's dispatches)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/step_c3b/$c" -o x --output-format csv -- $PY bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-small-batch --no-prof > "$OUT/step_c3b_$c.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/step_c5/$c" -o x --output-format csv -- $PY bench.py --workload c5 --steps 1 --warmup 3 --no-cpu-baseline --no-prof > "$OUT/step_c5_$c.log" 2>&1
+done
+$PY tools/pmc_class_traffic.py "$(git rev-parse --short HEAD 2>/dev/null || echo ${COMMIT:-unknown})" "c3b:$OUT/step_c3b" "c5:$OUT/step_c5" > "$OUT/${TAG}_traffic.json" 2> "$OUT/traffic_json.err"
 # 2. HBM-side bytes of the attention kernels at the bench shape (B = 12): FETCH_SIZE and WRITE_SIZE cannot share a pass
 for c in FETCH_SIZE WRITE_SIZE; do
   B=12 REPS=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o x --output-format csv -- $PY tools/prof_attn.py > "$OUT/pmc_$c.log" 2>&1

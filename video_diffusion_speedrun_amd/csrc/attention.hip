@@ -1550,6 +1550,15 @@ AttnP to_p(const vds_attn_args* a) {
   return p;
 }
 
+// The kernels are templates on the PADDED head dim (HDP: the Q K^T / dO V^T contraction, HDQ: the width of O / dQ / dK / dV);
+// rows are fetched with every 16-byte chunk at or past head_dim redirected out of range (zeros) and only head_dim columns
+// are stored, so any head_dim that is a multiple of 8 runs on the next instance (model.py:57 of the reference takes any
+// hidden_size // num_heads): <= 32, <= 64, <= 80 (HDP 96, HDQ 80: DiT-XL's 72), <= 96, <= 128.  0 = no instance.
+int kernel_instance(int hd) {
+  if (hd <= 0 || (hd & 7) || hd > 128) return 0;
+  return hd <= 32 ? 32 : hd <= 64 ? 64 : hd <= 80 ? 80 : hd <= 96 ? 96 : 128;
+}
+
 bool strides_ok(const vds_attn_args* a, bool bwd) {
   auto ok = [](int64_t s) { return (s & 7) == 0; };
   bool r = ok(a->q_sb) && ok(a->q_sh) && ok(a->q_sl) && ok(a->k_sb) && ok(a->k_sh) && ok(a->k_sl) &&
@@ -1753,10 +1762,10 @@ extern "C" int vds_attn_fwd(const vds_attn_args* a, vds_stream_t stream) {
   if (!strides_ok(a, false)) return VDS_ERR_ARG;
   AttnP p = to_p(a);
   hipStream_t s = (hipStream_t)stream;
-  switch (a->head_dim) {
+  switch (kernel_instance(a->head_dim)) {
     case 32: return run_fwd<32, 32>(p, s);  // (the reference's own smoke test: width 512 / 16 heads, model.py:545-565)
     case 64: return run_fwd<64, 64>(p, s);
-    case 72: return run_fwd<96, 80>(p, s);
+    case 80: return run_fwd<96, 80>(p, s);
     case 96: return run_fwd<96, 96>(p, s);
     case 128: return run_fwd<128, 128>(p, s);
     default: return VDS_ERR_UNSUPPORTED;
@@ -1779,10 +1788,10 @@ extern "C" int vds_attn_bwd(const vds_attn_args* a, vds_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   // floats in `delta`: 2*B*H*Lq when the caller does not say (ws_floats = 0: the pre-round-4 contract, no query split)
   const size_t ws = a->ws_floats > 0 ? (size_t)a->ws_floats : (size_t)2 * a->B * a->H * a->Lq;
-  switch (a->head_dim) {
+  switch (kernel_instance(a->head_dim)) {
     case 32: return run_bwd<32, 32>(p, s, ws);
     case 64: return run_bwd<64, 64>(p, s, ws);
-    case 72: return run_bwd<96, 80>(p, s, ws);
+    case 80: return run_bwd<96, 80>(p, s, ws);
     case 96: return run_bwd<96, 96>(p, s, ws);
     case 128: return run_bwd<128, 128>(p, s, ws);
     default: return VDS_ERR_UNSUPPORTED;

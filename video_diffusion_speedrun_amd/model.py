@@ -41,10 +41,14 @@ _NO_ATTN_EMIT = os.environ.get("VDS_FP8_ATTN_EMIT") == "0"  # experiments: atten
 
 bf16, f32 = torch.bfloat16, torch.float32
 N_REG = 16  # register tokens (model.py:316,362,386)
-# head_dim -> row length of the head-major q / k / v buffers (the attention kernels' LDS images are multiples of 32
-# columns; 72 -> 96 leaves room for the ones columns of the DiT-XL kernels).  The reference accepts any head_dim
-# (hidden_size // num_heads); other values raise in DiT.__init__ with the list below.
-HDP_OF = {32: 32, 64: 64, 72: 96, 96: 96, 128: 128}
+# head_dim -> row length of the head-major q / k / v buffers: head_dim itself, except 72 -> 96, which leaves room for the
+# ones columns of the DiT-XL kernels.  The reference accepts any head_dim = hidden_size // num_heads that its RoPE table
+# can be built for (a multiple of 8: model.py:192-209 reshapes arange(0, hd/2, 4) to hd/8 columns); so does this model up
+# to 128 (round 5): the attention kernels are templates on a padded head dim (32 / 64 / 80+96 / 96 / 128) that fetch a
+# row's chunks past head_dim as zeros, so e.g. 48 runs on the 64 instance and 112 on the 128 one (csrc/attention.hip,
+# kernel_instance); head dims above 128 raise in DiT.__init__.
+HDP_OF = {hd: hd for hd in range(8, 129, 8)}
+HDP_OF[72] = 96
 
 
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
@@ -700,8 +704,9 @@ class DiT(nn.Module):
         self.head_dim = hidden_size // num_heads
         if self.head_dim not in HDP_OF:
             raise ValueError(f"head_dim {self.head_dim} = hidden_size / num_heads has no attention kernel instance "
-                             f"({sorted(HDP_OF)}: DiT-S/B = 64, DiT-XL = 72, the reference's sweep = 128, its smoke "
-                             "test = 32); the kernels are templates on the padded head dim, see csrc/attention.hip")
+                             "(multiples of 8 up to 128: DiT-S/B = 64, DiT-XL = 72, the reference's sweep = 128, its "
+                             "smoke test = 32; the reference's own RoPE table needs a multiple of 8 too, model.py:192-209); "
+                             "the kernels are templates on the padded head dim, see csrc/attention.hip")
         self.patch_embed = PatchEmbed(patch_size, in_channels, hidden_size, time_patch_size)
         if use_rope:
             self.rope = ThreeDimRotary(hidden_size // (2 * num_heads), h=128, w=128, t=128)
