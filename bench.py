@@ -478,7 +478,7 @@ def comm_only(model, args, world, rank, device, desc, B):
         dist.destroy_process_group()
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -504,7 +504,11 @@ def main():
                          "SURVEY 8(d) names)")
     ap.add_argument("--no-fp8-cross-attention", action="store_true",
                     help="c5: keep the cross-attention products in bf16 (fp8 self-attention only)")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -219,10 +219,13 @@ def attn_ref(q, k, v, do=None):
 
 @pytest.mark.parametrize("hd,Lq,Lk", [(64, 272, 272), (64, 130, 512), (128, 200, 333), (72, 272, 272),
                                       (72, 129, 512), (128, 64, 64), (64, 1040, 1040), (64, 2100, 300),
-                                      (72, 2100, 300)])  # Lq >= 2048: the 64-queries-per-wave forward kernels
+                                      (72, 2100, 300),
+                                      # round 5: head dims without an instance of their own (rows stored unpadded, next instance)
+                                      (48, 272, 272), (40, 129, 512), (80, 272, 300), (112, 200, 333), (104, 2100, 300),
+                                      (24, 130, 130), (56, 2100, 300)])  # Lq >= 2048: the 64-queries-per-wave forward kernels
 def test_attention_fwd_bwd(ops, hd, Lq, Lk):
     B, H = 2, 3
-    hdp = {64: 64, 72: 96, 128: 128}[hd]
+    hdp = {64: 64, 72: 96, 128: 128}.get(hd, hd)
     q, k, v = gen(B, H, Lq, hd, seed=20), gen(B, H, Lk, hd, seed=21), gen(B, H, Lk, hd, seed=22)
     do = gen(B, Lq, H * hd, seed=23)
     # device layouts: q/k/v head-major padded rows [B,H,L,hdp]; o/do token-major [B,L,H*hd]
