@@ -78,6 +78,17 @@ int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);
  * values.  The environment variable VDS_GEMM_TILE sets the initial value.  Results are identical across tilings up
  * to fp32 summation order. */
 int vds_gemm_force_tile(int32_t tile);
+/* Stream-K launches of the 256^2 kernel (round 5; NT / NN, bf16 and fp8): a persistent grid of one workgroup per CU that
+ * takes the whole rounds of the tile list data-parallel and divides the K iterations of the leftover tiles evenly, with
+ * fp32 partial tiles handed over in HBM (csrc/gemm.hip, gemm_sk_kernel): the launch costs its work instead of whole
+ * rounds of 256 tiles.  mode: 1 on, 0 off, -1 (initial) = environment variable VDS_GEMM_SK (default on); returns the
+ * previous mode.  Results equal the plain launch's up to the fp32 summation order of split tiles.  Needs the chip to
+ * itself (the sharding runtime switches it off for world sizes > 1) and one stream per device for the GEMMs; the
+ * hand-off workspace (64 MiB per device) is allocated by the library on first use and kept. */
+int vds_gemm_stream_k(int32_t mode);
+/* 0, or 1 when a hand-off poll of a stream-K launch on the current device timed out since the last call (that
+ * launch's result is wrong; the kernel bounds every spin instead of hanging).  Synchronises the device. */
+int vds_gemm_stream_k_status(void);
 
 /* The same GEMM with OCP fp8 operands (BASELINE config 5; no reference counterpart -- the reference trains in
  * bf16): layout VDS_NT: A[M,K] and B[N,K] one byte per element (a_fmt / b_fmt: 0 = e4m3fn, 1 = e5m2; B must

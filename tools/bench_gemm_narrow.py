@@ -1,6 +1,7 @@
-"""Same-box A/B of the 256 x 128 body for a narrow last tile column (round 5, VDS_GEMM_NARROW) against the full-width
-body, at the DiT-XL shapes with the fused epilogues the model uses, bf16 and fp8.  Candidates run round-robin, median
-over the rounds.   B=12 python tools/bench_gemm_narrow.py"""
+"""Same-box A/B of a per-call GEMM knob of the library (an environment variable it reads per call: 0 = off, 1 = on) at the
+DiT-XL shapes with the fused epilogues the model uses, bf16 and fp8.  Candidates run round-robin, median over the rounds.
+    B=12 python tools/bench_gemm_narrow.py                     # VDS_GEMM_NARROW: 256 x 128 body for a narrow last tile column
+    B=2 KNOB=VDS_GEMM_SK python tools/bench_gemm_narrow.py     # stream-K launches of the 256^2 kernel (round 5)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -34,9 +35,12 @@ def ab(fns):
     return {k: sorted(v)[len(v) // 2] for k, v in times.items()}
 
 
+KNOB = os.environ.get("KNOB", "VDS_GEMM_NARROW")
+
+
 def with_env(val, fn):
     def run():
-        os.environ["VDS_GEMM_NARROW"] = val
+        os.environ[KNOB] = val
         fn()
     return run
 
@@ -58,10 +62,10 @@ cases = [("NT qkv fwd      N3456 K1152", lambda: ops.linear_fwd(x1, w["qkv"], No
          ("NN proj dgrad    N1152 K1152", lambda: ops.linear_dgrad(dy1, w["proj"]), 2 * M * D * D, 3),
          ("NN fc1 dgrad     N1152 K4608", lambda: ops.linear_dgrad(dy4, w["fc1"]), 2 * M * 4 * D * D, 1),
          ("NN fc2 dgelu+cs  N4608 K1152", lambda: ops.linear_dgrad(dy1, w["fc2"], pre=hpre, colsum=cs), 2 * M * 4 * D * D, 1)]
-total = {"full": 0.0, "narrow": 0.0}
-print(f"bf16, M = {M}")
+total = {"off": 0.0, "on": 0.0}
+print(f"{KNOB} off / on; bf16, M = {M}")
 for name, fn, fl, cnt in cases:
-    r = ab({"full": with_env("0", fn), "narrow": with_env("1", fn)})
+    r = ab({"off": with_env("0", fn), "on": with_env("1", fn)})
     for t in r:
         total[t] += r[t] * cnt
     print(f"{name}  " + "  ".join(f"{t}: {ms:6.3f} ms {fl / ms / 1e9:6.0f} TF" for t, ms in r.items()), flush=True)
@@ -70,7 +74,7 @@ print("per block (NT + NN): " + "  ".join(f"{t}: {v:7.3f} ms" for t, v in total.
 
 if os.environ.get("FP8", "1") == "1":
     print("fp8 (e4m3 x e4m3 forward, e5m2 x e4m3 dgrad, e5m2^T x e4m3 wgrad)")
-    tot8 = {"full": 0.0, "narrow": 0.0}
+    tot8 = {"off": 0.0, "on": 0.0}
     q = lambda t, fmt: F8.Q(t, fmt, True, False)
     qx1, qx4 = q(x1, F8.E4M3), q(x4, F8.E4M3)
     qw = {n: F8.Q(t, F8.E4M3, True, True, weight=True) for n, t in w.items()}
@@ -94,7 +98,7 @@ if os.environ.get("FP8", "1") == "1":
           ("fp8 fc2 wgrad   1152x4608", lambda: F8.wgrad(qdy1, qx4, g14), 2 * M * 4 * D * D, 1)]
     for name, fn, fl, cnt in c8:
         try:
-            r = ab({"full": with_env("0", fn), "narrow": with_env("1", fn)})
+            r = ab({"off": with_env("0", fn), "on": with_env("1", fn)})
         except Exception as ex:  # a case the fp8 front end does not take in this form
             print(f"{name}  skipped: {ex}")
             continue

@@ -75,6 +75,8 @@ SIGNATURES = {
     "vds_last_error": [],
     "vds_gemm_bf16": [C.POINTER(GemmArgs), c_vp],
     "vds_gemm_force_tile": [c_i32],
+    "vds_gemm_stream_k": [c_i32],
+    "vds_gemm_stream_k_status": [],
     "vds_attn_fwd": [C.POINTER(AttnArgs), c_vp],
     "vds_attn_bwd": [C.POINTER(AttnArgs), c_vp],
     "vds_attn_set_variant": [c_i32],

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 
@@ -776,10 +777,46 @@ __device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigne
 #ifndef VDS_GEMM_NPH
 #define VDS_GEMM_NPH 2  // phases per K tile of the 256-wide tiling (4: the loop of rounds 1-3, for A/B builds)
 #endif
+// ---- stream-K (round 5) ------------------------------------------------------------------------------------------
+// The persistent form of the kernel (gemm_sk_kernel below) hands a workgroup SEGMENTS of output tiles: K tiles
+// [kt_begin, kt_end) of one tile.  A segment that does not start at K tile 0 is a PRODUCER: its accumulators go to the
+// workgroup's slab (fp32, in the accumulator register layout: lane-private 16-byte pieces, 1 KiB per wave-instruction)
+// and a flag is raised.  The segment that starts at 0 but ends early is the tile's FINISHER: after its own K tiles it adds
+// the slabs of the `n_follow` workgroups behind it (which computed the later K tiles of the same tile at the START of
+// their ranges, i.e. earlier in time) and runs the fused epilogue.  Hand-off (MI355X_MICROARCH.md, "Valid forms", table
+// row 1): slab stores and loads are all sc1 (write-through / L1-bypassing), every storing wave drains vmcnt, a workgroup
+// barrier, ONE lane raises the flag with an sc1 store; the finisher's lane 0 polls with sc1 loads, a workgroup barrier
+// releases the other waves; the finisher lowers the flag again (each flag has one producer and one consumer per launch,
+// launches on a stream are ordered), so no host-side epoch is needed and a captured HIP graph can replay the launch.
+struct SkSeg {
+  int mode;          // 0 whole tile, 1 producer, 2 finisher
+  int w;             // this workgroup's slab / flag index
+  unsigned long long follow;  // finisher: bit i set = workgroup w + 1 + i produced a slab of this tile
+  float* slab;       // [workgroups][65536] fp32
+  unsigned* flag;    // [workgroups][16] (64-byte pitch)
+  unsigned* status;  // != 0: a poll timed out (results of that launch are wrong; never seen in practice, bounds the spin)
+};
+constexpr int SK_SLAB_FLOATS = 256 * 256;
+constexpr int SK_FLAG_PITCH = 16;
+
+// list index -> output tile: XCD-aware (blocks b, b + 8, .. share an XCD: each XCD gets a contiguous chunk of the list) +
+// grouped order (groups of group_m row tiles, row fastest)
+__host__ __device__ __forceinline__ void tile_of(int L, int nwg, int tiles_m, int tiles_n, int group_m, int& tile_m, int& tile_n) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, idx = L >> 3;
+  const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int group = group_m * tiles_n;
+  const int first_m = (pid / group) * group_m;
+  const int gsz = (tiles_m - first_m) < group_m ? (tiles_m - first_m) : group_m;
+  tile_m = first_m + (pid % group) % gsz;
+  tile_n = (pid % group) / gsz;
+}
+
 // One output tile: rows m0 .. m0 + 255, columns n0 .. n0 + BN - 1, K tiles kt_begin .. kt_end - 1.
+// first: the workgroup's first tile (persistent kernel: later tiles synchronise on the LDS ring first and find the GELU
+// table already staged).
 template <int LAYOUT, int EPI, int FMT, int WN, int NPH>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int m0, const int n0, const int kt_begin,
-                                          const int kt_end) {
+                                          const int kt_end, const SkSeg& sk, const bool first) {
   static_assert(FMT == 0 || (FMT != 3 && LAYOUT == VDS_NT) || (FMT == 3 && LAYOUT == VDS_TN && WN != 192),
                 "fp8 operands: k-contiguous (FMT 1 / 2, NT) or both k-major (FMT 3, TN: the weight gradient)");
   using G = Geo<WN>;
@@ -788,14 +825,19 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   constexpr int NPB1 = WN == 192 ? 1 : 2;  // 1-KiB pieces per wave of the B1 half / quarter tile
   constexpr bool A_KM = (LAYOUT == VDS_TN);
   constexpr bool B_KM = (LAYOUT != VDS_NT);
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid_ = threadIdx.x;
+  // (persistent kernel: without this the compiler hoists every lane-derived address of the tile body out of the tile loop
+  // and keeps them live across it -- 170-430 spilled VGPRs; opaque per call, they are recomputed per tile and die)
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const srd_t ra = make_srd(p.A, p.a_bytes);
   const srd_t rb = make_srd(p.B, p.b_bytes);
   constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
   char* const ring = smem + (USE_LUT ? LUT_BYTES : 0);  // stage ring / epilogue staging area
-  if constexpr (USE_LUT) {
+  if (!first) __syncthreads();  // the previous tile's epilogue is done with the ring (its stores may still be in flight)
+  if (USE_LUT && first) {
     // the GELU table (16 KiB) sits at LDS address 0, in front of the ring: two 1-KiB pieces per wave, older than
     // every operand DMA, so the counted waits of the main loop cover them
     const srd_t rl = make_srd(g_gelu_lut[EPI == VDS_EPI_DGELU ? 1 : 0], LUT_BYTES);
@@ -1130,6 +1172,22 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   // The aux tiles (residual / pre-activation) of BOTH quadrant rows are requested here, before the drain of the
   // operand pipeline: one exposed HBM round trip per output tile instead of one per quadrant row (with one workgroup
   // per CU nothing else hides it).  The drain waits for everything but these 16 loads (loads return in order).
+  if (sk.mode == 1) {
+    // ---- stream-K producer: accumulators -> slab (sc1 stores), flag ----
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
+    VDS_WAIT_VM(0);                              // (the zero-fill tail DMAs: the next tile re-stages the ring)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(sk.slab + (long)sk.w * SK_SLAB_FLOATS, SK_SLAB_FLOATS * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
+                                               (unsigned)(((wave * 32 + i * NJ + j) * 64 + lane) * 16), 0, 16 /* sc1 */);
+    VDS_WAIT_VM(0);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(sk.flag + sk.w * SK_FLAG_PITCH, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   u32x4 auxr2[2][8];
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa)
@@ -1142,6 +1200,27 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   if (aux_all) VDS_WAIT_VM(16);
   else VDS_WAIT_VM(0);
   __builtin_amdgcn_s_barrier();
+
+  // ---- stream-K finisher (sk.follow != 0): wait for the workgroups that computed the later K tiles of this tile; their
+  // slabs are added while the accumulators are staged below.  (The accumulators themselves are never modified: an add
+  // loop over them -- or an add behind an `if` -- makes the register allocator copy all 128 and spill 150-400 VGPRs.)
+  const unsigned long long follow = sk.follow;
+  if (follow != 0ull) {
+    if (tid == 0) {
+      for (unsigned long long rest = follow; rest != 0ull; rest &= rest - 1ull) {
+        const unsigned* fl = sk.flag + (sk.w + 1 + __builtin_ctzll(rest)) * SK_FLAG_PITCH;
+        int spins = 0;
+        while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > (1 << 24)) {  // ~ seconds: give up instead of hanging the GPU
+            __hip_atomic_store(sk.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
 
   float* stg = reinterpret_cast<float*>(ring) + wave * 64 * EPI_LD;
   float dq = 1.0f;
@@ -1170,6 +1249,14 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {  // lane (c, g): row i * 16 + c, columns j * 16 + 4 g .. + 3 (see `mma`)
         f32x4 v = acc[qa * 4 + i][j];
+        if (follow != 0ull) {  // (wave-uniform; sc1 loads: the hand-off's rule is that EVERY load of a slab bypasses L1)
+          for (unsigned long long rest = follow; rest != 0ull; rest &= rest - 1ull) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(sk.slab + (long)(sk.w + 1 + __builtin_ctzll(rest)) * SK_SLAB_FLOATS,
+                                                        SK_SLAB_FLOATS * 4);
+            v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                     rs, (unsigned)(((wave * 32 + (qa * 4 + i) * NJ + j) * 64 + lane) * 16), 0, 16 /* sc1 */));
+          }
+        }
         if constexpr (FMT != 0) v *= dq;
         *reinterpret_cast<f32x4*>(stg + (i * 16 + (lane & 15)) * EPI_LD + j * 16 + 4 * (lane >> 4)) = v;
       }
@@ -1183,6 +1270,13 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
     if (full) done = epilogue_full_dispatch<EPI, EMIT, WCOLS>(p, stg, lut, row0, col0, lane, cs, ew[qa], auxr, e_scale, e_max);
     if (!done) epilogue_64x64<EPI, EMIT, USE_LUT, WCOLS>(p, stg, row0, col0, lane, cs, ew[qa], auxr, lut);
     __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
+  }
+  if (follow != 0ull) {  // every wave has read its slab values: lower the producers' flags for the next launch
+    __syncthreads();
+    if (tid == 0)
+      for (unsigned long long rest = follow; rest != 0ull; rest &= rest - 1ull)
+        __hip_atomic_store(sk.flag + (sk.w + 1 + __builtin_ctzll(rest)) * SK_FLAG_PITCH, 0u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (EMIT) {
     if ((p.e_q || p.e_qt) && p.e_amax_out) {
@@ -1280,13 +1374,69 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     kt_end = min(kt_total, kt_begin + per);
     if (kt_begin >= kt_end) return;
   }
+  const SkSeg none = {0, 0, 0ull, nullptr, nullptr, nullptr};
   if constexpr (WN == 256 && NPH == 2) {
     if (p.narrow && tile_n == p.tiles_n - 1) {
-      gemm_tile<LAYOUT, EPI, FMT, 128, NPH>(p, smem, m0, n0, kt_begin, kt_end);
+      gemm_tile<LAYOUT, EPI, FMT, 128, NPH>(p, smem, m0, n0, kt_begin, kt_end, none, true);
       return;
     }
   }
-  gemm_tile<LAYOUT, EPI, FMT, WN, NPH>(p, smem, m0, n0, kt_begin, kt_end);
+  gemm_tile<LAYOUT, EPI, FMT, WN, NPH>(p, smem, m0, n0, kt_begin, kt_end, none, true);
+}
+
+// ---- persistent stream-K kernel: one workgroup per CU -----------------------------------------------------------------
+// The tile list (XCD-aware grouped order, narrow last column included) is cut into  dp = T / G  rounds that the G
+// workgroups take data-parallel -- workgroup b computes tiles b, b + G, ..: at any time the chip works on G consecutive
+// tiles of the list, the L2 locality of the plain launch -- and the remaining  T % G  tiles, whose K iterations are
+// divided evenly (by cost: a narrow tile's iteration counts 3/4) over the workgroups: every workgroup first computes its
+// iteration range [it_start[b], it_start[b + 1]) of that region (producer / finisher segments, see SkSeg), then its
+// whole tiles.  The launch takes  work / G + one hand-off  instead of  ceil(T / G)  tile times: the last, partly filled
+// round of the plain launch (N = 1152 at B = 12: 7.1 rounds of work run as ~7.8) is gone, and small problems (B = 1 .. 4:
+// 0.6 .. 2.5 rounds) fill the chip.
+constexpr int SK_MAX_WG = 256;
+struct SkSched {
+  int G, dp, t_dp, kt;         // workgroups, whole rounds, dp * G, K tiles per output tile
+  float* slab; unsigned* flag; unsigned* status;
+  int it_start[SK_MAX_WG + 2];  // iteration range starts in the region's iteration space (tile-major, kt per tile)
+};
+
+template <int LAYOUT, int EPI, int FMT>
+__global__ __launch_bounds__(512, 2) void gemm_sk_kernel(GemmP p, SkSched sc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x;
+  const int nwg = p.tiles_m * p.tiles_n;
+  int it = sc.it_start[b];
+  const int it_end = sc.it_start[b + 1];
+  bool first = true;
+  for (int r = 0; it < it_end || r < sc.dp;) {
+    int L, k0, k1;
+    SkSeg seg = {0, b, 0ull, sc.slab, sc.flag, sc.status};
+    if (it < it_end) {  // a segment of the stream-K region
+      const int ti = it / sc.kt;
+      k0 = it - ti * sc.kt;
+      k1 = min(sc.kt, k0 + (it_end - it));
+      L = sc.t_dp + ti;
+      if (k0 > 0) seg.mode = 1;
+      else if (k1 < sc.kt) {
+        seg.mode = 2;
+        const int tile_end = (ti + 1) * sc.kt;
+        for (int wp = b + 1; wp < sc.G && wp <= b + 64 && sc.it_start[wp] < tile_end; ++wp)
+          if (sc.it_start[wp + 1] > sc.it_start[wp]) seg.follow |= 1ull << (wp - b - 1);  // (empty ranges produce nothing)
+      }
+      it += k1 - k0;
+    } else {  // a whole tile of the data-parallel rounds
+      L = r * sc.G + b;
+      k0 = 0;
+      k1 = sc.kt;
+      ++r;
+    }
+    int tile_m, tile_n;
+    tile_of(L, nwg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * 256;
+    if (p.narrow && tile_n == p.tiles_n - 1) gemm_tile<LAYOUT, EPI, FMT, 128, 2>(p, smem, m0, n0, k0, k1, seg, first);
+    else gemm_tile<LAYOUT, EPI, FMT, 256, 2>(p, smem, m0, n0, k0, k1, seg, first);
+    first = false;
+  }
 }
 
 template <int LAYOUT, int EPI, int FMT = 0, int WN = 256, int NPH = VDS_GEMM_NPH>
@@ -1309,6 +1459,125 @@ int launch(const GemmP& p, hipStream_t s) {
                     s, 2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
   hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT, WN, NPH>), grid, dim3(512), LDS_TOTAL, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+// ---- stream-K launch ----------------------------------------------------------------------------------------------
+// Workspace of the stream-K hand-offs, one per device, allocated on first use and kept: [flags 256 x 64 B | status |
+// slabs n_cu x 256 KiB].  (Not during a stream capture: the caller then takes the plain launch.)  GEMMs of one device must
+// not run stream-K launches concurrently on two streams (they would share slabs); the package issues them on one.
+struct SkWs { char* base; int n_cu; };
+constexpr size_t SK_HDR = 32768;
+static std::mutex g_sk_mu;
+static SkWs g_sk_ws[64] = {};
+static bool g_sk_tried[64] = {};
+inline SkWs* sk_workspace(hipStream_t s) {
+  std::mutex& mu = g_sk_mu;
+  SkWs* ws = g_sk_ws;
+  bool* tried = g_sk_tried;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tried[dev]) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return nullptr;  // (not remembered: the next eager call allocates)
+    }
+    tried[dev] = true;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) return nullptr;
+    if (ncu > SK_MAX_WG) ncu = SK_MAX_WG;
+    void* b = nullptr;
+    if (hipMalloc(&b, SK_HDR + (size_t)ncu * SK_SLAB_FLOATS * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemsetAsync(b, 0, SK_HDR, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(b); return nullptr; }
+    ws[dev].base = (char*)b;
+    ws[dev].n_cu = ncu;
+  }
+  return ws[dev].base ? &ws[dev] : nullptr;
+}
+
+constexpr int SK_MIN_SEG = 4;    // K tiles: shorter segments do not amortise their pipeline fill and slab
+constexpr int SK_MAX_SPLIT = 4;  // segments per output tile (each but the first costs a 256-KiB slab round trip)
+constexpr int SK_SNAP = 2;       // a range boundary this close to a tile boundary moves onto it
+
+// the schedule of one launch (see gemm_sk_kernel); false: nothing to gain (the plain launch is taken)
+inline bool sk_schedule(const GemmP& p, int G, SkSched& sc) {
+  const int T = p.tiles_m * p.tiles_n;
+  sc.G = G;
+  sc.dp = T / G;
+  sc.t_dp = sc.dp * G;
+  sc.kt = (p.K + BK - 1) / BK;
+  const int tsk = T - sc.t_dp;
+  const long total = (long)tsk * sc.kt;
+  if (total >= (1l << 30)) return false;
+  for (int w = 0; w <= G + 1; ++w) sc.it_start[w] = 0;
+  if (tsk == 0) return sc.dp > 0;
+  long cu[SK_MAX_WG + 1];  // cumulative cost of the region's tiles: 4 per K tile, 3 for a narrow tile's
+  cu[0] = 0;
+  for (int j = 0; j < tsk; ++j) {
+    int tm, tn;
+    tile_of(sc.t_dp + j, T, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    cu[j + 1] = cu[j] + (long)((p.narrow && tn == p.tiles_n - 1) ? 3 : 4) * sc.kt;
+  }
+  const int min_seg = std::max(SK_MIN_SEG, (sc.kt + SK_MAX_SPLIT - 1) / SK_MAX_SPLIT);
+  long W = std::max<long>(total / min_seg, tsk);
+  W = std::min<long>(std::max<long>(W, 1), G);
+  int j = 0;
+  for (int w = 0; w <= G + 1; ++w) {
+    if (w >= W) { sc.it_start[w] = (int)total; continue; }
+    const long pos = cu[tsk] * w / W;
+    while (j + 1 < tsk && cu[j + 1] <= pos) ++j;
+    const long wgt = (cu[j + 1] - cu[j]) / sc.kt;
+    long it = (long)j * sc.kt + (pos - cu[j] + wgt - 1) / wgt;
+    const long r = it % sc.kt;
+    if (r != 0 && r <= SK_SNAP) it -= r;
+    else if (r != 0 && sc.kt - r <= SK_SNAP) it += sc.kt - r;
+    if (w > 0 && it < sc.it_start[w - 1]) it = sc.it_start[w - 1];
+    sc.it_start[w] = (int)std::min(it, total);
+  }
+  return true;
+}
+
+// returns VDS_OK / an error, or 1 when the stream-K launch is not available here (caller takes the plain launch)
+template <int LAYOUT, int EPI, int FMT = 0>
+int launch_sk(const GemmP& p, hipStream_t s) {
+  SkWs* ws = sk_workspace(s);
+  if (!ws) return 1;
+  SkSched sc;
+  if (!sk_schedule(p, ws->n_cu, sc)) return 1;
+  sc.flag = reinterpret_cast<unsigned*>(ws->base);
+  sc.status = reinterpret_cast<unsigned*>(ws->base + SK_MAX_WG * SK_FLAG_PITCH * 4);
+  sc.slab = reinterpret_cast<float*>(ws->base + SK_HDR);
+  constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
+  constexpr int LDS_TOTAL = LDS_BYTES + (USE_LUT ? LUT_BYTES : 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<LAYOUT, EPI, FMT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    attr_set = true;
+  }
+  if constexpr (USE_LUT) {
+    if (!ensure_gelu_lut()) return VDS_ERR_LAUNCH;
+  }
+  const double k = FMT != 0 ? p.prof_k : (double)p.K;
+  vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : VDS_PROF_GEMM_NN, s,
+                    2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
+  hipLaunchKernelGGL((gemm_sk_kernel<LAYOUT, EPI, FMT>), dim3(sc.G), dim3(512), LDS_TOTAL, s, p, sc);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+// the current device's "a hand-off poll timed out" word, cleared; synchronises the device (tests / debugging)
+inline int sk_status_and_clear() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  if (!g_sk_ws[dev].base) return 0;  // (a device that never ran a stream-K launch has nothing to report)
+  unsigned v = 0, zero = 0;
+  char* st = g_sk_ws[dev].base + SK_MAX_WG * SK_FLAG_PITCH * 4;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(&v, st, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (v) (void)hipMemcpy(st, &zero, 4, hipMemcpyHostToDevice);
+  return (int)v;
 }
 }  // namespace big
 
@@ -1575,6 +1844,25 @@ static int narrow_last_column(long N) {
   return rem > 0 && rem <= 128;
 }
 
+// stream-K launches of the 256^2 kernel (NT / NN): -1 = VDS_GEMM_SK (default on; read per call), 0 off, 1 on.  The
+// sharding runtime switches them off for world sizes > 1: a persistent one-workgroup-per-CU grid with a static share of
+// the work per workgroup assumes the whole chip, and RCCL's kernels hold CUs while a collective overlaps the GEMMs.
+static int g_sk_mode = -1;
+static bool sk_enabled() {
+  if (g_sk_mode >= 0) return g_sk_mode != 0;
+  const char* e = getenv("VDS_GEMM_SK");
+  return !(e && atoi(e) == 0);
+}
+constexpr int SK_MIN_TILES = 64;  // fewer 256^2 tiles: the hand-offs cost more than the idle CUs they fill
+
+extern "C" int vds_gemm_stream_k(int32_t mode) {
+  const int prev = g_sk_mode;
+  if (mode < -1 || mode > 1) return VDS_ERR_ARG;
+  g_sk_mode = mode;
+  return prev;
+}
+extern "C" int vds_gemm_stream_k_status(void) { return big::sk_status_and_clear(); }
+
 extern "C" int vds_gemm_force_tile(int32_t tile) {
   const int prev = g_force_tile < 0 ? 0 : g_force_tile;
   if (tile != 0 && tile != 128 && tile != 256 && tile != 2 && tile != 192) return VDS_ERR_ARG;
@@ -1648,7 +1936,11 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   const int tm = cdiv(a->M, 256), tn = cdiv(a->N, 256);
   const long rounds_big = ((long)tm * tn + 255) / 256;
   const long rounds_small = ((long)p.tiles_m * p.tiles_n + 511) / 512;
-  bool use_big = a->layout != VDS_TN && a->K >= 256 && (double)rounds_big * (2.0 / 1.24) < (double)rounds_small;
+  // stream-K (round 5): the 256^2 launch costs its work (+ one hand-off) instead of whole rounds
+  const bool sk_ok = sk_enabled() && a->layout != VDS_TN && (force_tile == 0 || force_tile == 256) && p.split_k == 1 &&
+                     (long)tm * tn >= SK_MIN_TILES;
+  const double rounds_big_eff = sk_ok ? (double)tm * tn / 256.0 + 0.3 : (double)rounds_big;
+  bool use_big = a->layout != VDS_TN && a->K >= 256 && rounds_big_eff * (2.0 / 1.24) < (double)rounds_small;
   if (force_tile == 128) use_big = false;
   if (force_tile == 256 || force_tile == 192) use_big = true;
   static int group_m = -1;
@@ -1734,7 +2026,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
       mid_factor = e ? atof(e) : 1.3;
     }
     const double cost_mid = (double)(((long)tmm * tnm + 511) / 512) * mid_factor;
-    const double cost_big = (double)rounds_big, cost_small = (double)rounds_small * (1.24 / 2.0);
+    const double cost_big = rounds_big_eff, cost_small = (double)rounds_small * (1.24 / 2.0);
     bool use_mid = a->K >= 128 && cost_mid < (use_big ? cost_big : cost_small) && a->layout != VDS_TN;
     (void)rounds_mid;
     if (force_tile == 2) use_mid = true;
@@ -1785,6 +2077,17 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     p.tiles_n = tn;
     p.narrow = narrow_last_column(a->N);
     p.e_colsum = a->colsum;  // DGELU only (checked above): column sums of the result in the epilogue
+    if (sk_ok) {
+      int rc = 1;
+#define GOSK(L, E) if (a->layout == L && a->epilogue == E) rc = big::launch_sk<L, E>(p, s);
+      GOSK(VDS_NT, VDS_EPI_STORE)
+      GOSK(VDS_NT, VDS_EPI_BIAS_GELU)
+      GOSK(VDS_NT, VDS_EPI_GATE_RES)
+      GOSK(VDS_NN, VDS_EPI_STORE)
+      // (not the GELU' epilogue: with its table, column sums and pre-activation tile the persistent form spills ~100 VGPRs)
+#undef GOSK
+      if (rc != 1) return rc;
+    }
 #define GOB(L, E) if (a->layout == L && a->epilogue == E) return big::launch<L, E>(p, s);
     GOB(VDS_NT, VDS_EPI_STORE)
     GOB(VDS_NT, VDS_EPI_BIAS_GELU)
@@ -1874,6 +2177,16 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
     GOFW(VDS_EPI_DGELU, 2)
 #undef GOFW
     p.tiles_n = cdiv(a->N, 256);
+  }
+  if (sk_enabled() && p.split_k == 1 && (g_force_tile == 0 || g_force_tile == 256) && (long)p.tiles_m * p.tiles_n >= SK_MIN_TILES) {
+    int rc = 1;
+#define GOFS(E, F) if (a->epilogue == E && a_fmt == F - 1) rc = big::launch_sk<VDS_NT, E, F>(p, s);
+    GOFS(VDS_EPI_STORE, 1)
+    GOFS(VDS_EPI_BIAS_GELU, 1)
+    GOFS(VDS_EPI_GATE_RES, 1)
+    GOFS(VDS_EPI_STORE, 2)
+#undef GOFS
+    if (rc != 1) return rc;
   }
 #define GOF(E, F) if (a->epilogue == E && a_fmt == F - 1) return big::launch<VDS_NT, E, F>(p, s);
   GOF(VDS_EPI_STORE, 1)

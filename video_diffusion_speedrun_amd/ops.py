@@ -61,6 +61,19 @@ def gemm_force_tile(tile: int) -> int:
     return prev
 
 
+def gemm_stream_k(mode: int) -> int:
+    """stream-K launches of the 256^2 GEMM kernel: 1 on, 0 off, -1 = VDS_GEMM_SK (default on); returns the previous mode"""
+    prev = _lib.load().vds_gemm_stream_k(int(mode))
+    if prev < -1:
+        raise ValueError(f"vds_gemm_stream_k({mode})")
+    return prev
+
+
+def gemm_stream_k_status() -> int:
+    """1 when a stream-K hand-off timed out on the current device since the last call (synchronises), else 0"""
+    return _lib.load().vds_gemm_stream_k_status()
+
+
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = x W^T + b.  x [M,K] bf16, W [N,K] bf16 -> y [M,N] bf16."""
