@@ -81,8 +81,8 @@ int vds_gemm_force_tile(int32_t tile);
 /* Stream-K launches of the 256^2 kernel (round 5; NT / NN, bf16 and fp8): a persistent grid of one workgroup per CU that
  * takes the whole rounds of the tile list data-parallel and divides the K iterations of the leftover tiles evenly, with
  * fp32 partial tiles handed over in HBM (csrc/gemm.hip, gemm_sk_kernel): the launch costs its work instead of whole
- * rounds of 256 tiles.  mode: 1 on, 0 off, -1 (initial) = environment variable VDS_GEMM_SK (default on); returns the
- * previous mode.  Results equal the plain launch's up to the fp32 summation order of split tiles.  Needs the chip to
+ * rounds of 256 tiles.  mode: 1 on, 0 off, -1 (initial) = environment variable VDS_GEMM_SK (default OFF: measured a
+ * net loss at the DiT-XL shapes, profiles/r05/negative_gemm_stream_k_*.log; an experiment); returns the previous mode.  Results equal the plain launch's up to the fp32 summation order of split tiles.  Needs the chip to
  * itself (the sharding runtime switches it off for world sizes > 1) and one stream per device for the GEMMs; the
  * hand-off workspace (64 MiB per device) is allocated by the library on first use and kept. */
 int vds_gemm_stream_k(int32_t mode);

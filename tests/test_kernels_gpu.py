@@ -818,11 +818,13 @@ def test_gemm_narrow_last_tile_column_is_bit_identical(ops, N, monkeypatch):
         return out
 
     ops.gemm_force_tile(256)
+    prev = ops.gemm_stream_k(0)  # (stream-K splits tiles along K by cost: its schedule differs between the two settings)
     try:
         got = run()
         monkeypatch.setenv("VDS_GEMM_NARROW", "0")
         ref = run()
     finally:
+        ops.gemm_stream_k(prev)
         ops.gemm_force_tile(0)
     for k in got:
         if k == "cs":  # fp32 atomics across workgroups: order-dependent in the last bits

@@ -1844,14 +1844,18 @@ static int narrow_last_column(long N) {
   return rem > 0 && rem <= 128;
 }
 
-// stream-K launches of the 256^2 kernel (NT / NN): -1 = VDS_GEMM_SK (default on; read per call), 0 off, 1 on.  The
-// sharding runtime switches them off for world sizes > 1: a persistent one-workgroup-per-CU grid with a static share of
-// the work per workgroup assumes the whole chip, and RCCL's kernels hold CUs while a collective overlaps the GEMMs.
+// stream-K launches of the 256^2 kernel (NT / NN): -1 = VDS_GEMM_SK (default OFF; read per call), 0 off, 1 on.
+// Measured a net loss at the DiT-XL shapes (profiles/r05/negative_gemm_stream_k_*.log): the plain launch's greedy hardware
+// dispatch does not pay a whole round for a partly filled last one (its tiles run faster on the emptier chip), the
+// persistent tile loop saves nothing over the hardware's workgroup dispatch (1.00-1.02x on whole rounds), and a seam moves
+// a 256 KiB fp32 slab through HBM at ~50-65 GB/s per CU (~10 us against a 28-33 us K = 1152 tile): +5.5 % per block at
+// B = 12, +9 % at B = 2; only K = 4608 launches at B = 2 gain (3-9 %).  Kept as a tested experiment.  (Also: a persistent
+// one-workgroup-per-CU grid with a static share of the work assumes the whole chip -- never under overlapped collectives.)
 static int g_sk_mode = -1;
 static bool sk_enabled() {
   if (g_sk_mode >= 0) return g_sk_mode != 0;
   const char* e = getenv("VDS_GEMM_SK");
-  return !(e && atoi(e) == 0);
+  return e && atoi(e) == 1;
 }
 constexpr int SK_MIN_TILES = 64;  // fewer 256^2 tiles: the hand-offs cost more than the idle CUs they fill
 

@@ -254,10 +254,4 @@ def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32
             from . import comm
             comm.ensure(process_group)  # the library's own RCCL communicator (vds_comm_*); collective call
         dit_model._fsdp = ShardRuntime(dit_model, cast_fn, process_group)
-        if device.type == "cuda" and world > 1 and world_rank is None and os.environ.get("VDS_GEMM_SK") is None:
-            # stream-K GEMM launches (round 5) are persistent one-workgroup-per-CU grids with a static share of the work
-            # per workgroup: they assume the whole chip.  RCCL's kernels hold CUs while a collective overlaps the GEMMs
-            # of the neighbouring block, so real multi-rank runs take the plain launches (VDS_GEMM_SK=1 overrides).
-            from . import ops
-            ops.gemm_stream_k(0)
     return dit_model
