@@ -179,7 +179,10 @@ typedef struct vds_attn_args {
    * them for hdp >= hd+8; the kernels then fold the per-query constants of the softmax (max, lse, delta)
    * into their MFMAs instead of spending VALU instructions on them.  With the flag the q rows must be
    * padded to head_dim+8 columns as well: vds_attn_bwd OVERWRITES their columns head_dim, head_dim+1
-   * (scratch: -lse*log2(e) as a bf16 hi/lo pair for the dK/dV kernel). */
+   * (scratch: -lse*log2(e) as a bf16 hi/lo pair for the dK/dV kernel).
+   * 2 (round 5; cross-attention, model.py:157): k / v carry the ones columns (vds_kv_pad_ones) but the q rows have NO pad
+   * (token-major views of a linear layer's output): forward and dQ run on the ones-column kernels -- they keep q / dO in
+   * registers and set the pad columns there --, dK/dV on the plain kernel; nothing is written into q. */
   int32_t kv_pad_ones;
   /* backward only: number of floats `delta` points to.  0 = exactly 2*B*H*Lq (the statistics).  With the size
    * vds_attn_bwd_workspace_bytes returns, the dK/dV kernel may split the query range over several workgroups per key
@@ -190,6 +193,11 @@ typedef struct vds_attn_args {
 
 int vds_attn_fwd(const vds_attn_args* args, vds_stream_t stream);
 int vds_attn_bwd(const vds_attn_args* args, vds_stream_t stream);
+/* K / V of a cross-attention, token-major bf16 rows [B*Lk, ld] with head h of K at columns k_col0 + h*hd and of V at
+ * v_col0 + h*hd (the context_kv output, model.py:150-156), copied into head-major padded rows kp, vp [B,H,Lk,hdp]
+ * (hdp >= hd + 8, multiples of 8) with the ones columns of vds_attn_args.kv_pad_ones and zeros in the rest of the pad. */
+int vds_kv_pad_ones(const void* kv, int64_t ld, int32_t k_col0, int32_t v_col0, void* kp, void* vp, int32_t B, int32_t Lk,
+                    int32_t H, int32_t hd, int32_t hdp, vds_stream_t stream);
 /* Tests / experiments: which of the head_dim-72 (ones-column) kernels run on v_mfma_f32_16x16x32_bf16 instead of
  * v_mfma_f32_32x32x16_bf16 -- bit 0: dK/dV, bit 1: dQ, bit 2: forward; -1 = back to the default / VDS_ATTN_MFMA16.
  * Returns the previous mask.  Results agree up to fp32 summation order. */

@@ -910,3 +910,48 @@ def test_gemm_stream_k_random_operands_close_to_plain(ops):
     close("sk.random", y1, ref, 4e-3)
     assert (y1 != y0).float().mean().item() < 0.02
     assert rel(y1, y0) < 2e-3
+
+
+@pytest.mark.parametrize("L,Lc", [(2100, 512), (8208, 512), (2304, 300)], ids=["Lq2100", "headline_8208", "ragged_Lk300"])
+def test_attention_cross_on_the_ones_column_kernels(ops, L, Lc):
+    """round 5 (vds_attn_args.kv_pad_ones = 2): cross-attention with token-major queries and head-major padded K / V copies
+    that carry the ones columns (vds_kv_pad_ones): forward and dQ on the 16x16x32 ones-column kernels, dK/dV on the plain
+    kernel with the query-range split; nothing may be written outside the rows.  Against fp32 attention and against the
+    plain path on the token-major K / V."""
+    B, H, hd, hdp = 2, 3, 72, 96
+    D = H * hd
+    qb, kvb = gen(B * L, D, seed=91), gen(B * Lc, 2 * D, seed=92)
+    qd, kvd = qb.cuda(), kvb.cuda()
+    kp, vp = ops.kv_pad_ones(kvd, B, Lc, H, hd, hdp, 0, D)
+    assert torch.equal(kp[..., :hd].reshape(B, H, Lc, hd), kvd[:, :D].reshape(B, Lc, H, hd).permute(0, 2, 1, 3))
+    assert torch.equal(vp[..., :hd].reshape(B, H, Lc, hd), kvd[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3))
+    pad_k = torch.zeros(hdp - hd); pad_k[0] = pad_k[1] = 1.0
+    pad_v = torch.zeros(hdp - hd); pad_v[0] = pad_v[4] = 1.0
+    assert torch.equal(kp[..., hd:].float().cpu(), pad_k.expand(B, H, Lc, hdp - hd))
+    assert torch.equal(vp[..., hd:].float().cpu(), pad_v.expand(B, H, Lc, hdp - hd))
+    qv = ops.heads_view(qd, B, L, H, hd)
+    o = torch.zeros(B * L, D, dtype=bf16, device="cuda")
+    lse = torch.zeros(B, H, L, dtype=f32, device="cuda")
+    q_before = qd.clone()
+    ops.attn_fwd(qv, kp[..., :hd], vp[..., :hd], ops.heads_view(o, B, L, H, hd), lse, kv_pad_ones=2)
+    o2 = torch.zeros_like(o)
+    lse2 = torch.zeros_like(lse)
+    ops.attn_fwd(qv, ops.heads_view(kvd, B, Lc, H, hd, 0), ops.heads_view(kvd, B, Lc, H, hd, D),
+                 ops.heads_view(o2, B, L, H, hd), lse2)
+    q = qb.reshape(B, L, H, hd).permute(0, 2, 1, 3)
+    k = kvb[:, :D].reshape(B, Lc, H, hd).permute(0, 2, 1, 3)
+    v = kvb[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3)
+    do = gen(B * L, D, seed=93)
+    o_ref, lse_ref, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, do.reshape(B, L, H, hd).permute(0, 2, 1, 3))
+    close("xones.o", o.reshape(B, L, H, hd).permute(0, 2, 1, 3), o_ref, 6e-3)
+    close("xones.lse", lse, lse_ref, 1e-3)
+    close("xones.o_vs_plain", o, o2, 6e-3)
+    dqb, dkvb = torch.zeros_like(qd), torch.zeros_like(kvd)
+    ops.attn_bwd(qv, kp[..., :hd], vp[..., :hd], ops.heads_view(o, B, L, H, hd), lse, ops.heads_view(do.cuda(), B, L, H, hd),
+                 ops.heads_view(dqb, B, L, H, hd), ops.heads_view(dkvb, B, Lc, H, hd, 0),
+                 ops.heads_view(dkvb, B, Lc, H, hd, D), None, kv_pad_ones=2)
+    torch.cuda.synchronize()
+    assert torch.equal(qd, q_before)  # (mode 1 annotates the q pad; mode 2 must not write into q)
+    close("xones.dq", dqb.reshape(B, L, H, hd).permute(0, 2, 1, 3), dq_ref, 8e-3)
+    close("xones.dk", dkvb[:, :D].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dk_ref, 8e-3)
+    close("xones.dv", dkvb[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dv_ref, 8e-3)

@@ -650,7 +650,7 @@ __global__ void attn_delta_kernel(AttnP p) {
     const float l2 = p.lse[row] * LOG2E;
     p.delta[row] = -acc;
     p.delta[rows + row] = l2;
-    if (p.kv_pad_ones) annotate_q(p, b, hh, q, l2);
+    if (p.kv_pad_ones == 1) annotate_q(p, b, hh, q, l2);
   }
 }
 
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void attn_delta_tokmajor_kernel(AttnP p) {
     const float l2 = p.lse[row] * LOG2E;
     p.delta[row] = -acc;
     p.delta[rows + row] = l2;
-    if (p.kv_pad_ones) annotate_q(p, b, lane, q, l2);
+    if (p.kv_pad_ones == 1) annotate_q(p, b, lane, q, l2);
   }
 }
 
@@ -1621,7 +1621,8 @@ int run_fwd(AttnP p, hipStream_t s) {
   const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
   const bool ones_fwd = HDP == 96 && HDQ == 80 && use_wide && p.kv_pad_ones && p.hd == 72;
-  vdsprof::Scope ps(ones_fwd ? VDS_PROF_ATTN_FWD : VDS_PROF_ATTN_FWD_PLAIN, s, fl,
+  // (kv_pad_ones == 2: cross-attention on the ones-column kernels -- keeps its own profiler class)
+  vdsprof::Scope ps(ones_fwd && p.kv_pad_ones == 1 ? VDS_PROF_ATTN_FWD : VDS_PROF_ATTN_FWD_PLAIN, s, fl,
                     2.0 * p.B * p.H * p.hd * (2.0 * p.Lq + 2.0 * p.Lk));
   if constexpr (HDP == 64) {
     if (use_wide) {
@@ -1694,7 +1695,9 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
   int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
   {
     bool ones_kv = false;
-    if constexpr (HDP == 96 && HDQ == 80) ones_kv = p.kv_pad_ones && p.hd == 72;
+    // (kv_pad_ones == 2: the q rows carry no annotated pad -- token-major cross-attention queries -- so the dK/dV pass takes
+    // the plain kernel, which stages -lse2 itself and masks the K / V pad columns)
+    if constexpr (HDP == 96 && HDQ == 80) ones_kv = p.kv_pad_ones == 1 && p.hd == 72;
     vdsprof::Scope ps(ones_kv ? VDS_PROF_ATTN_BWD_DKV : VDS_PROF_ATTN_BWD_DKV_PLAIN, s, 2.0 * prod, 2.0 * qb + 4.0 * kb);
     if constexpr (HDP == 96 && HDQ == 80) {
       if (ones_kv && (attn_variant() & 1))
@@ -1736,7 +1739,7 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
   {
     bool ones = false;
     if constexpr (HDP == 96 && HDQ == 80) ones = p.kv_pad_ones && p.hd == 72;
-    vdsprof::Scope ps(ones ? VDS_PROF_ATTN_BWD_DQ : VDS_PROF_ATTN_BWD_DQ_PLAIN, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
+    vdsprof::Scope ps(ones && p.kv_pad_ones == 1 ? VDS_PROF_ATTN_BWD_DQ : VDS_PROF_ATTN_BWD_DQ_PLAIN, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
     if constexpr (HDP == 96 && HDQ == 80) {
       if (ones && (attn_variant() & 2))
         hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP>), dim3(grid), dim3(256), LDS_DQ, s, p);
@@ -1749,6 +1752,42 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
 }
 
 }  // namespace
+
+// K / V of a cross-attention (token-major [B*Lk, ld] rows, head h at columns col0 + h*hd) -> head-major padded rows
+// [B,H,Lk,hdp] WITH the ones columns of the head_dim-72 kernels (K: 1.0 at hd, hd+1; V: 1.0 at hd, hd+4; zeros elsewhere
+// in the pad), so that the forward and dQ passes of the cross-attention run on the ones-column 16x16x32 kernels
+// (vds_attn_args.kv_pad_ones = 2).  One thread per 16-byte chunk of an output row.
+__global__ __launch_bounds__(256) void kv_pad_ones_kernel(const bf16_t* kv, long ld, int kcol0, int vcol0, bf16_t* kp,
+                                                          bf16_t* vp, int B, int Lk, int H, int hd, int hdp) {
+  const int cpr = hdp >> 3;  // chunks per output row
+  const long n = (long)B * H * Lk * cpr;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n) return;
+  const int which = blockIdx.y;  // 0 K, 1 V
+  const int c = (int)(gid % cpr);
+  const long row = gid / cpr;  // (b, h, l)
+  const int l = (int)(row % Lk);
+  const int h = (int)((row / Lk) % H);
+  const int b = (int)(row / ((long)Lk * H));
+  u32x4 w = {0u, 0u, 0u, 0u};
+  if (c * 8 < hd) {
+    w = *reinterpret_cast<const u32x4*>(kv + ((long)b * Lk + l) * ld + (which ? vcol0 : kcol0) + h * hd + c * 8);
+  } else if (c * 8 == hd) {
+    w[0] = which ? 0x00003f80u : 0x3f803f80u;  // K: 1.0 at hd, hd+1; V: 1.0 at hd ...
+    w[2] = which ? 0x00003f80u : 0u;           // ... and hd+4
+  }
+  *reinterpret_cast<u32x4*>((which ? vp : kp) + row * hdp + c * 8) = w;
+}
+
+extern "C" int vds_kv_pad_ones(const void* kv, int64_t ld, int32_t k_col0, int32_t v_col0, void* kp, void* vp, int32_t B,
+                               int32_t Lk, int32_t H, int32_t hd, int32_t hdp, vds_stream_t stream) {
+  if (!kv || !kp || !vp || B <= 0 || Lk <= 0 || H <= 0 || hd <= 0) return VDS_ERR_ARG;
+  if ((hd & 7) || (hdp & 7) || hdp < hd + 8 || (ld & 7) || (k_col0 & 7) || (v_col0 & 7)) return VDS_ERR_ARG;
+  const long n = (long)B * H * Lk * (hdp >> 3);
+  hipLaunchKernelGGL(kv_pad_ones_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)kv, (long)ld, k_col0, v_col0, (bf16_t*)kp, (bf16_t*)vp, B, Lk, H, hd, hdp);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
 
 extern "C" int vds_attn_set_variant(int32_t mask) {
   const int prev = attn_variant();
@@ -1775,7 +1814,7 @@ extern "C" int vds_attn_fwd(const vds_attn_args* a, vds_stream_t stream) {
 extern "C" size_t vds_attn_bwd_workspace_bytes(const vds_attn_args* a) {
   if (!a || a->B <= 0 || a->H <= 0 || a->Lq <= 0) return 0;
   size_t fl = (size_t)2 * a->B * a->H * a->Lq;
-  if (a->Lk > 0 && a->head_dim > 0 && !a->kv_pad_ones)  // fp32 partials of the query-split dK/dV kernel (short key sequences)
+  if (a->Lk > 0 && a->head_dim > 0 && a->kv_pad_ones != 1)  // fp32 partials of the query-split dK/dV kernel (short key sequences)
     fl += (size_t)dkv_qsplit(a->B, a->H, a->Lq, a->Lk) * a->B * a->H * a->Lk * 2 * a->head_dim;
   return fl * sizeof(float);
 }

@@ -38,6 +38,7 @@ from .params import FlatGroup
 _NO_EMIT = os.environ.get("VDS_FP8_NO_EMIT") == "1"  # experiments: quantise every fp8 operand in a separate pass
 _NO_PRODUCER_EMIT = os.environ.get("VDS_FP8_PRODUCER_EMIT") == "0"  # experiments: only the GEMM epilogues emit fp8
 _NO_ATTN_EMIT = os.environ.get("VDS_FP8_ATTN_EMIT") == "0"  # experiments: attention results quantised in a separate pass
+_CROSS_ONES = os.environ.get("VDS_CROSS_ONES", "1") != "0"  # head_dim 72: cross-attention forward / dQ on the ones-column kernels
 
 bf16, f32 = torch.bfloat16, torch.float32
 N_REG = 16  # register tokens (model.py:316,362,386)
@@ -430,6 +431,14 @@ class DiTBlock(nn.Module):
                 e_catt = ops.attn_fp8_fwd(qc8, kc8, vc8, deqc, ops.heads_view(catt, B, L, H, hd), lse2, hd,
                                           emit=(hist.prev(R0 + F8.ROW_CATT), hist.cur(R0 + F8.ROW_CATT))
                                           if (pemit and f8c and not _NO_ATTN_EMIT) else None)
+            elif _CROSS_ONES and hd == 72:
+                # round 5: forward (and dQ) of the cross-attention on the ones-column 16x16x32 kernels of the self-attention:
+                # K / V get head-major padded copies with the ones columns (512 context rows: a 38 MB copy), the queries stay
+                # token-major (the kernels keep them in registers and set their pad columns there)
+                kp, vp = ops.kv_pad_ones(ckv, B, Lc, H, hd, hdp, 0, D)
+                ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), kp[..., :hd], vp[..., :hd], ops.heads_view(catt, B, L, H, hd),
+                             lse2, kv_pad_ones=2)
+                del kp, vp  # (the backward pass makes them again from ckv: 12 us, nothing extra saved)
             else:
                 ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), ops.heads_view(ckv, B, Lc, H, hd, 0),
                              ops.heads_view(ckv, B, Lc, H, hd, D), ops.heads_view(catt, B, L, H, hd), lse2)
@@ -589,10 +598,15 @@ class DiTBlock(nn.Module):
                                          if emit_dqc else None)
             else:
                 # (workspace sized by the library: statistics + the fp32 partials of its query-split dK/dV launch)
-                ops.attn_bwd(ops.heads_view(bs.qc, B, L, H, hd), ops.heads_view(bs.ckv, B, Lc, H, hd, 0),
-                             ops.heads_view(bs.ckv, B, Lc, H, hd, D), ops.heads_view(bs.catt, B, L, H, hd), bs.lse2,
+                if _CROSS_ONES and hd == 72:
+                    kp, vp = ops.kv_pad_ones(bs.ckv, B, Lc, H, hd, hdp, 0, D)
+                    kvw, vvw, ones = kp[..., :hd], vp[..., :hd], 2
+                else:
+                    kvw, vvw, ones = ops.heads_view(bs.ckv, B, Lc, H, hd, 0), ops.heads_view(bs.ckv, B, Lc, H, hd, D), 0
+                ops.attn_bwd(ops.heads_view(bs.qc, B, L, H, hd), kvw, vvw, ops.heads_view(bs.catt, B, L, H, hd), bs.lse2,
                              ops.heads_view(dcatt, B, L, H, hd), ops.heads_view(dqc, B, L, H, hd),
-                             ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), None)
+                             ops.heads_view(dckv, B, Lc, H, hd, 0), ops.heads_view(dckv, B, Lc, H, hd, D), None,
+                             kv_pad_ones=ones)
                 if bs.c8_on:
                     ops.absmax(dcatt, fp8_hist.cur(R0 + F8.ROW_DOC))
             if G.has(pre + "context_kv.bias"):

@@ -224,15 +224,25 @@ def attn_fwd(q, k, v, o, lse, kv_pad_ones: bool = False):
     a.v, (a.v_sb, a.v_sh, a.v_sl) = _p(v), _st(v)
     a.o, (a.o_sb, a.o_sh, a.o_sl) = _p(o), _st(o)
     a.lse = _p(lse)
-    a.kv_pad_ones = 1 if kv_pad_ones else 0
+    a.kv_pad_ones = int(kv_pad_ones)  # (True = 1: self-attention layout; 2: ones in k / v only, cross-attention)
     check(_lib.load().vds_attn_fwd(C.byref(a), _stream()), f"vds_attn_fwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
+
+
+def kv_pad_ones(kv: torch.Tensor, B: int, Lk: int, H: int, hd: int, hdp: int, k_col0: int, v_col0: int):
+    """kv [B*Lk, ld] token-major bf16 (the context_kv output) -> (k, v) [B,H,Lk,hdp] with the ones columns of the
+    head_dim-72 attention kernels in the pad (vds_kv_pad_ones)"""
+    kp = torch.empty(B, H, Lk, hdp, dtype=bf16, device=kv.device)
+    vp = torch.empty(B, H, Lk, hdp, dtype=bf16, device=kv.device)
+    check(_lib.load().vds_kv_pad_ones(_p(kv), kv.stride(0), k_col0, v_col0, _p(kp), _p(vp), B, Lk, H, hd, hdp, _stream()),
+          "vds_kv_pad_ones")
+    return kp, vp
 
 
 def attn_bwd_workspace_floats(B, H, Lq, Lk, hd, kv_pad_ones: bool = False) -> int:
     """floats of workspace vds_attn_bwd wants: the [2,B,H,Lq] statistics + the fp32 partials of a query-split dK/dV launch"""
     a = AttnArgs()
     a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, hd
-    a.kv_pad_ones = 1 if kv_pad_ones else 0
+    a.kv_pad_ones = int(kv_pad_ones)
     return _lib.load().vds_attn_bwd_workspace_bytes(C.byref(a)) // 4
 
 
@@ -244,7 +254,7 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta=None, kv_pad_ones: bool = Fa
     Lk = k.shape[2]
     a = AttnArgs()
     a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, hd
-    a.kv_pad_ones = 1 if kv_pad_ones else 0
+    a.kv_pad_ones = int(kv_pad_ones)
     if delta is None:
         delta = torch.empty(_lib.load().vds_attn_bwd_workspace_bytes(C.byref(a)) // 4, dtype=f32, device=q.device)
     assert delta.numel() >= 2 * B * H * Lq and delta.is_contiguous(), "attn_bwd: delta workspace is [2,B,H,Lq] f32"
@@ -259,7 +269,7 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, delta=None, kv_pad_ones: bool = Fa
     a.dk, (a.dk_sb, a.dk_sh, a.dk_sl) = _p(dk), _st(dk)
     a.dv, (a.dv_sb, a.dv_sh, a.dv_sl) = _p(dv), _st(dv)
     a.delta = _p(delta)
-    a.kv_pad_ones = 1 if kv_pad_ones else 0
+    a.kv_pad_ones = int(kv_pad_ones)
     check(_lib.load().vds_attn_bwd(C.byref(a), _stream()), f"vds_attn_bwd(B={B},H={H},Lq={Lq},Lk={Lk},hd={hd})")
 
 
