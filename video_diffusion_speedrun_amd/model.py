@@ -431,17 +431,18 @@ class DiTBlock(nn.Module):
                 e_catt = ops.attn_fp8_fwd(qc8, kc8, vc8, deqc, ops.heads_view(catt, B, L, H, hd), lse2, hd,
                                           emit=(hist.prev(R0 + F8.ROW_CATT), hist.cur(R0 + F8.ROW_CATT))
                                           if (pemit and f8c and not _NO_ATTN_EMIT) else None)
-            elif _CROSS_ONES and hd == 72:
-                # round 5: forward (and dQ) of the cross-attention on the ones-column 16x16x32 kernels of the self-attention:
-                # K / V get head-major padded copies with the ones columns (512 context rows: a 38 MB copy), the queries stay
-                # token-major (the kernels keep them in registers and set their pad columns there)
-                kp, vp = ops.kv_pad_ones(ckv, B, Lc, H, hd, hdp, 0, D)
-                ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), kp[..., :hd], vp[..., :hd], ops.heads_view(catt, B, L, H, hd),
-                             lse2, kv_pad_ones=2)
-                del kp, vp  # (the backward pass makes them again from ckv: 12 us, nothing extra saved)
             else:
-                ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), ops.heads_view(ckv, B, Lc, H, hd, 0),
-                             ops.heads_view(ckv, B, Lc, H, hd, D), ops.heads_view(catt, B, L, H, hd), lse2)
+                if _CROSS_ONES and hd == 72:
+                    # round 5: forward (and dQ) of the cross-attention on the ones-column 16x16x32 kernels of the
+                    # self-attention: K / V get head-major padded copies with the ones columns (512 context rows: a 38 MB
+                    # copy), the queries stay token-major (the kernels keep them in registers and set their pad columns there)
+                    kp, vp = ops.kv_pad_ones(ckv, B, Lc, H, hd, hdp, 0, D)
+                    ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), kp[..., :hd], vp[..., :hd],
+                                 ops.heads_view(catt, B, L, H, hd), lse2, kv_pad_ones=2)
+                    del kp, vp  # (the backward pass makes them again from ckv: 12 us, nothing extra saved)
+                else:
+                    ops.attn_fwd(ops.heads_view(qc, B, L, H, hd), ops.heads_view(ckv, B, Lc, H, hd, 0),
+                                 ops.heads_view(ckv, B, Lc, H, hd, D), ops.heads_view(catt, B, L, H, hd), lse2)
                 if c8_on and save:
                     for j, t in enumerate((qc, ckv[:, :D], ckv[:, D:])):
                         ops.absmax(t, fp8_hist.cur(R0 + F8.ROW_QC + j))
