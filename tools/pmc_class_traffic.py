@@ -32,18 +32,48 @@ def klass(name: str):
     return None
 
 
+# Since round 5 the cross-attention's forward and dQ run on the SAME kernels as the self-attention (kv_pad_ones = 2):
+# their dispatches differ in what they fetch (512 context rows of K / V instead of 8208), not in name.  The dispatches of
+# these symbols are split at the midpoint of a counter's range when it is bimodal (max > 1.4 x min): upper cluster = the
+# self-attention class, lower = the cross-attention (`_plain`) class; a counter that does not separate them (both write
+# the same O / dQ) counts for both.
+SHARED = {"attn_fwd": "attn_fwd_plain", "attn_bwd_dq": "attn_bwd_dq_plain"}
+
+
 def section(d: str, batch: int):
     acc = collections.defaultdict(lambda: {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0], "symbols": collections.Counter()})
+    shared = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": [], "sym": None})
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             c = klass(r["Kernel_Name"])
             if c is None or r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
+            sym = re.sub(r"^void |\(anonymous namespace\)::|\(.*$", "", r["Kernel_Name"])
+            if c in SHARED and "16_kernel" in sym:
+                shared[c][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                shared[c]["sym"] = sym
+                continue
             a = acc[c][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"])
             a[1] += 1
-            sym = re.sub(r"^void |\(anonymous namespace\)::|\(.*$", "", r["Kernel_Name"])
             acc[c]["symbols"][sym] += 1
+    for c, v in shared.items():
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals = v[ctr]
+            if not vals:
+                continue
+            lo, hi = min(vals), max(vals)
+            if hi > 1.4 * lo:
+                mid = 0.5 * (lo + hi)
+                groups = {c: [x for x in vals if x >= mid], SHARED[c]: [x for x in vals if x < mid]}
+            else:
+                groups = {c: vals, SHARED[c]: vals if any(x for x in shared[c]["FETCH_SIZE"]) and
+                          max(shared[c]["FETCH_SIZE"]) > 1.4 * min(shared[c]["FETCH_SIZE"]) else []}
+            for cc, g in groups.items():
+                if g:
+                    acc[cc][ctr][0] += sum(g)
+                    acc[cc][ctr][1] += len(g)
+                    acc[cc]["symbols"][v["sym"]] += len(g)
     kernels = {}
     for c, v in sorted(acc.items()):
         if v["FETCH_SIZE"][1] == 0 or v["WRITE_SIZE"][1] == 0:
