@@ -912,12 +912,15 @@ def test_gemm_stream_k_random_operands_close_to_plain(ops):
     assert rel(y1, y0) < 2e-3
 
 
+@pytest.mark.parametrize("dkv16", ["0", "2"], ids=["dkv_plain_qsplit", "dkv16_from_staged_lse"])
 @pytest.mark.parametrize("L,Lc", [(2100, 512), (8208, 512), (2304, 300)], ids=["Lq2100", "headline_8208", "ragged_Lk300"])
-def test_attention_cross_on_the_ones_column_kernels(ops, L, Lc):
+def test_attention_cross_on_the_ones_column_kernels(ops, L, Lc, dkv16, monkeypatch):
     """round 5 (vds_attn_args.kv_pad_ones = 2): cross-attention with token-major queries and head-major padded K / V copies
     that carry the ones columns (vds_kv_pad_ones): forward and dQ on the 16x16x32 ones-column kernels, dK/dV on the plain
-    kernel with the query-range split; nothing may be written outside the rows.  Against fp32 attention and against the
+    kernel with the query-range split or on the 16x16x32 kernel with S started from the staged -lse2 (chosen by the
+    number of workgroups; both forced here); nothing may be written outside the rows.  Against fp32 attention and against the
     plain path on the token-major K / V."""
+    monkeypatch.setenv("VDS_CROSS_DKV16", dkv16)  # 2: the 16x16x32 dK/dV kernel whatever the grid (it needs >= 512 workgroups otherwise)
     B, H, hd, hdp = 2, 3, 72, 96
     D = H * hd
     qb, kvb = gen(B * L, D, seed=91), gen(B * Lc, 2 * D, seed=92)

@@ -1032,7 +1032,10 @@ __device__ __forceinline__ bf16x8 pack2(const f32x4& a, const f32x4& b) {
   return r;
 }
 
-template <int HDP>
+// QPAD = false (round 5, cross-attention: vds_attn_args.kv_pad_ones = 2): the q rows carry no annotated pad (token-major
+// views of a linear layer's output), so only head_dim columns of a q row are staged and the S accumulators START from
+// -lse2 of their queries, read from the statistics this kernel stages beside -delta anyway.
+template <int HDP, bool QPAD = true>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
   static_assert(HDP == 96, "head_dim 72 layout (ones columns at 72, 73)");
   constexpr int KS = HDP / 32, NDB = 5, Q_TILE = 64 * HDP * 2;
@@ -1046,7 +1049,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int key0 = kt_idx * 128 + wave * 32;
 
-  const int hd_q = p.hd + 8;  // Q rows are staged with their pad: -lse*log2(e) as (hi, lo) at columns hd, hd+1
+  const int hd_q = QPAD ? p.hd + 8 : p.hd;  // QPAD: Q rows are staged with their pad: -lse*log2(e) as (hi, lo) at columns hd, hd+1
   const srd_t rq = slice_srd(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, hd_q);
   const srd_t rdo = slice_srd(p.d_o + b * p.do_sb + hh * p.do_sh, p.do_sl, p.Lq, p.hd);
   const __amdgpu_buffer_rsrc_t rk = slice_rsrc(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, p.hd);
@@ -1124,8 +1127,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qb * 32 + rb * 16 + 4 * g);  // -delta of rows 4g..
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!QPAD) s0 = -*reinterpret_cast<const f32x4*>(stl + qb * 32 + rb * 16 + 4 * g);  // -lse2 of rows 4g..
 #pragma unroll
-        for (int cb = 0; cb < NKB; ++cb) { s[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[rb][cb] = d4; }
+        for (int cb = 0; cb < NKB; ++cb) { s[rb][cb] = s0; dp[rb][cb] = d4; }
       }
       PRIO_HI();
 #pragma unroll
@@ -1670,6 +1675,7 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
     set_lds(attn_bwd_dkv_kernel<HDP, HDQ, false>, LDS_DKV);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv_kernel<HDP, HDQ, true>, LDS_DKV);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv16_kernel<HDP>, LDS_DKV);
+    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv16_kernel<HDP, false>, LDS_DKV);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dq16_kernel<HDP>, LDS_DQ);
     once = true;
   }
@@ -1705,7 +1711,18 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
       else if (ones_kv)
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DKV, s, p);
     }
-    if (!ones_kv) {
+    bool done16 = false;
+    if constexpr (HDP == 96 && HDQ == 80) {
+      // cross-attention with padded K / V (kv_pad_ones = 2) and enough workgroups to fill the chip once (B*H*n_rt >= 512;
+      // the query-range split below exists in the plain kernel only): the 16x16x32 kernel with S started from -lse2
+      const char* e16 = getenv("VDS_CROSS_DKV16");  // (read per call: 0 = plain kernel, 2 = also for small grids; tests)
+      const int x16 = e16 ? atoi(e16) : 1;
+      if (!ones_kv && p.kv_pad_ones == 2 && p.hd == 72 && x16 && ((long)grid >= 512 || x16 == 2) && (attn_variant() & 1)) {
+        hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false>), dim3(grid), dim3(256), LDS_DKV, s, p);
+        done16 = true;
+      }
+    }
+    if (!ones_kv && !done16) {
       // few key tiles per head (cross-attention): B*H*n_rt workgroups leave most of the 2 x 256 slots empty (B = 2: 128
       // of 512) or end on a half-filled round (B = 12: 768 = 1.5 rounds).  The query range is then split so that the
       // launch is ~3 rounds of proportionally shorter workgroups; the fp32 partials (q_split x B*H*Lk*2*hd floats, at
