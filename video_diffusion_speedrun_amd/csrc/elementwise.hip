@@ -150,6 +150,72 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const bf16_t* x, l
   if constexpr (QF >= 0) qs.finish();
 }
 
+// Four rows per wave (round 5): D = 1152 is 144 chunks of 16 bytes = 2.25 wave-instructions per row in the mapping above,
+// i.e. the third load / store of every row runs with 16 of 64 lanes (measured, tools/bench_rmsnorm_width.py: 4.67 TB/s at
+// D = 1152 against 5.39 at D = 1024 and 5.31 at D = 1536).  Here each 16-lane group of a wave owns one of four
+// consecutive rows and a lane the chunks lane16 + 16 i, i < NCQ = D / 128: every instruction has all 64 lanes at work
+// (9 instead of 12 instructions per stream for four rows), the row statistics reduce over 16 lanes.  Same arithmetic
+// per element; the sum of squares is taken in a different order (16 partial sums of 9 x 8 terms instead of 64 of 3 x 8).
+// DiT-S / B / XL widths: D = 384, 768, 1152 (NCQ = 3, 6, 9).
+template <int NCQ, int QF = -1>
+__global__ __launch_bounds__(256) void rmsnorm_mod_fwd_q4_kernel(const bf16_t* x, long ldx, const bf16_t* w,
+                                                                 const float* mod, long ldmod, int shift_col,
+                                                                 int scale_col, bf16_t* y, long ldy, float* rstd,
+                                                                 int B, int L, float eps, QOut qo) {
+  constexpr int D = NCQ * 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * 4;  // first of this wave's four rows
+  const long rows = (long)B * L;
+  if (row0 >= rows) return;
+  QState<(QF < 0 ? 0 : QF)> qs;
+  if constexpr (QF >= 0) qs.init(qo, blockIdx.x == 0 && threadIdx.x == 0, row0);
+  const long row = row0 + (lane >> 4);
+  const bool live = row < rows;
+  const long rowc = live ? row : rows - 1;  // (idle groups of the last wave compute on a valid row and store nothing)
+  const int b = (int)(rowc / L);
+  u32x4 raw[NCQ];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCQ; ++i) {
+    raw[i] = ld_stream<8>(x + rowc * ldx + (l16 + 16 * i) * 8);
+    float v[8];
+    unpack8(raw[i], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // over the 16 lanes of the row
+  const float r = rsqrtf(ss / (float)D + eps);
+  if (l16 == 0 && live) rstd[row] = r;
+  const float* mrow = mod + (long)b * ldmod;
+#pragma unroll
+  for (int i = 0; i < NCQ; ++i) {
+    const int c = l16 + 16 * i;
+    float sh[8], sc[8], o[8], wv[8], v[8];
+    load8f(mrow + shift_col + c * 8, sh);
+    load8f(mrow + scale_col + c * 8, sc);
+    if (w) unpack8(*reinterpret_cast<const u32x4*>(w + c * 8), wv);
+    unpack8(raw[i], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xn = v[e] * r;
+      if (w) xn *= wv[e];
+      o[e] = xn * (1.0f + sc[e]) + sh[e];
+    }
+    if constexpr (QF >= 0) {
+      const u32x2 q8 = qs.cvt(o);  // (every lane converts: the wave's amax covers its live rows only, see below)
+      if (live) *reinterpret_cast<u32x2*>(qo.q + row * qo.ldq + c * 8) = q8;
+    } else {
+      if (live) st_stream<8>(y + row * ldy + c * 8, pack8(o));
+    }
+  }
+  if constexpr (QF >= 0) {
+    if (!live) qs.mxf = 0.f;  // an idle group repeated the last row: nothing of its own to record
+    qs.finish();
+  }
+}
+
 // (Measured negative, round 2: requesting the next row's dy / x / dres one row ahead in registers -- 36 more VGPRs --
 // dropped the kernel below its 3 waves per SIMD and tripled its time; occupancy, not an explicit prefetch, is what
 // keeps the loads in flight here.)
@@ -1194,6 +1260,14 @@ inline int rows_per_block_for(int L, int B) {
     else return VDS_ERR_UNSUPPORTED;               \
   } while (0)
 
+// widths whose 16-byte chunk count is a multiple of 16 but not of 64 (D = 384, 768, 1152): the four-rows-per-wave form
+// of the RMSNorm kernels; VDS_RMSNORM_Q4=0 (read per call) keeps the one-row-per-wave form (A/B)
+static bool rmsnorm_q4(int D) {
+  if (D != 384 && D != 768 && D != 1152) return false;
+  const char* e = getenv("VDS_RMSNORM_Q4");
+  return !(e && atoi(e) == 0);
+}
+
 extern "C" int vds_rmsnorm_mod_fwd(const void* x, int64_t ldx, const void* w, const float* mod, int64_t ldmod,
                                    int32_t shift_col, int32_t scale_col, void* y, int64_t ldy, float* rstd,
                                    int32_t B, int32_t L, int32_t D, float eps, vds_stream_t stream) {
@@ -1202,6 +1276,17 @@ extern "C" int vds_rmsnorm_mod_fwd(const void* x, int64_t ldx, const void* w, co
   const long rows = (long)B * L;
   hipStream_t s = (hipStream_t)stream;
   vdsprof::Scope ps(VDS_PROF_RMSNORM_FWD, s, 0.0, 4.0 * rows * D + 4.0 * rows);
+  if (rmsnorm_q4(D)) {  // DiT-S / B / XL widths: four rows per wave, every lane of every instruction at work
+#define CALLQ(NCQ)                                                                                             \
+  hipLaunchKernelGGL((rmsnorm_mod_fwd_q4_kernel<NCQ>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s,     \
+                     (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col,   \
+                     (bf16_t*)y, (long)ldy, rstd, B, L, eps, QOut{})
+    if (D == 384) CALLQ(3);
+    else if (D == 768) CALLQ(6);
+    else CALLQ(9);
+#undef CALLQ
+    return ok();
+  }
 #define CALL(NC)                                                                                              \
   hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NC>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,          \
                      (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col, \
@@ -1226,6 +1311,24 @@ extern "C" int vds_rmsnorm_mod_fwd_fp8(const void* x, int64_t ldx, const void* w
   hipStream_t s = (hipStream_t)stream;
   const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_part, dq_out};
   vdsprof::Scope ps(VDS_PROF_RMSNORM_FWD, s, 0.0, 3.0 * rows * D + 4.0 * rows);
+  if (rmsnorm_q4(D)) {
+#define CALLQ(NCQ)                                                                                               \
+  do {                                                                                                           \
+    if (fmt == 0)                                                                                                \
+      hipLaunchKernelGGL((rmsnorm_mod_fwd_q4_kernel<NCQ, 0>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, \
+                         (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col,   \
+                         (bf16_t*)nullptr, 0L, rstd, B, L, eps, qo);                                             \
+    else                                                                                                         \
+      hipLaunchKernelGGL((rmsnorm_mod_fwd_q4_kernel<NCQ, 1>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, \
+                         (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col,   \
+                         (bf16_t*)nullptr, 0L, rstd, B, L, eps, qo);                                             \
+  } while (0)
+    if (D == 384) CALLQ(3);
+    else if (D == 768) CALLQ(6);
+    else CALLQ(9);
+#undef CALLQ
+    return ok();
+  }
 #define CALL(NC)                                                                                               \
   do {                                                                                                         \
     if (fmt == 0)                                                                                              \
