@@ -958,3 +958,46 @@ def test_attention_cross_on_the_ones_column_kernels(ops, L, Lc, dkv16, monkeypat
     close("xones.dq", dqb.reshape(B, L, H, hd).permute(0, 2, 1, 3), dq_ref, 8e-3)
     close("xones.dk", dkvb[:, :D].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dk_ref, 8e-3)
     close("xones.dv", dkvb[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dv_ref, 8e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(20000, 1152, 328), (98496, 1152, 192), (16416, 3456, 1152), (66000, 1024, 136)])
+def test_gemm_persistent_kernel_is_bit_identical(ops, M, N, K, monkeypatch):
+    """round 5 (VDS_GEMM_PK=1): the persistent form of the 256^2 kernel -- one workgroup per CU with a host-built tile list,
+    the next tile's first K tile issued under the epilogue, epilogue staged in 32-row steps through the second ring buffer
+    -- runs the same products in the same order: every fused epilogue must give the bits of the plain launch (the second
+    run takes the cached lists)."""
+    B = 2 if M % 2 == 0 else 1
+    L = M // B
+    x, w, b = gen(M, K, seed=61), gen(N, K, seed=62, scale=0.05), gen(N, seed=63, scale=0.3)
+    res, mod = gen(M, N, seed=64), gen(B, 3 * N, seed=65, dtype=f32)
+    dy, w2, pre = gen(M, K, seed=66), gen(K, N, seed=67, scale=0.05), gen(M, N, seed=68)
+
+    def run():
+        out = {}
+        out["store"] = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
+        out["pre"], out["act"] = ops.linear_fwd_gelu(x.cuda(), w.cuda(), b.cuda())
+        out["y"], out["xn"] = ops.linear_fwd_gate_res(x.cuda(), w.cuda(), b.cuda(), mod.cuda(), 2 * N, res.cuda(), L)
+        out["nn"] = ops.linear_dgrad(dy.cuda(), w2.cuda())
+        cs = torch.zeros(N, dtype=f32, device="cuda")
+        out["dgelu"] = ops.linear_dgrad(dy.cuda(), w2.cuda(), pre.cuda(), colsum=cs)
+        out["cs"] = cs
+        torch.cuda.synchronize()
+        return out
+
+    ops.gemm_force_tile(256)
+    try:
+        monkeypatch.setenv("VDS_GEMM_PK", "0")
+        ref = run()
+        monkeypatch.setenv("VDS_GEMM_PK", "1")
+        got = run()
+        got2 = run()
+    finally:
+        ops.gemm_force_tile(0)
+    for k in ref:
+        if k == "cs":  # fp32 atomics across workgroups: order-dependent in the last bits
+            close("pk.cs", got[k], ref[k], 1e-5)
+            close("pk.cs2", got2[k], ref[k], 1e-5)
+        else:
+            assert torch.equal(got[k], ref[k]), k
+            assert torch.equal(got2[k], ref[k]), k
+    close("pk.store", got["store"], x.float() @ w.float().t() + b.float(), 4e-3)

@@ -216,14 +216,15 @@ __device__ __forceinline__ unsigned cvt4_fp8(int fmt, float a, float b, float c,
 // for all 8 row groups of the sub-tile BEFORE the accumulators are staged through LDS, so that the 8 loads are in
 // flight together and under the staging instead of one exposed HBM round trip per row group behind the stores.
 // WC: columns of the staged sub-tile that exist (64; 48 in the 256 x 192 tiling, whose lanes c8 >= 6 idle)
-template <int EPI, int WC = 64>
-__device__ __forceinline__ void epilogue_prefetch(const GemmP& p, int row0, int col0, int lane, u32x4 (&auxr)[8]) {
+// NIT: row groups of 8 rows per staged sub-tile (8: 64 rows; 4: the 32-row steps of the compact staging, see gemm_tile)
+template <int EPI, int WC = 64, int NIT = 8>
+__device__ __forceinline__ void epilogue_prefetch(const GemmP& p, int row0, int col0, int lane, u32x4 (&auxr)[NIT]) {
   if constexpr (EPI == VDS_EPI_GATE_RES || EPI == VDS_EPI_DGELU) {
     const int c8 = lane & 7, rin = lane >> 3;
     const int gcol = col0 + c8 * 8;
     const bool cok = gcol < p.N && (WC == 64 || c8 * 8 < WC);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const long grow = row0 + it * 8 + rin;
 #if VDS_GEMM_AUX_NT  // the aux tile (residual / pre-activation) is read exactly once per launch
       auxr[it] = (grow < p.M && cok) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.aux + grow * p.ldaux + gcol))
@@ -236,9 +237,9 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmP& p, int row0, int 
   }
 }
 
-template <int EPI, bool EMIT = false, bool LUT = false, int WC = 64>
+template <int EPI, bool EMIT = false, bool LUT = false, int WC = 64, int NIT = 8>
 __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int row0, int col0, int lane,
-                                               float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8],
+                                               float (&cs)[8], u32x2 (&ew)[NIT], const u32x4 (&auxr)[NIT],
                                                const char* lut = nullptr) {
   if constexpr (EPI == VDS_EPI_F32) {
     if (p.atomic) {
@@ -247,7 +248,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
       const int acol = col0 + lane;
       if (acol < p.N && lane < WC) {
         float* cbase = reinterpret_cast<float*>(p.C) + (long)row0 * p.ldc + acol;
-        const int rmax = min(64, p.M - row0);
+        const int rmax = min(8 * NIT, p.M - row0);
         for (int row = 0; row < rmax; ++row) atomicAdd(cbase + (long)row * p.ldc, stg[row * EPI_LD + lane]);
       }
       return;
@@ -278,7 +279,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
     }
   }
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     const int row = it * 8 + rin;
     const long grow = row0 + row;
     if constexpr (EMIT) ew[it] = u32x2{0u, 0u};
@@ -374,16 +375,16 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
 // results as epilogue_64x64<.., LUT = true>.  e_max: running |max| of the emitted values (the caller folds it).
 // The bf16 results leave with non-temporal stores: each is 0.2-0.9 GB written once and read by a later kernel from HBM
 // anyway, and keeping it out of the way of the operands in L2 / MALL measured -4.5 ms (bf16) / -6.5 ms (fp8) per step.
-template <int EPI, int EFMT, bool C1, bool C2, bool EQ, bool CS, int WC = 64>
+template <int EPI, int EFMT, bool C1, bool C2, bool EQ, bool CS, int WC = 64, int NIT = 8>
 __device__ __forceinline__ void epilogue_full(const GemmP& p, const float* stg, const char* lut, int row0, int col0, int lane,
-                                              float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8], float e_scale,
+                                              float (&cs)[8], u32x2 (&ew)[NIT], const u32x4 (&auxr)[NIT], float e_scale,
                                               float& e_max) {
   const int c8 = lane & 7, rin = lane >> 3;
   if constexpr (WC < 64) {
     if (c8 * 8 >= WC) {  // 256 x 192 tiling: the wave's sub-tile is 48 columns wide, lanes of chunks 6, 7 have no columns
       if constexpr (EQ) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) ew[it] = u32x2{0u, 0u};
+        for (int it = 0; it < NIT; ++it) ew[it] = u32x2{0u, 0u};
       }
       return;
     }
@@ -413,7 +414,7 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, const float* stg, 
   constexpr float FMAX = EFMT == 0 ? 448.0f : 57344.0f;
   const float* sp = stg + rin * EPI_LD + c8 * 8;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     const f32x4 lo = *reinterpret_cast<const f32x4*>(sp + it * 8 * EPI_LD);
     const f32x4 hi = *reinterpret_cast<const f32x4*>(sp + it * 8 * EPI_LD + 4);
     const f32x2 v[4] = {f32x2{lo[0], lo[1]}, f32x2{lo[2], lo[3]}, f32x2{hi[0], hi[1]}, f32x2{hi[2], hi[3]}};
@@ -477,9 +478,9 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, const float* stg, 
 }
 
 // picks the specialisation for the outputs this launch has; false = not covered (the caller takes epilogue_64x64)
-template <int EPI, bool EMIT, int WC = 64>
+template <int EPI, bool EMIT, int WC = 64, int NIT = 8>
 __device__ __forceinline__ bool epilogue_full_dispatch(const GemmP& p, const float* stg, const char* lut, int row0, int col0,
-                                                       int lane, float (&cs)[8], u32x2 (&ew)[8], const u32x4 (&auxr)[8],
+                                                       int lane, float (&cs)[8], u32x2 (&ew)[NIT], const u32x4 (&auxr)[NIT],
                                                        float e_scale, float& e_max) {
   const bool c1 = p.C != nullptr, c2 = p.C2 != nullptr;
   [[maybe_unused]] bool eq = false, eany = false, csum = false;
@@ -488,7 +489,7 @@ __device__ __forceinline__ bool epilogue_full_dispatch(const GemmP& p, const flo
     eany = p.e_q || p.e_qt;
     csum = p.e_colsum != nullptr;
   }
-#define VDS_FULL(E, F, A, B, Q, S) epilogue_full<E, F, A, B, Q, S, WC>(p, stg, lut, row0, col0, lane, cs, ew, auxr, e_scale, e_max)
+#define VDS_FULL(E, F, A, B, Q, S) epilogue_full<E, F, A, B, Q, S, WC, NIT>(p, stg, lut, row0, col0, lane, cs, ew, auxr, e_scale, e_max)
   if constexpr (EPI == VDS_EPI_STORE) {
     VDS_FULL(EPI, 0, true, false, false, false);
     return true;
@@ -814,9 +815,19 @@ __host__ __device__ __forceinline__ void tile_of(int L, int nwg, int tiles_m, in
 // One output tile: rows m0 .. m0 + 255, columns n0 .. n0 + BN - 1, K tiles kt_begin .. kt_end - 1.
 // first: the workgroup's first tile (persistent kernel: later tiles synchronise on the LDS ring first and find the GELU
 // table already staged).
-template <int LAYOUT, int EPI, int FMT, int WN, int NPH>
+// CST (persistent kernel, round 5): compact epilogue staging -- 32-row steps through the SECOND ring buffer only (8 waves x
+// 32 x EPI_LD floats = 69632 B behind the first buffer's 65536) -- so that the NEXT tile's first K tile (`nx`: its four
+// half-tiles, issued here right after the ring has drained) can land in the first ring buffer while this tile's epilogue
+// runs; the next call (`pre`) then only adds the second K tile's three half-tiles.  The stores of the epilogue are
+// younger than those DMAs and older than the second K tile's, so the ordinary counted wait still retires the first K tile.
+struct NextTile { int m0, n0, narrow; };  // m0 < 0: none
+// persistent kernel (gemm_pk_kernel): what gemm_tile needs to start the NEXT tile of the workgroup's list under this tile's
+// epilogue -- its list index (< 0: this was the last one) and the geometry tile_of wants
+struct PkCtx { int T; int next; int tiles_m, tiles_n, group_m, narrow; };
+template <int LAYOUT, int EPI, int FMT, int WN, int NPH, bool CST = false>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int m0, const int n0, const int kt_begin,
-                                          const int kt_end, const SkSeg& sk, const bool first) {
+                                          const int kt_end, const SkSeg& sk, const bool first, const bool pre = false,
+                                          const PkCtx* pk = nullptr) {
   static_assert(FMT == 0 || (FMT != 3 && LAYOUT == VDS_NT) || (FMT == 3 && LAYOUT == VDS_TN && WN != 192),
                 "fp8 operands: k-contiguous (FMT 1 / 2, NT) or both k-major (FMT 3, TN: the weight gradient)");
   using G = Geo<WN>;
@@ -941,7 +952,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   // re-staged one phase after its last read (the distances of the four-phase loop below, which NPH = 4 keeps for A/B:
   // VDS_GEMM_PHASES=4).  Same-process A/B, B = 12 (profiles/r04/gemm_2phase_vs_4phase.log): qkv forward 0.705 -> 0.668
   // ms, q_cross 0.252 -> 0.237, fc1 dgrad 0.945 -> 0.908, 8192^3 1.40 -> 1.50 PFLOP/s; results bit-identical.
-  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0);
+  if (!(CST && pre)) { issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0); }
   issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1); issue(kt_begin + 1, 2, 1);
   VDS_WAIT_VM(8);
   __builtin_amdgcn_s_barrier();
@@ -992,7 +1003,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   } else if constexpr (WN == 128) {
   // ---- narrow last tile column: A0 B0 | A1 per K tile (6 pieces per wave), two phases of 16 MFMAs; the waits leave 6
   // pieces (three half-tiles) in flight; retire / re-stage distances as in the two-phase loop above
-  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 3, 0);
+  if (!(CST && pre)) { issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 3, 0); }
   issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1);
   VDS_WAIT_VM(6);
   __builtin_amdgcn_s_barrier();
@@ -1188,10 +1199,13 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
     if (tid == 0) __hip_atomic_store(sk.flag + sk.w * SK_FLAG_PITCH, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  u32x4 auxr2[2][8];
+  constexpr int NIT = CST ? 4 : 8;        // row groups of 8 rows per staging step
+  constexpr int NSTEP = 16 / NIT;         // steps per wave tile of 128 rows
+  constexpr int RSTEP = 8 * NIT;          // rows per step
+  u32x4 auxr2[NSTEP][NIT];
 #pragma unroll
-  for (int qa = 0; qa < 2; ++qa)
-    epilogue_prefetch<EPI, G::WCOLS>(p, m0 + wr * 128 + qa * 64, n0 + wc * G::WCOLS, lane, auxr2[qa]);
+  for (int st = 0; st < NSTEP; ++st)
+    epilogue_prefetch<EPI, G::WCOLS, NIT>(p, m0 + wr * 128 + st * RSTEP, n0 + wc * G::WCOLS, lane, auxr2[st]);
   if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
   // the zero-fill tail DMAs target LDS the epilogue reuses
   // (a wave whose sub-tile sticks out of the matrix may have issued fewer than 16: it drains everything)
@@ -1200,6 +1214,40 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   if (aux_all) VDS_WAIT_VM(16);
   else VDS_WAIT_VM(0);
   __builtin_amdgcn_s_barrier();
+
+  if constexpr (CST && FMT != 3) {
+    NextTile nx = NextTile{-1, -1, 0};
+    if (pk && pk->next >= 0) {
+      int tm2, tn2;
+      tile_of(pk->next, pk->T, pk->tiles_m, pk->tiles_n, pk->group_m, tm2, tn2);
+      nx = NextTile{tm2 * BM, tn2 * 256, (pk->narrow && tn2 == pk->tiles_n - 1) ? 1 : 0};
+    }
+    if (nx.m0 >= 0) {
+      // the ring has drained and every wave is past its last fragment read: the next tile's first K tile goes into ring
+      // buffer 0 now (the epilogue below stages behind it); offsets of THIS tile are dead, their registers are reused
+      half_offsets<A_KM, 64, 128, 0, 2>(va[0], ca[0], wave, lane, p.lda, nx.m0);
+      half_offsets<A_KM, 64, 128, 64, 2>(va[1], ca[1], wave, lane, p.lda, nx.m0);
+      char* buf0 = ring;
+      const int krem0 = p.K;
+      if (nx.narrow) {
+        unsigned vn[2];
+        int cn[2];
+        half_offsets<B_KM, 32, 32, 0, 2>(vn, cn, wave, lane, p.ldb, nx.n0);
+        issue_half<A_KM>(ra, buf0 + SLOT_A0, va[0], ca[0], 0u, krem0, wave);
+        issue_half<B_KM>(rb, buf0 + SLOT_B0, vn, cn, 0u, krem0, wave);
+        issue_half<A_KM>(ra, buf0 + SLOT_A1, va[1], ca[1], 0u, krem0, wave);
+      } else {
+        unsigned vn0[2], vn1[2];
+        int cn0[2], cn1[2];
+        half_offsets<B_KM, 32, 64, 0, 2>(vn0, cn0, wave, lane, p.ldb, nx.n0);
+        half_offsets<B_KM, 32, 64, 32, 2>(vn1, cn1, wave, lane, p.ldb, nx.n0);
+        issue_half<A_KM>(ra, buf0 + SLOT_A0, va[0], ca[0], 0u, krem0, wave);
+        issue_half<B_KM>(rb, buf0 + SLOT_B0, vn0, cn0, 0u, krem0, wave);
+        issue_half<B_KM>(rb, buf0 + SLOT_B1, vn1, cn1, 0u, krem0, wave);
+        issue_half<A_KM>(ra, buf0 + SLOT_A1, va[1], ca[1], 0u, krem0, wave);
+      }
+    }
+  }
 
   // ---- stream-K finisher (sk.follow != 0): wait for the workgroups that computed the later K tiles of this tile; their
   // slabs are added while the accumulators are staged below.  (The accumulators themselves are never modified: an add
@@ -1222,14 +1270,15 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
     __syncthreads();
   }
 
-  float* stg = reinterpret_cast<float*>(ring) + wave * 64 * EPI_LD;
+  constexpr int STG_BASE = CST ? 65536 : 0, STG_WAVE = RSTEP * EPI_LD;  // (floats per wave)
+  float* stg = reinterpret_cast<float*>(ring + STG_BASE) + wave * STG_WAVE;
   float dq = 1.0f;
   if constexpr (FMT != 0) dq = (p.sa ? *p.sa : 1.0f) * (p.sb ? *p.sb : 1.0f);
   // EMIT also serves the bf16 DGELU GEMM: no fp8 copies there (e_q / e_qt are null), only the column sums of its
   // result -- the fc1 bias gradient -- folded into the epilogue instead of a separate pass over the [tokens, 4D] tensor
   constexpr bool EMIT = (FMT != 0 && (EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU)) || (FMT == 0 && EPI == VDS_EPI_DGELU);
   float cs[8];  // EMIT: per-lane partial column sums of the emitted result over both quadrant rows
-  u32x2 ew[2][8];  // EMIT: the fp8 bytes of both quadrant rows (for the transposed copy)
+  u32x2 ew[NSTEP][NIT];  // EMIT: the fp8 bytes of every staging step (for the transposed copy)
 #pragma unroll
   for (int e = 0; e < 8; ++e) cs[e] = 0.f;
   [[maybe_unused]] float e_scale = 1.0f, e_max = 0.f;
@@ -1241,20 +1290,20 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   }
   const char* lut = smem;
 #pragma unroll
-  for (int qa = 0; qa < 2; ++qa) {
-    const u32x4 (&auxr)[8] = auxr2[qa];
-    const int row0 = m0 + wr * 128 + qa * 64, col0 = n0 + wc * WCOLS;
+  for (int qa = 0; qa < NSTEP; ++qa) {
+    const u32x4 (&auxr)[NIT] = auxr2[qa];
+    const int row0 = m0 + wr * 128 + qa * RSTEP, col0 = n0 + wc * WCOLS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RSTEP / 16; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {  // lane (c, g): row i * 16 + c, columns j * 16 + 4 g .. + 3 (see `mma`)
-        f32x4 v = acc[qa * 4 + i][j];
+        f32x4 v = acc[qa * (RSTEP / 16) + i][j];
         if (follow != 0ull) {  // (wave-uniform; sc1 loads: the hand-off's rule is that EVERY load of a slab bypasses L1)
           for (unsigned long long rest = follow; rest != 0ull; rest &= rest - 1ull) {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(sk.slab + (long)(sk.w + 1 + __builtin_ctzll(rest)) * SK_SLAB_FLOATS,
                                                         SK_SLAB_FLOATS * 4);
             v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                     rs, (unsigned)(((wave * 32 + (qa * 4 + i) * NJ + j) * 64 + lane) * 16), 0, 16 /* sc1 */));
+                     rs, (unsigned)(((wave * 32 + (qa * (RSTEP / 16) + i) * NJ + j) * 64 + lane) * 16), 0, 16 /* sc1 */));
           }
         }
         if constexpr (FMT != 0) v *= dq;
@@ -1263,12 +1312,12 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
     VDS_WAIT_LGKM0();
     __builtin_amdgcn_wave_barrier();
     // sub-tiles completely inside the matrix (all but the last row / column of tiles) take the lean path
-    bool full = row0 + 64 <= p.M && col0 + WCOLS <= p.N;
-    if constexpr (EPI == VDS_EPI_GATE_RES) full = full && ((row0 + p.row_base) % p.rows_per_batch) + 64 <= p.rows_per_batch;
+    bool full = row0 + RSTEP <= p.M && col0 + WCOLS <= p.N;
+    if constexpr (EPI == VDS_EPI_GATE_RES) full = full && ((row0 + p.row_base) % p.rows_per_batch) + RSTEP <= p.rows_per_batch;
     if constexpr (EPI == VDS_EPI_F32) full = false;
     bool done = false;
-    if (full) done = epilogue_full_dispatch<EPI, EMIT, WCOLS>(p, stg, lut, row0, col0, lane, cs, ew[qa], auxr, e_scale, e_max);
-    if (!done) epilogue_64x64<EPI, EMIT, USE_LUT, WCOLS>(p, stg, row0, col0, lane, cs, ew[qa], auxr, lut);
+    if (full) done = epilogue_full_dispatch<EPI, EMIT, WCOLS, NIT>(p, stg, lut, row0, col0, lane, cs, ew[qa], auxr, e_scale, e_max);
+    if (!done) epilogue_64x64<EPI, EMIT, USE_LUT, WCOLS, NIT>(p, stg, row0, col0, lane, cs, ew[qa], auxr, lut);
     __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
   }
   if (follow != 0ull) {  // every wave has read its slab values: lower the producers' flags for the next launch
@@ -1287,7 +1336,8 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
     }
   }
   if constexpr (EMIT) {
-    if (p.e_qt) {
+    // (the transposed copy's byte tile needs 9216 B of staging per wave: not in the compact layout; its launcher avoids it)
+    if (!CST && p.e_qt) {
       // transposed fp8 copy of the wave's 128 x 64 outputs: the staging area (fp32 tiles consumed) becomes a
       // [128 m][64 k] byte tile (72-byte rows), read back as 4x4 byte blocks, transposed in registers (v_perm_b32)
       // and stored as 128 contiguous bytes per k row and instruction
@@ -1295,9 +1345,9 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
       unsigned char* bt = reinterpret_cast<unsigned char*>(stg);
       const int c8 = lane & 7, rin = lane >> 3;
 #pragma unroll
-      for (int qa = 0; qa < 2; ++qa)
+      for (int qa = 0; qa < NSTEP; ++qa)
 #pragma unroll
-        for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x2*>(bt + (qa * 64 + it * 8 + rin) * TLD + c8 * 8) = ew[qa][it];
+        for (int it = 0; it < NIT; ++it) *reinterpret_cast<u32x2*>(bt + (qa * RSTEP + it * 8 + rin) * TLD + c8 * 8) = ew[qa][it];
       VDS_WAIT_LGKM0();
       __builtin_amdgcn_wave_barrier();
       const int mq = lane & 31;
@@ -1339,7 +1389,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
         for (int e = 0; e < 8; ++e) stg[lane * 8 + e] = cs[e];
       __syncthreads();
       if (wr == 0 && lane < WCOLS / 8) {
-        const float* other = reinterpret_cast<const float*>(ring) + (wave + 4) * 64 * EPI_LD;
+        const float* other = reinterpret_cast<const float*>(ring + STG_BASE) + (wave + 4) * STG_WAVE;
         const int gcol = n0 + wc * WCOLS + lane * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -1461,6 +1511,41 @@ int launch(const GemmP& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 
+// ---- persistent kernel with the next tile's first K tile under the epilogue (round 5) ---------------------------------
+// One workgroup per CU, each with its own list of tiles, built on the host (pk_schedule below) and copied into LDS when the
+// kernel starts: no tile counter.  (The first version drew tiles from per-XCD atomic counters.  A returning atomic is a
+// poor fit for this kernel: hipcc waits for it where its value is formed -- the drawing wave, and behind it the workgroup
+// at its next barrier, stands for the 1-2 us round trip, as much as the overlap saves -- and issued from inline asm, to be
+// collected a tile later, its destination register gets copied by the compiler between the two tile bodies before the value
+// has landed.  profiles/r05/gemm_persistent_overlap.log has both measurements.)
+struct PkSched { int T; const int* lists; int pitch; };  // lists[b * pitch]: n_b, then the n_b list indices of workgroup b
+constexpr int PK_MAX_PITCH = 1024;                       // (4096 B of LDS are free behind the compact staging area)
+
+template <int LAYOUT, int EPI, int FMT>
+__global__ __launch_bounds__(512, 2) void gemm_pk_kernel(GemmP p, PkSched sc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
+  int* lst = reinterpret_cast<int*>(smem + (USE_LUT ? LUT_BYTES : 0) + 65536 + 8 * 32 * EPI_LD * 4);  // behind the staging area
+  for (int i = threadIdx.x; i < sc.pitch; i += 512) lst[i] = sc.lists[(long)blockIdx.x * sc.pitch + i];
+  __syncthreads();
+  const int n = __builtin_amdgcn_readfirstlane(lst[0]);
+  PkCtx pk = {sc.T, -1, p.tiles_m, p.tiles_n, p.group_m, p.narrow};
+  const SkSeg none = {0, 0, 0ull, nullptr, nullptr, nullptr};
+  const int kt = (p.K + BK - 1) / BK;
+  bool first = true, pre = false;
+  for (int k = 0; k < n; ++k) {
+    const int cur = __builtin_amdgcn_readfirstlane(lst[1 + k]);
+    pk.next = k + 1 < n ? __builtin_amdgcn_readfirstlane(lst[2 + k]) : -1;
+    int tile_m, tile_n;
+    tile_of(cur, sc.T, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * 256;
+    if (p.narrow && tile_n == p.tiles_n - 1) gemm_tile<LAYOUT, EPI, FMT, 128, 2, true>(p, smem, m0, n0, 0, kt, none, first, pre, &pk);
+    else gemm_tile<LAYOUT, EPI, FMT, 256, 2, true>(p, smem, m0, n0, 0, kt, none, first, pre, &pk);
+    first = false;
+    pre = pk.next >= 0;
+  }
+}
+
 // ---- stream-K launch ----------------------------------------------------------------------------------------------
 // Workspace of the stream-K hand-offs, one per device, allocated on first use and kept: [flags 256 x 64 B | status |
 // slabs n_cu x 256 KiB].  (Not during a stream capture: the caller then takes the plain launch.)  GEMMs of one device must
@@ -1563,6 +1648,122 @@ int launch_sk(const GemmP& p, hipStream_t s) {
   vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : VDS_PROF_GEMM_NN, s,
                     2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
   hipLaunchKernelGGL((gemm_sk_kernel<LAYOUT, EPI, FMT>), dim3(sc.G), dim3(512), LDS_TOTAL, s, p, sc);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
+}
+
+// The lists of gemm_pk_kernel: what the hardware's greedy dispatch of the plain launch would do, simulated with the
+// measured tile times (7.3 us + 1.44 us per K tile for a full tile; the 128-column tile of a narrow last column costs 0.83
+// of that: it saves 5 us of 31 at K = 1152; VDS_PK_NARROW_COST overrides).  List index L belongs to XCD L & 7 (tile_of gives each XCD a contiguous chunk of the grouped tile order) and so
+// do the workgroups b with b & 7 == L & 7: every XCD's chunk is dealt, in list order, to whichever of its workgroups is free
+// first.  Depends on the shape only: built once per (tiles_m, tiles_n, narrow, K tiles, workgroups), kept on the device.
+inline int device_cus() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+struct PkLists { int tiles_m, tiles_n, narrow, kt, G, dev; int pitch; int* d; std::vector<int> h; };
+static std::mutex g_pk_mu;
+static std::vector<PkLists*> g_pk_lists;
+inline void pk_schedule(PkLists& e, int group_m) {
+  const int T = e.tiles_m * e.tiles_n, G = e.G;
+  std::vector<std::vector<int>> per(G);
+  static const double narrow_cost = [] {
+    const char* v = getenv("VDS_PK_NARROW_COST");
+    const double x = v ? atof(v) : 0.0;
+    return x > 0.0 && x <= 1.0 ? x : 0.83;
+  }();
+  const double full = 7.3 + 1.44 * e.kt, narrow = narrow_cost * full;
+  for (int x = 0; x < 8; ++x) {
+    std::vector<int> wgs;
+    for (int b = x; b < G; b += 8) wgs.push_back(b);
+    if (wgs.empty()) continue;
+    std::vector<double> free_at(wgs.size(), 0.0);
+    for (int L = x; L < T; L += 8) {
+      size_t w = 0;
+      for (size_t i = 1; i < wgs.size(); ++i)
+        if (free_at[i] < free_at[w]) w = i;  // (ties: the lowest workgroup, as the dispatcher)
+      int tm, tn;
+      tile_of(L, T, e.tiles_m, e.tiles_n, group_m, tm, tn);
+      free_at[w] += (e.narrow && tn == e.tiles_n - 1) ? narrow : full;
+      per[wgs[w]].push_back(L);
+    }
+  }
+  size_t longest = 0;
+  for (auto& v : per) longest = v.size() > longest ? v.size() : longest;
+  e.pitch = (int)longest + 1;
+  e.h.assign((size_t)G * e.pitch, -1);
+  for (int b = 0; b < G; ++b) {
+    e.h[(size_t)b * e.pitch] = (int)per[b].size();
+    for (size_t i = 0; i < per[b].size(); ++i) e.h[(size_t)b * e.pitch + 1 + i] = per[b][i];
+  }
+}
+// the device copy of the lists for this problem, or nullptr (too long for LDS / allocation failed / first use inside a
+// stream capture: the caller takes the plain launch)
+inline const PkLists* pk_lists(const GemmP& p, int G, hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const int kt = (p.K + BK - 1) / BK;
+  std::lock_guard<std::mutex> lk(g_pk_mu);
+  for (PkLists* e : g_pk_lists)
+    if (e->tiles_m == p.tiles_m && e->tiles_n == p.tiles_n && e->narrow == p.narrow && e->kt == kt && e->G == G && e->dev == dev)
+      return e->d ? e : nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;  // (not remembered: the next eager call builds them)
+  }
+  PkLists* e = new PkLists{p.tiles_m, p.tiles_n, p.narrow, kt, G, dev, 0, nullptr, {}};
+  pk_schedule(*e, p.group_m);
+  g_pk_lists.push_back(e);
+  if (e->pitch > PK_MAX_PITCH) return nullptr;
+  int* d = nullptr;
+  if (hipMalloc(&d, e->h.size() * sizeof(int)) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  // (synchronous on purpose: once per shape, and the lists are then valid for every stream of the device)
+  if (hipMemcpy(d, e->h.data(), e->h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(d);
+    return nullptr;
+  }
+  e->d = d;
+  return e;
+}
+
+// returns VDS_OK / an error, or 1 when the persistent launch is not available here (caller takes the plain launch)
+template <int LAYOUT, int EPI, int FMT = 0>
+int launch_pk(const GemmP& p, hipStream_t s) {
+  if (p.e_qt) return 1;  // (the transposed fp8 copy stages a byte tile that the compact staging has no room for)
+  const int T = p.tiles_m * p.tiles_n;
+  const int n_cu = device_cus();
+  if (n_cu <= 0) return 1;
+  const int G = T < n_cu ? T : n_cu;
+  const PkLists* pl = pk_lists(p, G, s);
+  if (!pl) return 1;
+  PkSched sc = {T, pl->d, pl->pitch};
+  constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
+  constexpr int LDS_TOTAL = LDS_BYTES + (USE_LUT ? LUT_BYTES : 0);
+  static_assert(65536 + 8 * 32 * EPI_LD * 4 + PK_MAX_PITCH * 4 <= LDS_BYTES, "staging + tile list fit behind ring buffer 0");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<LAYOUT, EPI, FMT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    attr_set = true;
+  }
+  if constexpr (USE_LUT) {
+    if (!ensure_gelu_lut()) return VDS_ERR_LAUNCH;
+  }
+  const double k = FMT != 0 ? p.prof_k : (double)p.K;
+  vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : VDS_PROF_GEMM_NN, s,
+                    2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
+  hipLaunchKernelGGL((gemm_pk_kernel<LAYOUT, EPI, FMT>), dim3(G), dim3(512), LDS_TOTAL, s, p, sc);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 
@@ -1858,6 +2059,12 @@ static bool sk_enabled() {
   return e && atoi(e) == 1;
 }
 constexpr int SK_MIN_TILES = 64;  // fewer 256^2 tiles: the hand-offs cost more than the idle CUs they fill
+// persistent launches with the next tile's first K tile under the epilogue (gemm_pk_kernel): VDS_GEMM_PK (read per call)
+static bool pk_enabled() {
+  const char* e = getenv("VDS_GEMM_PK");
+  return e && atoi(e) == 1;
+}
+constexpr int PK_MIN_TILES = 256;  // at least one tile per CU
 
 extern "C" int vds_gemm_stream_k(int32_t mode) {
   const int prev = g_sk_mode;
@@ -2092,6 +2299,18 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
 #undef GOSK
       if (rc != 1) return rc;
     }
+    if (pk_enabled() && a->layout != VDS_TN && (force_tile == 0 || force_tile == 256) && p.split_k == 1 &&
+        (long)tm * tn >= PK_MIN_TILES) {
+      int rc = 1;
+#define GOPK(L, E) if (a->layout == L && a->epilogue == E) rc = big::launch_pk<L, E>(p, s);
+      GOPK(VDS_NT, VDS_EPI_STORE)
+      GOPK(VDS_NT, VDS_EPI_BIAS_GELU)
+      GOPK(VDS_NT, VDS_EPI_GATE_RES)
+      GOPK(VDS_NN, VDS_EPI_STORE)
+      GOPK(VDS_NN, VDS_EPI_DGELU)
+#undef GOPK
+      if (rc != 1) return rc;
+    }
 #define GOB(L, E) if (a->layout == L && a->epilogue == E) return big::launch<L, E>(p, s);
     GOB(VDS_NT, VDS_EPI_STORE)
     GOB(VDS_NT, VDS_EPI_BIAS_GELU)
@@ -2190,6 +2409,17 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
     GOFS(VDS_EPI_GATE_RES, 1)
     GOFS(VDS_EPI_STORE, 2)
 #undef GOFS
+    if (rc != 1) return rc;
+  }
+  if (pk_enabled() && p.split_k == 1 && (g_force_tile == 0 || g_force_tile == 256) && (long)p.tiles_m * p.tiles_n >= PK_MIN_TILES) {
+    int rc = 1;
+#define GOFP(E, F) if (a->epilogue == E && a_fmt == F - 1) rc = big::launch_pk<VDS_NT, E, F>(p, s);
+    GOFP(VDS_EPI_STORE, 1)
+    GOFP(VDS_EPI_BIAS_GELU, 1)
+    GOFP(VDS_EPI_GATE_RES, 1)
+    GOFP(VDS_EPI_STORE, 2)
+    GOFP(VDS_EPI_DGELU, 2)
+#undef GOFP
     if (rc != 1) return rc;
   }
 #define GOF(E, F) if (a->epilogue == E && a_fmt == F - 1) return big::launch<VDS_NT, E, F>(p, s);
