@@ -39,6 +39,56 @@ _NO_EMIT = os.environ.get("VDS_FP8_NO_EMIT") == "1"  # experiments: quantise eve
 _NO_PRODUCER_EMIT = os.environ.get("VDS_FP8_PRODUCER_EMIT") == "0"  # experiments: only the GEMM epilogues emit fp8
 _NO_ATTN_EMIT = os.environ.get("VDS_FP8_ATTN_EMIT") == "0"  # experiments: attention results quantised in a separate pass
 _CROSS_ONES = os.environ.get("VDS_CROSS_ONES", "1") != "0"  # head_dim 72: cross-attention forward / dQ on the ones-column kernels
+_WGRAD_STREAM = os.environ.get("VDS_WGRAD_STREAM", "0") == "1"  # weight-gradient GEMMs of the blocks on a second stream
+
+
+class _WgradLane:
+    """The weight-gradient GEMMs of the DiT blocks on a second HIP stream (round 5).
+
+    dW = dy^T x depends on nothing but dy and a saved activation and nothing in the backward pass depends on it: issued on
+    a side stream it runs beside the input-gradient chain -- under the HBM-bound kernels between the GEMMs (gate / RMSNorm /
+    RoPE backward), which leave the matrix cores idle, and in the partly filled last round of the MFMA kernels.  The side
+    stream waits for an event behind the producer of dy; the operands are kept alive here until the main stream has waited
+    for the GEMMs that read them (the caching allocator would otherwise hand their memory to the next main-stream
+    kernel); the main stream joins `lag` blocks later (0: at the end of every block -- the sharded runtime reduces a
+    block's gradients right behind its backward) and at the end of the pass.
+
+    MEASURED (MI355X, C3b B=12, same box, interleaved): 846.6-851.8 ms per step against 819.3-822.1 ms in stream order,
+    also with the pass on a high-priority stream (ROCm offers two levels).  Two MFMA kernels sharing the chip lose more
+    than the overlap with the HBM-bound kernels and the filled last rounds give back: a CU holding one 74-KiB workgroup
+    of the weight-gradient tiling cannot take a 139-KiB workgroup of the 256^2 tiling and runs half empty.  Off by
+    default (VDS_WGRAD_STREAM=1); kept as a tested experiment switch (profiles/r05/wgrad_side_stream_ab.log)."""
+    _streams = {}
+
+    def __init__(self, dev, lag: int):
+        self.main = torch.cuda.current_stream(dev)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device())
+        if key not in _WgradLane._streams:
+            _WgradLane._streams[key] = torch.cuda.Stream(device=dev)
+        self.side = _WgradLane._streams[key]
+        self.lag = lag
+        self.refs, self.pending = [], []
+
+    def run(self, fn, *args):
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            fn(*args)
+        self.refs.append(args)
+
+    def end_block(self, lag=None):
+        if self.refs:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.pending.append((ev, self.refs))
+            self.refs = []
+        while len(self.pending) > (self.lag if lag is None else lag):
+            ev, _ = self.pending.pop(0)
+            self.main.wait_event(ev)
+
+    def join(self):
+        self.end_block(0)
 
 bf16, f32 = torch.bfloat16, torch.float32
 N_REG = 16  # register tokens (model.py:316,362,386)
@@ -526,6 +576,9 @@ class DiTBlock(nn.Module):
         dev = dX.device
         mod = bs.mod
         batched_adaln = dmod is not None  # DiT.backward: the adaLN weight gradients of all blocks in one launch at the end
+        lane = getattr(sv, "wgrad_lane", None)
+        wgrad = ops.linear_wgrad if lane is None else (lambda *a: lane.run(ops.linear_wgrad, *a))
+        wgrad8 = F8.wgrad if lane is None else (lambda *a: lane.run(F8.wgrad, *a))
         if dmod is None:
             dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
         # --- MLP
@@ -542,7 +595,7 @@ class DiTBlock(nn.Module):
         if bs.f8:
             if not pemit:
                 q_dy = F8.Q(dy, F8.E5M2, True, True, hist, F8.ROWS * i + 4)
-            F8.wgrad(q_dy, bs.q_hact, Gr("mlp.2.weight"))
+            wgrad8(q_dy, bs.q_hact, Gr("mlp.2.weight"))
             if emit:  # the fc2 input gradient leaves the GEMM as e5m2 (+ transposed, + bias gradient)
                 dh = None
                 q_dh = F8.dgrad_gelu_emit(q_dy, bs.q_w2, bs.hpre, hist.prev(F8.ROWS * i + 1), hist.cur(F8.ROWS * i + 1),
@@ -551,13 +604,13 @@ class DiTBlock(nn.Module):
                 dh = F8.dgrad(q_dy, bs.q_w2, pre=bs.hpre)
                 q_dh = F8.Q(dh, F8.E5M2, True, True, hist, F8.ROWS * i + 1)
                 ops.colsum(dh, Gr("mlp.0.bias"))
-            F8.wgrad(q_dh, bs.q_xn3, Gr("mlp.0.weight"))
+            wgrad8(q_dh, bs.q_xn3, Gr("mlp.0.weight"))
             dxn = F8.dgrad(q_dh, bs.q_w1)
             del q_dy, q_dh
         else:
-            ops.linear_wgrad(dy, bs.hact, Gr("mlp.2.weight"))
+            wgrad(dy, bs.hact, Gr("mlp.2.weight"))
             dh = ops.linear_dgrad(dy, W("mlp.2.weight"), pre=bs.hpre, colsum=Gr("mlp.0.bias"))  # + fc1 bias gradient
-            ops.linear_wgrad(dh, bs.xn3, Gr("mlp.0.weight"))
+            wgrad(dh, bs.xn3, Gr("mlp.0.weight"))
             dxn = ops.linear_dgrad(dh, W("mlp.0.weight"))
         del dh
         dX2 = ops.rmsnorm_mod_bwd(dxn, bs.X2, Wo("norm3.weight"), mod, 6 * D, 7 * D, bs.rstd3, dX, dmod,
@@ -573,12 +626,12 @@ class DiTBlock(nn.Module):
         if bs.has_cross:
             if bs.f8c:
                 q_dy = gate_bwd_q(dX2, bs.y_ca, 5 * D, R0 + F8.ROW_DY_CP)
-                F8.wgrad(q_dy, bs.q_catt, Gr("cross_proj.weight"))
+                wgrad8(q_dy, bs.q_catt, Gr("cross_proj.weight"))
                 dcatt = F8.dgrad(q_dy, bs.q_wcp)
                 del q_dy
             else:
                 dy = ops.gate_bwd(dX2, bs.y_ca, mod, 5 * D, dmod, None, B, L)
-                ops.linear_wgrad(dy, bs.catt, Gr("cross_proj.weight"))
+                wgrad(dy, bs.catt, Gr("cross_proj.weight"))
                 dcatt = ops.linear_dgrad(dy, W("cross_proj.weight"))
             # fp8 cross-attention + fp8 q_cross: dQ leaves the attention kernel as e5m2 (and as bf16 only for a bias gradient)
             emit_dqc = bs.c8 and bs.f8c and pemit and not _NO_ATTN_EMIT
@@ -616,15 +669,15 @@ class DiTBlock(nn.Module):
                 ops.colsum(dqc, Gr("q_cross.bias"))
             if bs.f8c:
                 q_dckv = F8.Q(dckv, F8.E5M2, F8.TN, not F8.TN, hist, R0 + F8.ROW_DCKV)  # (a weight-gradient operand only)
-                F8.wgrad(q_dckv, q_ctx, Gr("context_kv.weight"))
+                wgrad8(q_dckv, q_ctx, Gr("context_kv.weight"))
                 q_dqc = (F8.Q.from_rowmajor(*e_dqc, True) if e_dqc is not None else
                          F8.Q(dqc, F8.E5M2, True, True, hist, R0 + F8.ROW_DQC))
-                F8.wgrad(q_dqc, bs.q_xn2, Gr("q_cross.weight"))
+                wgrad8(q_dqc, bs.q_xn2, Gr("q_cross.weight"))
                 dxn = F8.dgrad(q_dqc, bs.q_wqc)
                 del q_dckv, q_dqc
             else:
-                ops.linear_wgrad(dckv, sv.ctx2d, Gr("context_kv.weight"))
-                ops.linear_wgrad(dqc, bs.xn2, Gr("q_cross.weight"))
+                wgrad(dckv, sv.ctx2d, Gr("context_kv.weight"))
+                wgrad(dqc, bs.xn2, Gr("q_cross.weight"))
                 dxn = ops.linear_dgrad(dqc, W("q_cross.weight"))
             dX1 = ops.rmsnorm_mod_bwd(dxn, bs.X1, Wo("norm2.weight"), mod, 3 * D, 4 * D, bs.rstd2, dX2, dmod,
                                       Go("norm2.weight"), B, L)
@@ -633,12 +686,12 @@ class DiTBlock(nn.Module):
         # --- self attention
         if bs.f8l:
             q_dy = gate_bwd_q(dX1, bs.y_sa, 2 * D, R0 + F8.ROW_DY_AP)
-            F8.wgrad(q_dy, bs.q_attn, Gr("attn_proj.weight"))
+            wgrad8(q_dy, bs.q_attn, Gr("attn_proj.weight"))
             dattn = F8.dgrad(q_dy, bs.q_wap)
             del q_dy
         else:
             dy = ops.gate_bwd(dX1, bs.y_sa, mod, 2 * D, dmod, None, B, L)
-            ops.linear_wgrad(dy, bs.attn, Gr("attn_proj.weight"))
+            wgrad(dy, bs.attn, Gr("attn_proj.weight"))
             dattn = ops.linear_dgrad(dy, W("attn_proj.weight"))
         dq = torch.empty(B, H, L, hdp, dtype=bf16, device=dev)
         dk = torch.empty_like(dq)
@@ -672,11 +725,11 @@ class DiTBlock(nn.Module):
         if bs.f8:
             if not emit_dqkv:
                 q_dqkv = F8.Q(dqkv, F8.E5M2, True, True, fp8_hist, F8.ROWS * i + 5)
-            F8.wgrad(q_dqkv, bs.q_xn1, Gr("qkv.weight"))
+            wgrad8(q_dqkv, bs.q_xn1, Gr("qkv.weight"))
             dxn = F8.dgrad(q_dqkv, bs.q_wqkv)
             del q_dqkv
         else:
-            ops.linear_wgrad(dqkv, bs.xn1, Gr("qkv.weight"))
+            wgrad(dqkv, bs.xn1, Gr("qkv.weight"))
             dxn = ops.linear_dgrad(dqkv, W("qkv.weight"))
         dX0 = ops.rmsnorm_mod_bwd(dxn, bs.X, Wo("norm1.weight"), mod, 0, D, bs.rstd1, dX1, dmod, Go("norm1.weight"),
                                   B, L)
@@ -684,6 +737,8 @@ class DiTBlock(nn.Module):
         if not batched_adaln:
             ops.small_linear_bwd(dmod, sv.cvec, W("adaLN_modulation.1.weight"), Gr("adaLN_modulation.1.weight"),
                                  Gr("adaLN_modulation.1.bias"), dc, 1)
+        if lane is not None:
+            lane.end_block()
         return dX0
 
 
@@ -991,6 +1046,7 @@ class DiT(nn.Module):
                              R.g("final_modulation.1.bias"), dc, 1)
         hdp = HDP_OF[hd]
         dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev) if (self.residual_v and self.depth > 1) else None
+        sv.wgrad_lane = _WgradLane(dev, 0 if fs is not None else 1) if _WGRAD_STREAM else None
         for i in reversed(range(self.depth)):
             if fs is not None:
                 fs.pre_backward_block(i)
@@ -1000,6 +1056,9 @@ class DiT(nn.Module):
             sv.blocks[i] = None
             if fs is not None:
                 fs.post_backward_block(i)
+        if sv.wgrad_lane is not None:
+            sv.wgrad_lane.join()
+            sv.wgrad_lane = None
         if dmods is not None:  # adaLN weight / bias gradients of all blocks and their fan-in to dc: one launch each
             wt, _, gwt, gbt = self._adaln_tables()
             ops.small_linear_bwd_batched(dmods, sv.cvec, wt, gwt, gbt, dc, 1)
