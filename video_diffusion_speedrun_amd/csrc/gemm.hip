@@ -2204,9 +2204,36 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
         if (cost < best - 1e-9) { best = cost; best_tile = cand == 0 ? 128 : 2; best_s = sp; }
       }
     }
+    // round 5: the 256^2 tiling as a third candidate (one workgroup per CU).  Its TN main loop is as good as its NT / NN
+    // ones (1395 TFLOP/s at 8192^3 against 1300 for the 256 x 128 tiling); what made it lose on weight gradients was the
+    // split it was given.  Priced from its measured launches (tools/bench_gemm_tn_square.py): a 64-token step of a tile
+    // costs 1.29 units, a workgroup 8 units of prologue + fp32-atomic epilogue; it has to win by 3 % (the two models
+    // above run 0-14 % pessimistic).  At the DiT-XL shapes it takes the fc1 / fc2 weight gradients (18 x 5 / 5 x 18
+    // tiles x 8 splits: 0.907 -> 0.871 and 0.956 -> 0.909 ms at B = 12 in a loop of launches) and leaves qkv and the
+    // 1152^2 ones alone.  Inside the train step the gain is not there (gemm_tn 1096 -> 1084 TFLOP/s, step 818.5 / 819.2
+    // -> 818.2 / 820.1 ms, same box): OFF by default, VDS_GEMM_BIG_TN=1 enables it; VDS_GEMM_TILE=256 uses its split.
+    static int big_tn = -1;
+    if (big_tn < 0) {
+      const char* e = getenv("VDS_GEMM_BIG_TN");
+      big_tn = e ? atoi(e) : 0;
+    }
+    bool tn_big = false;
+    if ((big_tn || force_tile == 256) && (force_tile == 0 || force_tile == 256) && a->K >= 256) {
+      const long tiles = (long)tm * tn;
+      double bb = 1e300;
+      int bs = 1;
+      for (int sp = 1; sp <= 32; ++sp) {
+        if (sp > 1 && kt / sp < 8) break;
+        const long rounds = (tiles * sp + 255) / 256;
+        const double cost = (double)rounds * ((double)((kt + sp - 1) / sp) * 1.29 + 8.0);
+        if (cost < bb - 1e-9) { bb = cost; bs = sp; }
+      }
+      if (force_tile == 256 || bb < 0.97 * best) { tn_big = true; best_s = bs; }
+    }
     p.split_k = best_s;
     p.atomic = (best_s > 1 || a->split_k == -1) ? 1 : 0;
-    if (force_tile != 256) {
+    if (tn_big) use_big = true;
+    else if (force_tile != 256) {
       if (best_tile == 2) {
         p.tiles_m = cdiv(a->M, 256);
         p.tiles_n = cdiv(a->N, 128);
