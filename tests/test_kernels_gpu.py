@@ -1001,3 +1001,41 @@ def test_gemm_persistent_kernel_is_bit_identical(ops, M, N, K, monkeypatch):
             assert torch.equal(got[k], ref[k]), k
             assert torch.equal(got2[k], ref[k]), k
     close("pk.store", got["store"], x.float() @ w.float().t() + b.float(), 4e-3)
+
+
+@pytest.mark.parametrize("Lq,Lk,spike", [(2100, 300, False), (2304, 4160, True), (8208, 8208, False), (4000, 64, False),
+                                          (2060, 130, True)])
+def test_attention_fwd_software_pipelined(ops, Lq, Lk, spike, monkeypatch):
+    """round 5 (VDS_ATTN_FWD_PIPE=1): the forward kernel with the S product of the next 32-key sub-block issued between the
+    exp2 / pack instructions of the current one (48 queries per wave, three-buffer K / V ring) does the arithmetic of
+    attn_fwd16_kernel in the same order per query: identical bits in O and lse as long as the running maximum is raised at
+    the same sub-blocks (the lazy raise is a wave-uniform decision, and a wave now holds other queries: the spike cases are
+    compared within rounding); ragged query / key counts, one- and two-tile key ranges."""
+    B, H, hd, hdp = 1, 2, 72, 96
+    q, k, v = gen(B, H, Lq, hd, seed=41), gen(B, H, Lk, hd, seed=42), gen(B, H, Lk, hd, seed=43)
+    if spike:
+        k[:, :, Lk - 70] = 6.0 * q[:, :, 5]
+        q[:, :, 1000] *= 8.0
+    def padk(t, cols):
+        out = torch.zeros(*t.shape[:-1], hdp, dtype=bf16)
+        out[..., :hd] = t
+        for c in cols:
+            out[..., c] = 1
+        return out.cuda()
+    qd, kd, vd = padk(q, []), padk(k, [hd, hd + 1]), padk(v, [hd, hd + 4])
+    res = []
+    for pipe in ("0", "1"):
+        monkeypatch.setenv("VDS_ATTN_FWD_PIPE", pipe)
+        o = torch.full((B * Lq, H * hd), 7.0, dtype=bf16, device="cuda")
+        lse = torch.full((B, H, Lq), 7.0, dtype=f32, device="cuda")
+        ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o, B, Lq, H, hd), lse, kv_pad_ones=True)
+        torch.cuda.synchronize()
+        res.append((o, lse))
+    if spike:
+        close("attn.pipe.o_vs_plain", res[1][0], res[0][0].float(), 6e-3)
+        close("attn.pipe.lse_vs_plain", res[1][1], res[0][1], 1e-4)
+    else:
+        assert torch.equal(res[0][0], res[1][0])
+        assert torch.equal(res[0][1], res[1][1])
+    sc = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(hd)
+    close("attn.pipe.o", res[1][0].view(B, Lq, H, hd).permute(0, 2, 1, 3), torch.softmax(sc, -1) @ v.float(), 1e-2)
