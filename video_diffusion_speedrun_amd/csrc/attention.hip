@@ -1211,6 +1211,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv16_kernel(AttnP p) {
 // blocks of 16; lane (c = l & 15, g = l >> 4) holds key rows 4g..4g+3 of each 16-key block of query c.  The ones-column
 // softmax is unchanged: -m rides in column head_dim of Q', the denominator comes out of the PV MFMA as rows head_dim
 // (lanes g = 2) and head_dim + 4 (g = 3) of O^T, the running maximum is raised lazily (wave-uniform branch).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float max_over_lane_groups(float x) {  // max over the 4 lanes l & 15 + 16 g
   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
@@ -1305,12 +1306,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
       float mx[4];
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        mx[cb] = fmaxf(fmaxf(fmaxf(s[0][cb][0], s[0][cb][1]), fmaxf(s[0][cb][2], s[0][cb][3])),
-                       fmaxf(fmaxf(s[1][cb][0], s[1][cb][1]), fmaxf(s[1][cb][2], s[1][cb][3])));
+        // 4 instructions per query block as three-operand maxima (the issue port is ~90 % booked: tools/probes)
+        mx[cb] = max3f(max3f(s[0][cb][0], s[0][cb][1], s[0][cb][2]), max3f(s[0][cb][3], s[1][cb][0], s[1][cb][1]),
+                       fmaxf(s[1][cb][2], s[1][cb][3]));
       }
       float mxa = mx[0];
+      if constexpr (NCB == 4) mxa = fmaxf(max3f(mx[0], mx[1], mx[2]), mx[3]);
+      else {
 #pragma unroll
-      for (int cb = 1; cb < NCB; ++cb) mxa = fmaxf(mxa, mx[cb]);
+        for (int cb = 1; cb < NCB; ++cb) mxa = fmaxf(mxa, mx[cb]);
+      }
       if (first || __builtin_amdgcn_ballot_w64(mxa > LAZY_THR) != 0) {  // wave-uniform, rare after the first tile
         asm volatile("; rescale" ::: "memory");  // keeps this a real branch (no if-conversion of the O multiplies)
 #pragma unroll
