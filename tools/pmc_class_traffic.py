@@ -19,6 +19,8 @@ def klass(name: str):
         if fmt != 0:
             return "gemm_fp8"
         return ("gemm_nt", "gemm_nn", "gemm_tn")[int(m.group(2))]
+    if "attn_bwd_dkv16_kernel<96, false>" in n:  # the cross-attention's dK/dV on the 16x16x32 kernel (QPAD = false)
+        return "attn_bwd_dkv_plain"
     table = (("attn8_fwd_kernel", "attn_fp8_fwd"), ("attn8_bwd_dkv_kernel", "attn_fp8_dkv"), ("attn8_bwd_dq_kernel", "attn_fp8_dq"),
              ("attn8_delta_kernel", "attn_bwd_delta"), ("attn_fwd16_kernel", "attn_fwd"), ("attn_bwd_dkv16_kernel", "attn_bwd_dkv"),
              ("attn_bwd_dq16_kernel", "attn_bwd_dq"), ("attn_fwd_wide_kernel", "attn_fwd_plain"), ("attn_fwd_kernel", "attn_fwd_plain"),
