@@ -1039,3 +1039,33 @@ def test_attention_fwd_software_pipelined(ops, Lq, Lk, spike, monkeypatch):
         assert torch.equal(res[0][1], res[1][1])
     sc = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(hd)
     close("attn.pipe.o", res[1][0].view(B, Lq, H, hd).permute(0, 2, 1, 3), torch.softmax(sc, -1) @ v.float(), 1e-2)
+
+
+@pytest.mark.parametrize("L", [8208, 2100, 200])
+def test_attention_dq_three_query_blocks_per_wave_is_bit_identical(ops, L, monkeypatch):
+    """round 5 experiment (VDS_ATTN_DQ_NQ=3): the dQ kernel with 48 instead of 32 queries per wave (every K / V fragment read
+    from LDS feeds 3 instead of 2 MFMAs) computes every query exactly as the default form: identical bits in dQ."""
+    B, H, hd, hdp = 1, 2, 72, 96
+    q, k, v = gen(B, H, L, hd, seed=51), gen(B, H, L, hd, seed=52), gen(B, H, L, hd, seed=53)
+    do = gen(B * L, H * hd, seed=54).cuda()
+    def padk(t, cols):
+        out = torch.zeros(*t.shape[:-1], hdp, dtype=bf16)
+        out[..., :hd] = t
+        for c in cols:
+            out[..., c] = 1
+        return out.cuda()
+    qd, kd, vd = padk(q, []), padk(k, [hd, hd + 1]), padk(v, [hd, hd + 4])
+    o = torch.zeros(B * L, H * hd, dtype=bf16, device="cuda")
+    lse = torch.zeros(B, H, L, dtype=f32, device="cuda")
+    ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o, B, L, H, hd), lse, kv_pad_ones=True)
+    res = []
+    for nq in ("2", "3"):
+        monkeypatch.setenv("VDS_ATTN_DQ_NQ", nq)
+        q2 = qd.clone()  # (the backward pass annotates the q pad)
+        dq, dk, dv = torch.full_like(qd, 3.0), torch.zeros_like(kd), torch.zeros_like(vd)
+        delta = torch.zeros(2, B, H, L, dtype=f32, device="cuda")
+        ops.attn_bwd(q2[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o, B, L, H, hd), lse,
+                     ops.heads_view(do, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta, kv_pad_ones=True)
+        torch.cuda.synchronize()
+        res.append(dq[..., :hd].clone())
+    assert torch.equal(res[0], res[1])

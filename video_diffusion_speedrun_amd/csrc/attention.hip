@@ -1655,8 +1655,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16p_kernel(AttnP p) {
 // dP^T = V dO'^T with 16 key rows from LDS as A and 16 queries in registers as B; dQ^T += K^T dS^T with K^T read by
 // transposing reads and the stacked dS^T accumulators used in place as B.  Per 32 x 32 block: 34 MFMAs of 16 cycles
 // (544) against 16 of 32 (512) -- the contraction pads 72 -> 96 instead of 80 -- in exchange for the higher clock.
-template <int HDP>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
+// NQ: 16-query blocks per wave.  2 (three waves per SIMD) reads every K / V fragment for 2 MFMAs: at the full MFMA rate the
+// 12 waves of a CU would keep the LDS 100 % busy (136 LDS cycles per wave and 32-key sub-block against 544 MFMA cycles per
+// SIMD and wave) -- the kernel is LDS-bound.  3 (two waves per SIMD, experiment: VDS_ATTN_DQ_NQ=3) reads them for 3.
+template <int HDP, int NQ = 2>
+__global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void attn_bwd_dq16_kernel(AttnP p) {
   static_assert(HDP == 96, "head_dim 72 layout");
   constexpr int KS = HDP / 32, NDB = 5, TILE = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1665,7 +1668,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
   const int b = bh / p.H, hh = bh % p.H;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qrow0 = qt * 128 + wave * 32 + (lane & 15);  // query of column block 0; block 1 = + 16
+  const int qrow0 = qt * (64 * NQ) + wave * (16 * NQ) + (lane & 15);  // query of column block 0; block cb = + 16 cb
   const int hd_kv = p.hd + 8;
 
   const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
@@ -1681,9 +1684,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
 
   const long nrows = (long)p.B * p.H * p.Lq;
   const float c = p.scale * LOG2E;
-  bf16x8 qf[2][KS], dof[2][KS];
+  bf16x8 qf[NQ][KS], dof[NQ][KS];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < NQ; ++cb) {
     const int qrow = qrow0 + 16 * cb;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -1710,11 +1713,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
     }
   }
 
-  f32x4 dq[NDB][2];
+  f32x4 dq[NDB][NQ];
 #pragma unroll
   for (int db = 0; db < NDB; ++db)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) dq[db][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < NQ; ++cb) dq[db][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nkt = (p.Lk + 63) / 64;
   VDS_WAIT_VM(0);
   __syncthreads();  // tile 0 landed
@@ -1734,7 +1737,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
     if constexpr (NCB > 0)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      f32x4 s[2][2], dp[2][2];
+      f32x4 s[2][NQ], dp[2][NQ];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -1763,7 +1766,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[rb][cb][r] *= dp[rb][cb][r];  // dS^T (unscaled)
-      bf16x8 df[2];
+      bf16x8 df[NQ];
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) df[cb] = pack2(s[0][cb], s[1][cb]);
 #pragma unroll
@@ -1782,12 +1785,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
       if (j + 1 < nkt) kv_tile(j + 1, std::integral_constant<int, 1>{}, NCBT);
     }
   };
-  const int ncb = min(2, max(0, (p.Lq - (qt * 128 + wave * 32) + 15) >> 4));  // wave-uniform
-  if (ncb == 2) run(std::integral_constant<int, 2>{});
+  const int ncb = min(NQ, max(0, (p.Lq - (qt * (64 * NQ) + wave * (16 * NQ)) + 15) >> 4));  // wave-uniform
+  if (ncb == NQ) run(std::integral_constant<int, NQ>{});
+  else if (ncb == 2) run(std::integral_constant<int, 2>{});
   else if (ncb == 1) run(std::integral_constant<int, 1>{});
   else run(std::integral_constant<int, 0>{});
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < NQ; ++cb) {
     const int qrow = qrow0 + 16 * cb;
     float vq[NDB][4];
 #pragma unroll
@@ -1958,6 +1962,7 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv16_kernel<HDP>, LDS_DKV);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv16_kernel<HDP, false>, LDS_DKV);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dq16_kernel<HDP>, LDS_DQ);
+    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dq16_kernel<HDP, 3>, LDS_DQ);
     once = true;
   }
   const long rows = (long)p.B * p.H * p.Lq;
@@ -2039,7 +2044,12 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
     if constexpr (HDP == 96 && HDQ == 80) ones = p.kv_pad_ones && p.hd == 72;
     vdsprof::Scope ps(ones && p.kv_pad_ones == 1 ? VDS_PROF_ATTN_BWD_DQ : VDS_PROF_ATTN_BWD_DQ_PLAIN, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
     if constexpr (HDP == 96 && HDQ == 80) {
-      if (ones && (attn_variant() & 2))
+      const char* nqe = getenv("VDS_ATTN_DQ_NQ");  // read per call (experiment): 3 = 48 queries per wave
+      if (ones && (attn_variant() & 2) && nqe && atoi(nqe) == 3) {
+        p.n_rt = cdiv(p.Lq, 192);
+        p.tail_last = tail_last_for(p.Lq, 192);
+        hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP, 3>), dim3(cdiv(p.B * p.H, 8) * 8 * p.n_rt), dim3(256), LDS_DQ, s, p);
+      } else if (ones && (attn_variant() & 2))
         hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP>), dim3(grid), dim3(256), LDS_DQ, s, p);
       else if (ones)
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DQ, s, p);
