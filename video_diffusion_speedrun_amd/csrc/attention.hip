@@ -1394,9 +1394,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
 // sub-block) after the barrier that publishes tile j + 1, so the DMA for tile j + 2 must not land in it.  Same arithmetic
 // in the same order as attn_fwd16_kernel: bit-identical results.  NQ = query blocks of 16 per wave: 3 (a second set of S
 // accumulators beside 4 blocks' O, Q' and S does not fit 256 registers: the compiler keeps 8 of the 12 Q' fragments in
-// scratch and every MFMA waits for a scratch load).
+// scratch and every MFMA waits for a scratch load).  6 blocks per wave with ONE wave per SIMD (512 registers, 256 of them
+// AGPRs) measured 3.35 ms against 1.84 ms: a single wave does not keep the pipe fed.
 template <int HDP, int NQ>
-__global__ __launch_bounds__(256, 2) void attn_fwd16p_kernel(AttnP p) {
+__global__ __launch_bounds__(256, NQ > 4 ? 1 : 2) void attn_fwd16p_kernel(AttnP p) {
   static_assert(HDP == 96, "head_dim 72 layout (ones columns at 72, 73 / 72, 76)");
   constexpr int KS = HDP / 32, NDB = 5, TILE = 64 * HDP * 2, BUF = 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
