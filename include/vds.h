@@ -245,12 +245,19 @@ int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float* sinb, cons
                      const void* lam, void* q, void* k, void* v, int32_t B, int32_t L, int32_t H,
                      int32_t hd, int32_t hdp, vds_stream_t stream);
 /* backward: dq,dk,dv [B,H,L,hdp] -> dqkv [B,L,3D] (un-rotated, dv*lam);
- *   dv0_acc (f32 [B,H,L,hdp]) += (1-lam)*dv  when mix != 0;  dlam (f32 scalar) += sum dv*(v_raw - v0);
+ *   dv0_acc (f32 [B,H,L,hdp]) += (1-lam)*dv  when mix == 1;  dlam (f32 scalar) += sum dv*(v_raw - v0) when mix != 0;
+ *   mix == 2 (round 5): as 1 without the dv0_acc update (dv0_acc may be NULL) -- the caller sums the blocks' terms in
+ *   one pass with vds_dv0_reduce before block 0's call;
  *   when add_dv0 != 0 (block 0): dv_total = dv + dv0_acc. */
 int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, const float* cosb,
                      const float* sinb, const void* qkv_raw, const void* v0, const void* lam,
                      float* dv0_acc, float* dlam, void* dqkv, int32_t mix, int32_t add_dv0, int32_t B,
                      int32_t L, int32_t H, int32_t hd, int32_t hdp, vds_stream_t stream);
+/* residual-V (/root/reference/model.py:129-130, backward): out[b,h,l,:hd] (f32 [B,H,L,hdp]; + its old value when
+ * accumulate != 0) = sum_i (1 - lam_i) dv_i[b,h,l,:hd] over n blocks.  dv / lam: HOST arrays of n DEVICE pointers (dv_i bf16
+ * [B,H,L,hdp] contiguous, 16-byte aligned; lam_i one bf16).  Columns >= hd of out are not touched. */
+int vds_dv0_reduce(const void* const* dv, const void* const* lam, int32_t n, float* out, int32_t accumulate, int32_t B,
+                   int32_t H, int32_t L, int32_t hd, int32_t hdp, vds_stream_t stream);
 
 /* apply_rotary_emb (model.py:266-275) on its own: y = rotate(x) for x, y [B,H,L,hd] bf16 addressed as
  * base + b*sb + h*sh + l*sl (elements, multiples of 4; rows of hd contiguous), cos / sin f32 [L, hd/2];

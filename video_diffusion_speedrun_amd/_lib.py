@@ -81,6 +81,7 @@ SIGNATURES = {
     "vds_attn_bwd": [C.POINTER(AttnArgs), c_vp],
     "vds_attn_set_variant": [c_i32],
     "vds_kv_pad_ones": [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "vds_dv0_reduce": [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "vds_attn_bwd_workspace_bytes": [C.POINTER(AttnArgs)],
     "vds_rmsnorm_mod_fwd": [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32,
                             c_f32, c_vp],

@@ -646,15 +646,20 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* dq, con
         const u32x2 a2 = *reinterpret_cast<const u32x2*>(v0 + src + half);
         const float vr[8] = {bflo(r1[0]), bfhi(r1[0]), bflo(r1[1]), bfhi(r1[1]), bflo(r2[0]), bfhi(r2[0]), bflo(r2[1]), bfhi(r2[1])};
         const float vz[8] = {bflo(a1[0]), bfhi(a1[0]), bflo(a1[1]), bfhi(a1[1]), bflo(a2[0]), bfhi(a2[0]), bflo(a2[1]), bfhi(a2[1])};
-        f32x4 o1 = *reinterpret_cast<f32x4*>(acc1), o2 = *reinterpret_cast<f32x4*>(acc2);
+        if (mix == 1) {  // (mix == 2: the (1 - lambda) dv terms of all blocks are summed later, vds_dv0_reduce)
+          f32x4 o1 = *reinterpret_cast<f32x4*>(acc1), o2 = *reinterpret_cast<f32x4*>(acc2);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (e < 4) o1[e] += oml * g[e]; else o2[e - 4] += oml * g[e];
+          }
+          *reinterpret_cast<f32x4*>(acc1) = o1;
+          *reinterpret_cast<f32x4*>(acc2) = o2;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           dl += g[e] * (vr[e] - vz[e]);
-          if (e < 4) o1[e] += oml * g[e]; else o2[e - 4] += oml * g[e];
           g[e] *= lam;
         }
-        *reinterpret_cast<f32x4*>(acc1) = o1;
-        *reinterpret_cast<f32x4*>(acc2) = o2;
       } else if (add_dv0) {
         const f32x4 o1 = *reinterpret_cast<const f32x4*>(acc1), o2 = *reinterpret_cast<const f32x4*>(acc2);
 #pragma unroll
@@ -768,18 +773,22 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
       float g[8];
       unpack8(ld_stream<16>(dv + so), g);
       if (mix) {
-        float vr[8], vz[8], a[8];
+        float vr[8], vz[8];
         unpack8(*reinterpret_cast<const u32x4*>(qkv_raw + tok * 3 * D + 2 * D + c * 8), vr);
         unpack8(*reinterpret_cast<const u32x4*>(v0 + so), vz);
-        load8f(dv0_acc + so, a);
+        if (mix == 1) {  // (mix == 2: the (1 - lambda) dv terms of all blocks are summed later, vds_dv0_reduce)
+          float a[8];
+          load8f(dv0_acc + so, a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += oml * g[e];
+          *reinterpret_cast<f32x4*>(dv0_acc + so) = f32x4{a[0], a[1], a[2], a[3]};
+          *reinterpret_cast<f32x4*>(dv0_acc + so + 4) = f32x4{a[4], a[5], a[6], a[7]};
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           dl += g[e] * (vr[e] - vz[e]);
-          a[e] += oml * g[e];
           g[e] *= lam;
         }
-        *reinterpret_cast<f32x4*>(dv0_acc + so) = f32x4{a[0], a[1], a[2], a[3]};
-        *reinterpret_cast<f32x4*>(dv0_acc + so + 4) = f32x4{a[4], a[5], a[6], a[7]};
       } else if (add_dv0) {
         float a[8];
         load8f(dv0_acc + so, a);
@@ -1490,12 +1499,73 @@ extern "C" int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float*
   return ok();
 }
 
+// ---- residual-V: the gradient that reaches v_0 from the blocks that mixed it in (model.py:129-130), summed once -------
+// dv0[b,h,l,:hd] = sum_i (1 - lambda_i) dv_i[b,h,l,:hd] over the n mixed blocks (fp32 accumulation in registers, one write)
+// instead of an fp32 read-modify-write of dv0 in every block's RoPE backward (vds_qkv_rope_bwd with mix = 2 leaves it out):
+// 27 x 0.9 GB of accumulator traffic per DiT-XL step at B = 12 become one 6 GB pass over the blocks' bf16 dv tensors.
+struct Dv0Args { const bf16_t* dv[32]; const bf16_t* lam[32]; int n; };
+__global__ __launch_bounds__(256) void dv0_reduce_kernel(Dv0Args a, float* out, long rows, int hd, int hdp, int accumulate) {
+  const int cpr = hd >> 3;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= rows * cpr) return;
+  const long so = (gid / cpr) * hdp + (gid % cpr) * 8;
+  float acc[8];
+  if (accumulate) load8f(out + so, acc);
+  else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  }
+  for (int i0 = 0; i0 < a.n; i0 += 4) {  // four independent 16-byte loads in flight
+    u32x4 r[4];
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u < a.n) {
+        r[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dv[i0 + u] + so));  // read once
+        w[u] = 1.0f - bf2f(*a.lam[i0 + u]);
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u < a.n) {
+        float g[8];
+        unpack8(r[u], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w[u] * g[e];
+      }
+  }
+  *reinterpret_cast<f32x4*>(out + so) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+  *reinterpret_cast<f32x4*>(out + so + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
+// dv / lam: host arrays of n device pointers (dv_i: bf16 [B,H,L,hdp] contiguous; lam_i: one bf16); out: f32 [B,H,L,hdp]
+// (columns >= hd are not touched).  accumulate != 0: added to what out holds.  Any n (32 tensors per launch).
+extern "C" int vds_dv0_reduce(const void* const* dv, const void* const* lam, int32_t n, float* out, int32_t accumulate,
+                              int32_t B, int32_t H, int32_t L, int32_t hd, int32_t hdp, vds_stream_t stream) {
+  if (!dv || !lam || !out || n < 0 || B <= 0 || H <= 0 || L <= 0 || (hd & 7) || (hdp & 7) || hdp < hd) return VDS_ERR_ARG;
+  if (((uintptr_t)out & 15) != 0) return VDS_ERR_ARG;
+  const long rows = (long)B * H * L;
+  const long items = rows * (hd >> 3);
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    Dv0Args a;
+    a.n = n - i0 < 32 ? n - i0 : 32;
+    for (int i = 0; i < 32; ++i) {
+      a.dv[i] = i < a.n ? (const bf16_t*)dv[i0 + i] : nullptr;
+      a.lam[i] = i < a.n ? (const bf16_t*)lam[i0 + i] : nullptr;
+      if (i < a.n && (!a.dv[i] || !a.lam[i] || ((uintptr_t)a.dv[i] & 15) != 0)) return VDS_ERR_ARG;
+    }
+    vdsprof::Scope ps(VDS_PROF_QKV_ROPE_BWD, (hipStream_t)stream, 0.0, (2.0 * a.n + 4.0 + ((accumulate || i0) ? 4.0 : 0.0)) * rows * hd);
+    hipLaunchKernelGGL(dv0_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, out,
+                       rows, hd, hdp, (accumulate || i0) ? 1 : 0);
+  }
+  return ok();
+}
+
 extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, const float* cosb,
                                 const float* sinb, const void* qkv_raw, const void* v0, const void* lam,
                                 float* dv0_acc, float* dlam, void* dqkv, int32_t mix, int32_t add_dv0, int32_t B,
                                 int32_t L, int32_t H, int32_t hd, int32_t hdp, vds_stream_t stream) {
   if (!dq || !dk || !dv || !cosb || !sinb || !dqkv || (hd & 7)) return VDS_ERR_ARG;
-  if (mix && (!qkv_raw || !v0 || !lam || !dv0_acc || !dlam)) return VDS_ERR_ARG;
+  if (mix && (!qkv_raw || !v0 || !lam || !dlam || (mix == 1 && !dv0_acc) || mix < 0 || mix > 2)) return VDS_ERR_ARG;
   if (add_dv0 && !dv0_acc) return VDS_ERR_ARG;
   const long n = (long)B * L * H * (hd >> 3);
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_BWD, (hipStream_t)stream, 0.0, (mix ? 24.0 : 12.0) * B * L * H * hd);
@@ -1527,7 +1597,7 @@ extern "C" int vds_qkv_rope_bwd_fp8(const void* dq, const void* dk, const void* 
                                     int32_t add_dv0, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t hdp,
                                     vds_stream_t stream) {
   if (!dq || !dk || !dv || !cosb || !sinb || (hd & 7) || !qout_ok(q, ldq, fmt, amax_in)) return VDS_ERR_ARG;
-  if (mix && (!qkv_raw || !v0 || !lam || !dv0_acc || !dlam)) return VDS_ERR_ARG;
+  if (mix && (!qkv_raw || !v0 || !lam || !dlam || (mix == 1 && !dv0_acc) || mix < 0 || mix > 2)) return VDS_ERR_ARG;
   if (add_dv0 && !dv0_acc) return VDS_ERR_ARG;
   if ((hdp & 7) || H * hd > 2048 || ldq < 3 * H * hd) return VDS_ERR_UNSUPPORTED;
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_BWD, (hipStream_t)stream, 0.0, (mix ? 21.0 : 9.0) * B * L * H * hd);

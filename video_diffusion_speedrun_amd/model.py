@@ -40,6 +40,9 @@ _NO_PRODUCER_EMIT = os.environ.get("VDS_FP8_PRODUCER_EMIT") == "0"  # experiment
 _NO_ATTN_EMIT = os.environ.get("VDS_FP8_ATTN_EMIT") == "0"  # experiments: attention results quantised in a separate pass
 _CROSS_ONES = os.environ.get("VDS_CROSS_ONES", "1") != "0"  # head_dim 72: cross-attention forward / dQ on the ones-column kernels
 _WGRAD_STREAM = os.environ.get("VDS_WGRAD_STREAM", "0") == "1"  # weight-gradient GEMMs of the blocks on a second stream
+# residual-V: d v_0 = sum over the mixed blocks of (1 - lambda_i) dv_i, summed in ONE pass before block 0's RoPE backward
+# (ops.dv0_reduce) instead of an fp32 read-modify-write of the accumulator in every block (0: the per-block form)
+_DV0_DEFER = os.environ.get("VDS_DV0_DEFER", "1") != "0"
 
 
 class _WgradLane:
@@ -710,9 +713,16 @@ class DiTBlock(nn.Module):
                          kv_pad_ones=(hdp - hd) >= 8)
             if bs.a8_on:
                 ops.absmax(dattn, fp8_hist.cur(F8.ROWS * i + F8.ROW_DO))
+        defer = getattr(sv, "dv_terms", None)  # DiT.backward: [(dv, lambda)] of the mixed blocks, summed at block 0
+        mix_mode = (2 if defer is not None else 1) if bs.mix else 0
+        if mix_mode == 2:
+            defer.append((dv, W("lambda_param")))  # (keeps dv alive until block 0)
+        if first and dv0 is not None and defer:
+            ops.dv0_reduce([t for t, _ in defer], [l for _, l in defer], dv0, B, H, L, hd, hdp)
+            defer.clear()
         rope_args = (dq, dk, dv, sv.cos, sv.sin, bs.qkv if bs.mix else None, sv.v0 if bs.mix else None,
                      W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),
-                     Gr("lambda_param") if bs.mix else None, bs.mix, first and dv0 is not None, B, L, H, hd, hdp)
+                     Gr("lambda_param") if bs.mix else None, mix_mode, first and dv0 is not None, B, L, H, hd, hdp)
         # the qkv output gradient leaves the RoPE backward as e5m2 (a qkv bias gradient needs the bf16 tensor)
         emit_dqkv = pemit and not G.has(pre + "qkv.bias") and hdp % 8 == 0 and D <= 2048
         if emit_dqkv:
@@ -1047,6 +1057,7 @@ class DiT(nn.Module):
         hdp = HDP_OF[hd]
         dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev) if (self.residual_v and self.depth > 1) else None
         sv.wgrad_lane = _WgradLane(dev, 0 if fs is not None else 1) if _WGRAD_STREAM else None
+        sv.dv_terms = [] if (_DV0_DEFER and dv0 is not None) else None
         for i in reversed(range(self.depth)):
             if fs is not None:
                 fs.pre_backward_block(i)

@@ -498,6 +498,20 @@ def qkv_rope_bwd(dq, dk, dv, cos, sin, qkv_raw, v0, lam, dv0_acc, dlam, mix, add
     return dqkv
 
 
+def dv0_reduce(dvs, lams, out, B, H, L, hd, hdp, accumulate: bool = False):
+    """out[B,H,L,hdp] f32 (+)= sum_i (1 - lam_i) dvs[i][..., :hd]: the residual-V gradient of v_0 from all mixed blocks in one
+    pass (vds_dv0_reduce; the blocks' RoPE backward then runs with mix = 2)"""
+    import ctypes
+    n = len(dvs)
+    assert n == len(lams) and out.dtype == f32 and out.is_contiguous()
+    for t in dvs:
+        assert t.dtype == bf16 and t.is_contiguous() and tuple(t.shape) == (B, H, L, hdp)
+    pa = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in dvs])
+    la = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in lams])
+    check(_lib.load().vds_dv0_reduce(ctypes.cast(pa, ctypes.c_void_p), ctypes.cast(la, ctypes.c_void_p), n, _p(out),
+                                     int(accumulate), B, H, L, hd, hdp, _stream()), "vds_dv0_reduce")
+
+
 def rope_apply(x, cos, sin, inverse: bool = False):
     """apply_rotary_emb (model.py:266-275): x [B,H,L,hd] bf16 (last dim contiguous), cos / sin f32 [L, hd/2]"""
     B, H, L, hd = x.shape
