@@ -1069,3 +1069,43 @@ def test_attention_dq_three_query_blocks_per_wave_is_bit_identical(ops, L, monke
         torch.cuda.synchronize()
         res.append(dq[..., :hd].clone())
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("hd,hdp,n", [(72, 96, 3), (64, 64, 1), (72, 96, 35)])
+def test_dv0_reduce_equals_the_per_block_accumulation(ops, hd, hdp, n):
+    """round 5: vds_qkv_rope_bwd with mix = 2 (no dv0 update) + ONE vds_dv0_reduce over the blocks' dv tensors gives the
+    accumulator, the un-rotated gradients and the lambda gradients of n calls with mix = 1 -- bit for bit (same terms, same
+    order, fp32); 35 tensors take two launches of the reduction (32 pointers per launch); pad columns are never touched."""
+    B, H, thw = 2, 2, (2, 4, 5)
+    L = thw[0] * thw[1] * thw[2] + 16
+    D = H * hd
+    cos, sin = O.rope_cos_sin(hd, thw, (3, 7, 11))
+    cosd, sind = cos.cuda(), sin.cuda()
+    v0 = gen(B, H, L, hdp, seed=171)
+    v0[..., hd:] = 0
+    v0d = v0.cuda()
+    blocks = []
+    for i in range(n):
+        dq, dk, dv = (gen(B, H, L, hdp, seed=200 + 3 * i + j).cuda() for j in range(3))
+        dv[..., hd:] = float("nan")  # (attention leaves the pad of dv unwritten: it must never be read)
+        blocks.append((dq, dk, dv, gen(B * L, 3 * D, seed=400 + i).cuda(), torch.tensor([0.1 + 0.8 * i / max(n, 2)]).to(bf16).cuda()))
+    acc = torch.zeros(B, H, L, hdp, dtype=f32, device="cuda")
+    dlam1 = torch.zeros(n, dtype=f32, device="cuda")
+    ref = [ops.qkv_rope_bwd(dq, dk, dv, cosd, sind, qkv, v0d, lam, acc, dlam1[i:i + 1], 1, False, B, L, H, hd, hdp)
+           for i, (dq, dk, dv, qkv, lam) in enumerate(blocks)]
+    dlam2 = torch.zeros(n, dtype=f32, device="cuda")
+    got = [ops.qkv_rope_bwd(dq, dk, dv, cosd, sind, qkv, v0d, lam, None, dlam2[i:i + 1], 2, False, B, L, H, hd, hdp)
+           for i, (dq, dk, dv, qkv, lam) in enumerate(blocks)]
+    out = torch.full((B, H, L, hdp), 5.0, dtype=f32, device="cuda")
+    ops.dv0_reduce([b[2] for b in blocks], [b[4] for b in blocks], out, B, H, L, hd, hdp)
+    torch.cuda.synchronize()
+    assert torch.equal(out[..., :hd], acc[..., :hd])
+    if hdp > hd:
+        assert (out[..., hd:] == 5.0).all()  # pad columns untouched
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    close("dv0.dlam", dlam2, dlam1, 1e-6)  # (atomics of per-block partial sums: order may differ in the last bit)
+    # accumulate = True adds to what is there
+    ops.dv0_reduce([b[2] for b in blocks[:1]], [b[4] for b in blocks[:1]], out, B, H, L, hd, hdp, accumulate=True)
+    want = acc[..., :hd] + (1.0 - blocks[0][4].float()) * blocks[0][2][..., :hd].float()
+    close("dv0.accumulate", out[..., :hd], want, 1e-6)
