@@ -1252,9 +1252,21 @@ inline int ok() { return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUN
 // rows of one sample per workgroup: ~768 workgroups in total (3 per CU, enough waves to stream HBM)
 // while every workgroup still folds >= 8 rows into its column sums before the atomics
 inline int rows_per_block_for(int L, int B) {
+  static int min_rows = -1, target = 768;
+  if (min_rows < 0) {
+    const char* e = getenv("VDS_EW_MIN_ROWS");
+    min_rows = e ? atoi(e) : 8;
+    if (min_rows < 1) min_rows = 1;
+    const char* t = getenv("VDS_EW_WGS");
+    if (t && atoi(t) > 0) target = atoi(t);
+  }
   const long total = (long)L * B;
-  int rpb = (int)((total + 767) / 768);
-  return rpb < 8 ? 8 : rpb;
+  int rpb = (int)((total + target - 1) / target);
+  // (round 5) mid-sized problems (C3b at B = 2: 16 416 rows -> 22 per workgroup): the column-sum epilogue -- two LDS passes
+  // and D atomics per workgroup -- is worth 32 rows; measured 4.66 -> 4.40 (rmsnorm_mod_bwd) and 3.18 -> 2.89 ms (gate_bwd)
+  // per step.  Small problems (C1: 1088 rows) keep 8 rows per workgroup: they need the workgroups more.
+  const int floor_rows = (min_rows == 8 && total >= 8192) ? 32 : min_rows;
+  return rpb < floor_rows ? floor_rows : rpb;
 }
 
 }  // namespace
