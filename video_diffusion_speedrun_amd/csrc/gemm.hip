@@ -2148,7 +2148,19 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   const long rounds_big = ((long)tm * tn + 255) / 256;
   const long rounds_small = ((long)p.tiles_m * p.tiles_n + 511) / 512;
   // stream-K (round 5): the 256^2 launch costs its work (+ one hand-off) instead of whole rounds
-  const bool sk_ok = sk_enabled() && a->layout != VDS_TN && (force_tile == 0 || force_tile == 256) && p.split_k == 1 &&
+  // With no explicit choice (neither vds_gemm_stream_k nor VDS_GEMM_SK): stream-K for the one case it measured faster in --
+  // long contractions (K >= 4608) of launches between one and two rounds of tiles (C3b at B = 2: fc2 forward 0.206 -> 0.187 ms,
+  // fc1 input gradient 0.184 -> 0.179 ms; profiles/r05/negative_gemm_stream_k_b2.log): the seam's slab round trip is paid
+  // once per 72 K tiles instead of once per 18.
+  static int sk_lo = -1, sk_hi = 512, sk_k = 4608;
+  if (sk_lo < 0) {
+    const char* e;
+    sk_lo = (e = getenv("VDS_SK_AUTO_LO")) ? atoi(e) : 256;
+    if ((e = getenv("VDS_SK_AUTO_HI"))) sk_hi = atoi(e);
+    if ((e = getenv("VDS_SK_AUTO_K"))) sk_k = atoi(e);
+  }
+  const bool sk_auto = g_sk_mode < 0 && !getenv("VDS_GEMM_SK") && a->K >= sk_k && (long)tm * tn > sk_lo && (long)tm * tn < sk_hi;
+  const bool sk_ok = (sk_enabled() || sk_auto) && a->layout != VDS_TN && (force_tile == 0 || force_tile == 256) && p.split_k == 1 &&
                      (long)tm * tn >= SK_MIN_TILES;
   const double rounds_big_eff = sk_ok ? (double)tm * tn / 256.0 + 0.3 : (double)rounds_big;
   bool use_big = a->layout != VDS_TN && a->K >= 256 && rounds_big_eff * (2.0 / 1.24) < (double)rounds_small;
