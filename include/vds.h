@@ -340,10 +340,14 @@ int vds_registers_bwd(const void* dx, int64_t batch_stride, float* dreg, int32_t
  * z_t = x(1-t) + n t ; v = x - n  in bf16 (train.py:115-117); t f32 [B] already bf16-rounded. */
 int vds_noise_latents(const void* x, const void* noise, const float* t, void* z_t, void* v,
                       int32_t B, int64_t per_sample, vds_stream_t stream);
-/* loss = mean_b mean_chw (v - out)^2 in f32 (train.py:121-125):
- * loss_out[0] += ... (pre-zeroed), per_sample[b] +=.  dout = bf16( 2 (out - v) * gscale/(B*per_sample) ). */
+/* loss = mean_b mean_chw (v - out)^2 in f32 (train.py:121-125), as a FIXED-ORDER two-stage reduction (per-workgroup
+ * partial sums -> one pass that sums a sample's partials, divides by per_sample_n, then sums the samples in index order
+ * and divides by B): loss_out[0] and per_sample[b] are WRITTEN (no pre-zeroing), bit-identical run to run, and a batch of
+ * identical samples gives the single-sample loss to the bit.  workspace: vds_flow_loss_workspace_floats(B, per_sample_n)
+ * floats, caller-allocated, contents irrelevant.  dout (may be NULL) = bf16( 2 (out - v) * gscale/(B*per_sample_n) ). */
+int64_t vds_flow_loss_workspace_floats(int32_t B, int64_t per_sample_n);
 int vds_flow_loss(const void* v, const void* out, float* loss_out, float* per_sample, void* dout,
-                  float gscale, int32_t B, int64_t per_sample_n, vds_stream_t stream);
+                  float gscale, int32_t B, int64_t per_sample_n, float* workspace, vds_stream_t stream);
 /* its backward for an arbitrary upstream gradient (autograd of train.py:121-125 under `(loss * s).backward()`,
  * loss scaling, micro-batch accumulation): dout = bf16( 2 (out - v) * *gloss_dev / (B*per_sample) ), the upstream
  * scalar read from device memory (no host synchronisation; graph-capturable).  B*per_sample % 8 == 0. */

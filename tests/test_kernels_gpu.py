@@ -573,6 +573,13 @@ def test_registers_noise_loss_cast(ops):
     lr.backward()
     close("loss", loss.reshape(1), lr.reshape(1), 1e-5)
     close("loss.per", per, pr, 1e-5)
+    for _ in range(3):  # fixed-order reduction: the same words every time, and batch mean == mean of the per-sample means
+        loss_b, per_b, _ = ops.flow_loss(v, out.cuda(), False)
+        assert torch.equal(loss_b, loss) and torch.equal(per_b, per)
+    tot = torch.zeros((), dtype=f32)
+    for b in range(B):  # the second stage's order: samples in index order, then one division (train.py:125)
+        tot = tot + per[b].cpu()
+    assert loss.item() == (tot / B).item()
     close("loss.dout", dout, of.grad, 4e-3)
     a = gen(1000003, seed=106, dtype=f32)
     d = torch.empty(a.numel(), dtype=bf16, device="cuda")

@@ -112,7 +112,8 @@ SIGNATURES = {
     "vds_fill_registers": [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp],
     "vds_registers_bwd": [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp],
     "vds_noise_latents": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
-    "vds_flow_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i64, c_vp],
+    "vds_flow_loss_workspace_floats": [c_i32, c_i64],
+    "vds_flow_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i64, c_vp, c_vp],
     "vds_flow_loss_bwd": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp],
     "vds_cfg_euler_step": [c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i64, c_vp],
     "vds_adamw_multi": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32, c_vp],
@@ -177,7 +178,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name in ("vds_last_error", "vds_prof_class_name") else
-                      C.c_size_t if name.endswith("_workspace_bytes") else C.c_int)
+                      C.c_size_t if name.endswith("_workspace_bytes") else
+                      C.c_int64 if name.endswith("_workspace_floats") else C.c_int)
     _lib = lib
     return lib
 

@@ -1137,10 +1137,15 @@ __global__ void noise_kernel(const bf16_t* x, const bf16_t* n, const float* t, b
   v[gid] = f2bf(xv - nv);
 }
 
-// train.py:121-125: fp32 MSE per sample -> batch mean; also emits d(loss)/d(out) in bf16
-__global__ __launch_bounds__(256) void flow_loss_kernel(const bf16_t* v, const bf16_t* out, float* loss,
-                                                        float* per_sample, bf16_t* dout, float gscale, int B,
-                                                        long per, int blocks_per_sample) {
+// train.py:121-125: fp32 MSE per sample -> batch mean; also emits d(loss)/d(out) in bf16.
+// FIXED-ORDER two-stage reduction (the reference's `.pow(2).mean(dim=(1,2,3,4)).mean()` is one): stage 1 leaves one partial
+// sum of squares per workgroup (strided loop -> wave butterfly -> 4 adds, all in an order that depends on `per` only),
+// stage 2 (one workgroup) sums a sample's partials in a fixed lane / butterfly order, divides by `per`, then sums the
+// samples in index order and divides by B.  No atomics: the scalar is bit-identical run to run and the loss of a batch
+// of identical samples equals the single-sample loss to the bit.
+__global__ __launch_bounds__(256) void flow_loss_partial_kernel(const bf16_t* v, const bf16_t* out, float* partials,
+                                                                bf16_t* dout, float gscale, int B, long per,
+                                                                int blocks_per_sample) {
   __shared__ float red[4];
   const int b = blockIdx.y;
   const long base = (long)b * per;
@@ -1154,10 +1159,24 @@ __global__ __launch_bounds__(256) void flow_loss_kernel(const bf16_t* v, const b
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
+  if (threadIdx.x == 0) partials[(long)b * blocks_per_sample + blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void flow_loss_final_kernel(const float* partials, float* loss, float* per_sample,
+                                                              int B, long per, int blocks_per_sample) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int b = wave; b < B; b += 4) {  // one wave per sample
+    const float* p = partials + (long)b * blocks_per_sample;
+    float s = 0.f;
+    for (int j = lane; j < blocks_per_sample; j += 64) s += p[j];
+    s = wave_sum(s);
+    if (lane == 0) per_sample[b] = s / (float)per;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const float tot = (red[0] + red[1] + red[2] + red[3]) / (float)per;
-    atomicAdd(per_sample + b, tot);
-    atomicAdd(loss, tot / (float)B);
+    float tot = 0.f;
+    for (int b = 0; b < B; ++b) tot += per_sample[b];
+    loss[0] = tot / (float)B;
   }
 }
 
@@ -1912,14 +1931,24 @@ extern "C" int vds_noise_latents(const void* x, const void* noise, const float* 
   return ok();
 }
 
+static int flow_loss_bps(long per_sample_n) {
+  long bps = (per_sample_n + 256 * 16 - 1) / (256 * 16);
+  return bps < 1 ? 1 : bps > 256 ? 256 : (int)bps;
+}
+
+extern "C" int64_t vds_flow_loss_workspace_floats(int32_t B, int64_t per_sample_n) {
+  if (B <= 0 || per_sample_n <= 0) return 0;
+  return (int64_t)B * flow_loss_bps(per_sample_n);
+}
+
 extern "C" int vds_flow_loss(const void* v, const void* out, float* loss_out, float* per_sample, void* dout,
-                             float gscale, int32_t B, int64_t per_sample_n, vds_stream_t stream) {
-  if (!v || !out || !loss_out || !per_sample) return VDS_ERR_ARG;
-  int bps = (int)((per_sample_n + 256 * 16 - 1) / (256 * 16));
-  if (bps < 1) bps = 1;
-  if (bps > 256) bps = 256;
-  hipLaunchKernelGGL(flow_loss_kernel, dim3(bps, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v,
-                     (const bf16_t*)out, loss_out, per_sample, (bf16_t*)dout, gscale, B, (long)per_sample_n, bps);
+                             float gscale, int32_t B, int64_t per_sample_n, float* workspace, vds_stream_t stream) {
+  if (!v || !out || !loss_out || !per_sample || !workspace || B <= 0 || per_sample_n <= 0) return VDS_ERR_ARG;
+  const int bps = flow_loss_bps(per_sample_n);
+  hipLaunchKernelGGL(flow_loss_partial_kernel, dim3(bps, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v,
+                     (const bf16_t*)out, workspace, (bf16_t*)dout, gscale, B, (long)per_sample_n, bps);
+  hipLaunchKernelGGL(flow_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                     loss_out, per_sample, B, (long)per_sample_n, bps);
   return ok();
 }
 

@@ -643,11 +643,13 @@ def noise_latents(x, noise, t):
 def flow_loss(v, out, want_grad: bool, gscale: float = 1.0):
     B = v.shape[0]
     per = v.numel() // B
-    acc = torch.zeros(1 + B, dtype=f32, device=v.device)
+    lib = _lib.load()
+    # [loss | per-sample | per-workgroup partials]: every word is written by the kernels (fixed-order two-stage reduction)
+    acc = torch.empty(1 + B + lib.vds_flow_loss_workspace_floats(B, per), dtype=f32, device=v.device)
     dout = torch.empty_like(out) if want_grad else None
-    check(_lib.load().vds_flow_loss(_p(v), _p(out), _p(acc), _p(acc[1:]), _p(dout), gscale, B, per, _stream()),
+    check(lib.vds_flow_loss(_p(v), _p(out), _p(acc), _p(acc[1:]), _p(dout), gscale, B, per, _p(acc[1 + B:]), _stream()),
           "vds_flow_loss")
-    return acc[0], acc[1:], dout
+    return acc[0], acc[1:1 + B], dout
 
 
 def flow_loss_bwd(v, out, gloss):
