@@ -75,20 +75,28 @@ typedef struct vds_gemm_args {
 int vds_gemm_bf16(const vds_gemm_args* args, vds_stream_t stream);
 /* Tests / experiments: pin the tiling vds_gemm_bf16 picks (0 = by its cost model (default), 128 = 128x128 tiles,
  * 256 = 256x256, 2 = 256x128 with two workgroups per CU); returns the previous setting, VDS_ERR_ARG for other
- * values.  The environment variable VDS_GEMM_TILE sets the initial value.  Results are identical across tilings up
+ * values.  Knob "gemm_tile" (VDS_GEMM_TILE sets the initial value).  Results are identical across tilings up
  * to fp32 summation order. */
 int vds_gemm_force_tile(int32_t tile);
-/* Stream-K launches of the 256^2 kernel (round 5; NT / NN, bf16 and fp8): a persistent grid of one workgroup per CU that
- * takes the whole rounds of the tile list data-parallel and divides the K iterations of the leftover tiles evenly, with
- * fp32 partial tiles handed over in HBM (csrc/gemm.hip, gemm_sk_kernel): the launch costs its work instead of whole
- * rounds of 256 tiles.  mode: 1 on, 0 off, -1 (initial) = environment variable VDS_GEMM_SK (default OFF: measured a
- * net loss at the DiT-XL shapes, profiles/r05/negative_gemm_stream_k_*.log; an experiment); returns the previous mode.  Results equal the plain launch's up to the fp32 summation order of split tiles.  Needs the chip to
- * itself (the sharding runtime switches it off for world sizes > 1) and one stream per device for the GEMMs; the
- * hand-off workspace (64 MiB per device) is allocated by the library on first use and kept. */
-int vds_gemm_stream_k(int32_t mode);
-/* 0, or 1 when a hand-off poll of a stream-K launch on the current device timed out since the last call (that
- * launch's result is wrong; the kernel bounds every spin instead of hanging).  Synchronises the device. */
-int vds_gemm_stream_k_status(void);
+/* ------------------------------------------------------------ process-wide settings -----
+ * Every tuning knob of the library lives in ONE table (csrc/config.h lists them with their defaults) that is filled from
+ * the environment once, when the library is loaded; no entry point reads the environment afterwards.  vds_knob_set
+ * changes an entry by name (e.g. "gemm_narrow", "cross_dkv16", "attn_wide_stores": same-process A/B measurements and
+ * tests); VDS_ERR_ARG for an unknown name.  vds_knob_get returns the value, NaN for an unknown name.  Besides the
+ * communicator this table is the library's only mutable global state. */
+int vds_knob_set(const char* name, double value);
+double vds_knob_get(const char* name);
+
+/* Deterministic mode (default off).  The default backward accumulates with fp32 atomics in several places -- the split-K
+ * slices of the weight-gradient GEMMs, the per-workgroup column sums of the modulation / bias / RMSNorm-weight gradients,
+ * the lambda gradients -- so two runs differ in the last bits (autograd's reductions behind the reference's
+ * train.py:431-433 have a fixed order).  on = 1: every one of them becomes a fixed-order reduction: partial results go to
+ * `workspace` (caller-allocated, 16-byte aligned, `workspace_bytes` long; kept until the mode is switched off) with plain
+ * stores and one pass sums them in index order.  Two backward passes over the same inputs then give bit-identical
+ * gradients.  A split-K GEMM uses as many splits as fit the workspace (M*N*4 bytes each); row kernels need
+ * 3 * D * 4 bytes per workgroup (<= 2048 workgroups).  All deterministic launches must be on one stream.  Returns the
+ * previous mode, VDS_ERR_ARG for a bad argument. */
+int vds_set_deterministic(int32_t on, void* workspace, size_t workspace_bytes);
 
 /* The same GEMM with OCP fp8 operands (BASELINE config 5; no reference counterpart -- the reference trains in
  * bf16): layout VDS_NT: A[M,K] and B[N,K] one byte per element (a_fmt / b_fmt: 0 = e4m3fn, 1 = e5m2; B must
@@ -199,7 +207,7 @@ int vds_attn_bwd(const vds_attn_args* args, vds_stream_t stream);
 int vds_kv_pad_ones(const void* kv, int64_t ld, int32_t k_col0, int32_t v_col0, void* kp, void* vp, int32_t B, int32_t Lk,
                     int32_t H, int32_t hd, int32_t hdp, vds_stream_t stream);
 /* Tests / experiments: which of the head_dim-72 (ones-column) kernels run on v_mfma_f32_16x16x32_bf16 instead of
- * v_mfma_f32_32x32x16_bf16 -- bit 0: dK/dV, bit 1: dQ, bit 2: forward; -1 = back to the default / VDS_ATTN_MFMA16.
+ * v_mfma_f32_32x32x16_bf16 -- bit 0: dK/dV, bit 1: dQ, bit 2: forward; -1 = back to the default (7); knob "attn_mfma16".
  * Returns the previous mask.  Results agree up to fp32 summation order. */
 int vds_attn_set_variant(int32_t mask);
 /* bytes of the caller-allocated `delta` workspace vds_attn_bwd wants for these B, H, Lq, Lk, head_dim, kv_pad_ones:

@@ -56,9 +56,9 @@ def _small_ints(M, K, seed, vals):
     return v[torch.randint(0, len(vals), (M, K), generator=g)]
 
 
-@pytest.fixture(params=[0, 256, 192], ids=["auto", "t256", "t256x192"])
+@pytest.fixture(params=[0, 256], ids=["auto", "t256"])
 def tile8(request, ops):
-    """the fp8 GEMM under the dispatcher's choice and with the 256 x 256 / 256 x 192 (round 4) output tiles pinned"""
+    """the fp8 GEMM under the dispatcher's choice and with the 256 x 256 output tile pinned"""
     ops.gemm_force_tile(request.param)
     yield request.param
     ops.gemm_force_tile(0)
@@ -88,36 +88,6 @@ def test_gemm_fp8_exact_on_small_integers(ops, tile8, a_fmt, M, N, K):
     Cb = torch.empty(M, N, dtype=bf16, device="cuda")
     ops.gemm_fp8(EPI_STORE, M, N, K, Aq, Bq, sa, None, a_fmt, Cb, N)
     assert torch.equal(Cb.cpu(), (want * 0.5).to(bf16))
-
-
-@pytest.mark.parametrize("a_fmt", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(20000, 1152, 1152), (4500, 1152, 656), (16416, 1280, 4608)])
-def test_gemm_fp8_stream_k_exact_on_small_integers(ops, a_fmt, M, N, K):
-    """round 5: the stream-K launch of the fp8 GEMM (same persistent kernel as bf16: leftover tiles split along K, fp32
-    slabs handed over in HBM): exact on small integers and bit-identical to the plain launch, no hand-off times out"""
-    from video_diffusion_speedrun_amd._lib import EPI_STORE
-    A = _small_ints(M, K, 11, [-2.0, -1.0, -0.5, 0.0, 0.5, 1.0, 2.0])
-    B = _small_ints(N, K, 12, [-1.0, 0.0, 0.25, 1.0, 2.0])
-    Aq, Bq = A.to(ops.fp8_dtypes[a_fmt]).cuda(), B.to(torch.float8_e4m3fn).cuda()
-    sa, sb = torch.tensor([0.5], device="cuda"), torch.tensor([4.0], device="cuda")
-    bias = torch.arange(N, dtype=f32).remainder(7).sub(3).to(bf16).cuda()
-    out = {}
-    ops.gemm_force_tile(256)
-    prev = ops.gemm_stream_k(1)
-    try:
-        for mode in (1, 0, 1):
-            ops.gemm_stream_k(mode)
-            C = torch.empty(M, N, dtype=bf16, device="cuda")
-            ops.gemm_fp8(EPI_STORE, M, N, K, Aq, Bq, sa, sb, a_fmt, C, N, bias=bias)
-            torch.cuda.synchronize()
-            out.setdefault(mode, []).append(C)
-        assert ops.gemm_stream_k_status() == 0
-    finally:
-        ops.gemm_stream_k(prev)
-        ops.gemm_force_tile(0)
-    want = ((A @ B.t()) * 2.0 + bias.float().cpu()).to(bf16)
-    for C in out[1] + out[0]:
-        assert torch.equal(C.cpu(), want)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1152, 1152, 1040), (144, 3456, 912), (272, 48, 4112), (16, 16, 16)])

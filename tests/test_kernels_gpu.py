@@ -53,10 +53,10 @@ def test_lane_maps(ops):
 
 
 # ------------------------------------------------------------------------------- GEMM ----
-@pytest.fixture(params=[0, 128, 256, 2, 192], ids=["auto", "t128", "t256", "t256x128", "t256x192"])
+@pytest.fixture(params=[0, 128, 256, 2], ids=["auto", "t128", "t256", "t256x128"])
 def tile(request, ops):
-    """every GEMM test runs under the dispatcher's own choice and with each of the four tilings pinned
-    (vds_gemm_force_tile): 128x128, 256x256, 256x128 (two workgroups per CU) and 256x192 (round 4)"""
+    """every GEMM test runs under the dispatcher's own choice and with each of the three tilings pinned
+    (vds_gemm_force_tile): 128x128, 256x256, 256x128 (two workgroups per CU)"""
     ops.gemm_force_tile(request.param)
     yield request.param
     ops.gemm_force_tile(0)
@@ -802,10 +802,10 @@ def test_gemm_nn_dgelu_with_fused_bias_gradient(ops, tile):
 
 
 @pytest.mark.parametrize("N", [1152, 384, 1096, 72])
-def test_gemm_narrow_last_tile_column_is_bit_identical(ops, N, monkeypatch):
+def test_gemm_narrow_last_tile_column_is_bit_identical(ops, N):
     """round 5: on the 256^2 kernel a last tile column that holds at most 128 columns runs the 256 x 128 body (wave tile
     128 x 32, B staged as one half-tile, 32 MFMAs per wave and K tile).  Same products in the same k order: every fused
-    epilogue must give the bits of the full-width body (VDS_GEMM_NARROW=0), and the reference values."""
+    epilogue must give the bits of the full-width body (knob gemm_narrow = 0), and the reference values."""
     B, L, K = 3, 1500, 328  # 4500 rows = 17.6 row tiles, K = 5.1 K tiles
     M = B * L
     x, w, b = gen(M, K, seed=41), gen(N, K, seed=42, scale=0.05), gen(N, seed=43, scale=0.3)
@@ -825,13 +825,12 @@ def test_gemm_narrow_last_tile_column_is_bit_identical(ops, N, monkeypatch):
         return out
 
     ops.gemm_force_tile(256)
-    prev = ops.gemm_stream_k(0)  # (stream-K splits tiles along K by cost: its schedule differs between the two settings)
     try:
         got = run()
-        monkeypatch.setenv("VDS_GEMM_NARROW", "0")
+        ops.knob_set("gemm_narrow", 0)
         ref = run()
     finally:
-        ops.gemm_stream_k(prev)
+        ops.knob_set("gemm_narrow", 1)
         ops.gemm_force_tile(0)
     for k in got:
         if k == "cs":  # fp32 atomics across workgroups: order-dependent in the last bits
@@ -850,84 +849,16 @@ def _ints(shape, seed, lo=-2, hi=2, dtype=bf16):
     return torch.randint(lo, hi + 1, shape, generator=g).to(dtype)
 
 
-@pytest.mark.parametrize("M,N,K", [(4500, 1152, 328),      # 90 tiles < 256: everything stream-K, tiles split 4 + 2 K tiles
-                                   (20000, 1152, 1152),    # 395 tiles: one data-parallel round + 139 split tiles (narrow ones too)
-                                   (98496, 1152, 192),     # B=12: 7 rounds + 133 whole leftover tiles (3 K tiles: no split)
-                                   (16416, 3456, 1152),    # B=2 qkv: 3 rounds + 142 tiles, 18 K tiles each
-                                   (16416, 1280, 4608)])   # five full columns (no narrow body), 72 K tiles: up to 4 segments
-def test_gemm_stream_k_is_exact_on_integers(ops, M, N, K, monkeypatch):
-    """round 5: stream-K launches of the 256^2 kernel (persistent grid; leftover tiles split along K, fp32 partial tiles
-    handed over in HBM).  On small-integer operands every fp32 sum is exact whatever the summation order, so the stream-K
-    result must equal the plain launch's bit for bit -- forward (bias), bias + GELU, gate + residual, input gradient --
-    and the exact matrix product; no hand-off may time out."""
-    B = 2 if M % 2 == 0 else 1
-    L = M // B
-    x, w = _ints((M, K), 71), _ints((N, K), 72)
-    b = _ints((N,), 73, -3, 3)
-    res, mod = _ints((M, N), 74, -8, 8), _ints((B, 3 * N), 75, -2, 2, f32)
-    dy, w2 = _ints((M, K), 76), _ints((K, N), 77)
-
-    def run():
-        out = {}
-        out["store"] = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
-        out["pre"], out["act"] = ops.linear_fwd_gelu(x.cuda(), w.cuda(), b.cuda())
-        out["y"], out["xn"] = ops.linear_fwd_gate_res(x.cuda(), w.cuda(), b.cuda(), mod.cuda(), 2 * N, res.cuda(), L)
-        out["nn"] = ops.linear_dgrad(dy.cuda(), w2.cuda())
-        torch.cuda.synchronize()
-        return out
-
-    ops.gemm_force_tile(256)
-    prev = ops.gemm_stream_k(1)
-    try:
-        got = run()
-        assert ops.gemm_stream_k_status() == 0
-        ops.gemm_stream_k(0)
-        ref = run()
-        got2 = None
-        ops.gemm_stream_k(1)
-        got2 = run()  # a second launch finds every flag lowered again
-        assert ops.gemm_stream_k_status() == 0
-    finally:
-        ops.gemm_stream_k(prev)
-        ops.gemm_force_tile(0)
-    for k in got:
-        assert torch.equal(got[k], ref[k]), k
-        assert torch.equal(got2[k], ref[k]), k
-    want = (x.float() @ w.float().t() + b.float()).to(bf16)
-    assert torch.equal(got["store"].cpu(), want)
-    assert torch.equal(got["nn"].cpu(), (dy.float() @ w2.float()).to(bf16))
-
-
-def test_gemm_stream_k_random_operands_close_to_plain(ops):
-    """random bf16 operands: split tiles differ from the plain launch only by the fp32 summation order of their K
-    segments (a few results flip by one bf16 ulp); against fp32 math both meet the GEMM tolerance"""
-    M, N, K = 20000, 1152, 1152
-    x, w = gen(M, K, seed=81), gen(N, K, seed=82, scale=0.05)
-    ops.gemm_force_tile(256)
-    prev = ops.gemm_stream_k(1)
-    try:
-        y1 = ops.linear_fwd(x.cuda(), w.cuda(), None)
-        ops.gemm_stream_k(0)
-        y0 = ops.linear_fwd(x.cuda(), w.cuda(), None)
-        torch.cuda.synchronize()
-    finally:
-        ops.gemm_stream_k(prev)
-        ops.gemm_force_tile(0)
-    ref = x.float() @ w.float().t()
-    close("sk.random", y1, ref, 4e-3)
-    assert (y1 != y0).float().mean().item() < 0.02
-    assert rel(y1, y0) < 2e-3
-
-
 @pytest.mark.parametrize("dkv16", ["0", "2"], ids=["dkv_plain_qsplit", "dkv16_from_staged_lse"])
 @pytest.mark.parametrize("L,Lc", [(2100, 512), (8208, 512), (2304, 300)], ids=["Lq2100", "headline_8208", "ragged_Lk300"])
-def test_attention_cross_on_the_ones_column_kernels(ops, L, Lc, dkv16, monkeypatch):
+def test_attention_cross_on_the_ones_column_kernels(ops, L, Lc, dkv16, request):
     """round 5 (vds_attn_args.kv_pad_ones = 2): cross-attention with token-major queries and head-major padded K / V copies
     that carry the ones columns (vds_kv_pad_ones): forward and dQ on the 16x16x32 ones-column kernels, dK/dV on the plain
     kernel with the query-range split or on the 16x16x32 kernel with S started from the staged -lse2 (chosen by the
     number of workgroups; both forced here); nothing may be written outside the rows.  Against fp32 attention and against the
     plain path on the token-major K / V."""
-    monkeypatch.setenv("VDS_CROSS_DKV16", dkv16)  # 2: the 16x16x32 dK/dV kernel whatever the grid (it needs >= 512 workgroups otherwise)
+    prev = ops.knob_set("cross_dkv16", int(dkv16))  # 2: the 16x16x32 dK/dV kernel whatever the grid (it needs >= 512 workgroups otherwise)
+    request.addfinalizer(lambda: ops.knob_set("cross_dkv16", prev))
     B, H, hd, hdp = 2, 3, 72, 96
     D = H * hd
     qb, kvb = gen(B * L, D, seed=91), gen(B * Lc, 2 * D, seed=92)
@@ -965,117 +896,6 @@ def test_attention_cross_on_the_ones_column_kernels(ops, L, Lc, dkv16, monkeypat
     close("xones.dq", dqb.reshape(B, L, H, hd).permute(0, 2, 1, 3), dq_ref, 8e-3)
     close("xones.dk", dkvb[:, :D].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dk_ref, 8e-3)
     close("xones.dv", dkvb[:, D:].reshape(B, Lc, H, hd).permute(0, 2, 1, 3), dv_ref, 8e-3)
-
-
-@pytest.mark.parametrize("M,N,K", [(20000, 1152, 328), (98496, 1152, 192), (16416, 3456, 1152), (66000, 1024, 136)])
-def test_gemm_persistent_kernel_is_bit_identical(ops, M, N, K, monkeypatch):
-    """round 5 (VDS_GEMM_PK=1): the persistent form of the 256^2 kernel -- one workgroup per CU with a host-built tile list,
-    the next tile's first K tile issued under the epilogue, epilogue staged in 32-row steps through the second ring buffer
-    -- runs the same products in the same order: every fused epilogue must give the bits of the plain launch (the second
-    run takes the cached lists)."""
-    B = 2 if M % 2 == 0 else 1
-    L = M // B
-    x, w, b = gen(M, K, seed=61), gen(N, K, seed=62, scale=0.05), gen(N, seed=63, scale=0.3)
-    res, mod = gen(M, N, seed=64), gen(B, 3 * N, seed=65, dtype=f32)
-    dy, w2, pre = gen(M, K, seed=66), gen(K, N, seed=67, scale=0.05), gen(M, N, seed=68)
-
-    def run():
-        out = {}
-        out["store"] = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
-        out["pre"], out["act"] = ops.linear_fwd_gelu(x.cuda(), w.cuda(), b.cuda())
-        out["y"], out["xn"] = ops.linear_fwd_gate_res(x.cuda(), w.cuda(), b.cuda(), mod.cuda(), 2 * N, res.cuda(), L)
-        out["nn"] = ops.linear_dgrad(dy.cuda(), w2.cuda())
-        cs = torch.zeros(N, dtype=f32, device="cuda")
-        out["dgelu"] = ops.linear_dgrad(dy.cuda(), w2.cuda(), pre.cuda(), colsum=cs)
-        out["cs"] = cs
-        torch.cuda.synchronize()
-        return out
-
-    ops.gemm_force_tile(256)
-    try:
-        monkeypatch.setenv("VDS_GEMM_PK", "0")
-        ref = run()
-        monkeypatch.setenv("VDS_GEMM_PK", "1")
-        got = run()
-        got2 = run()
-    finally:
-        ops.gemm_force_tile(0)
-    for k in ref:
-        if k == "cs":  # fp32 atomics across workgroups: order-dependent in the last bits
-            close("pk.cs", got[k], ref[k], 1e-5)
-            close("pk.cs2", got2[k], ref[k], 1e-5)
-        else:
-            assert torch.equal(got[k], ref[k]), k
-            assert torch.equal(got2[k], ref[k]), k
-    close("pk.store", got["store"], x.float() @ w.float().t() + b.float(), 4e-3)
-
-
-@pytest.mark.parametrize("Lq,Lk,spike", [(2100, 300, False), (2304, 4160, True), (8208, 8208, False), (4000, 64, False),
-                                          (2060, 130, True)])
-def test_attention_fwd_software_pipelined(ops, Lq, Lk, spike, monkeypatch):
-    """round 5 (VDS_ATTN_FWD_PIPE=1): the forward kernel with the S product of the next 32-key sub-block issued between the
-    exp2 / pack instructions of the current one (48 queries per wave, three-buffer K / V ring) does the arithmetic of
-    attn_fwd16_kernel in the same order per query: identical bits in O and lse as long as the running maximum is raised at
-    the same sub-blocks (the lazy raise is a wave-uniform decision, and a wave now holds other queries: the spike cases are
-    compared within rounding); ragged query / key counts, one- and two-tile key ranges."""
-    B, H, hd, hdp = 1, 2, 72, 96
-    q, k, v = gen(B, H, Lq, hd, seed=41), gen(B, H, Lk, hd, seed=42), gen(B, H, Lk, hd, seed=43)
-    if spike:
-        k[:, :, Lk - 70] = 6.0 * q[:, :, 5]
-        q[:, :, 1000] *= 8.0
-    def padk(t, cols):
-        out = torch.zeros(*t.shape[:-1], hdp, dtype=bf16)
-        out[..., :hd] = t
-        for c in cols:
-            out[..., c] = 1
-        return out.cuda()
-    qd, kd, vd = padk(q, []), padk(k, [hd, hd + 1]), padk(v, [hd, hd + 4])
-    res = []
-    for pipe in ("0", "1"):
-        monkeypatch.setenv("VDS_ATTN_FWD_PIPE", pipe)
-        o = torch.full((B * Lq, H * hd), 7.0, dtype=bf16, device="cuda")
-        lse = torch.full((B, H, Lq), 7.0, dtype=f32, device="cuda")
-        ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o, B, Lq, H, hd), lse, kv_pad_ones=True)
-        torch.cuda.synchronize()
-        res.append((o, lse))
-    if spike:
-        close("attn.pipe.o_vs_plain", res[1][0], res[0][0].float(), 6e-3)
-        close("attn.pipe.lse_vs_plain", res[1][1], res[0][1], 1e-4)
-    else:
-        assert torch.equal(res[0][0], res[1][0])
-        assert torch.equal(res[0][1], res[1][1])
-    sc = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(hd)
-    close("attn.pipe.o", res[1][0].view(B, Lq, H, hd).permute(0, 2, 1, 3), torch.softmax(sc, -1) @ v.float(), 1e-2)
-
-
-@pytest.mark.parametrize("L", [8208, 2100, 200])
-def test_attention_dq_three_query_blocks_per_wave_is_bit_identical(ops, L, monkeypatch):
-    """round 5 experiment (VDS_ATTN_DQ_NQ=3): the dQ kernel with 48 instead of 32 queries per wave (every K / V fragment read
-    from LDS feeds 3 instead of 2 MFMAs) computes every query exactly as the default form: identical bits in dQ."""
-    B, H, hd, hdp = 1, 2, 72, 96
-    q, k, v = gen(B, H, L, hd, seed=51), gen(B, H, L, hd, seed=52), gen(B, H, L, hd, seed=53)
-    do = gen(B * L, H * hd, seed=54).cuda()
-    def padk(t, cols):
-        out = torch.zeros(*t.shape[:-1], hdp, dtype=bf16)
-        out[..., :hd] = t
-        for c in cols:
-            out[..., c] = 1
-        return out.cuda()
-    qd, kd, vd = padk(q, []), padk(k, [hd, hd + 1]), padk(v, [hd, hd + 4])
-    o = torch.zeros(B * L, H * hd, dtype=bf16, device="cuda")
-    lse = torch.zeros(B, H, L, dtype=f32, device="cuda")
-    ops.attn_fwd(qd[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o, B, L, H, hd), lse, kv_pad_ones=True)
-    res = []
-    for nq in ("2", "3"):
-        monkeypatch.setenv("VDS_ATTN_DQ_NQ", nq)
-        q2 = qd.clone()  # (the backward pass annotates the q pad)
-        dq, dk, dv = torch.full_like(qd, 3.0), torch.zeros_like(kd), torch.zeros_like(vd)
-        delta = torch.zeros(2, B, H, L, dtype=f32, device="cuda")
-        ops.attn_bwd(q2[..., :hd], kd[..., :hd], vd[..., :hd], ops.heads_view(o, B, L, H, hd), lse,
-                     ops.heads_view(do, B, L, H, hd), dq[..., :hd], dk[..., :hd], dv[..., :hd], delta, kv_pad_ones=True)
-        torch.cuda.synchronize()
-        res.append(dq[..., :hd].clone())
-    assert torch.equal(res[0], res[1])
 
 
 @pytest.mark.parametrize("hd,hdp,n", [(72, 96, 3), (64, 64, 1), (72, 96, 35)])

@@ -75,8 +75,9 @@ SIGNATURES = {
     "vds_last_error": [],
     "vds_gemm_bf16": [C.POINTER(GemmArgs), c_vp],
     "vds_gemm_force_tile": [c_i32],
-    "vds_gemm_stream_k": [c_i32],
-    "vds_gemm_stream_k_status": [],
+    "vds_knob_set": [C.c_char_p, C.c_double],
+    "vds_knob_get": [C.c_char_p],
+    "vds_set_deterministic": [c_i32, c_vp, C.c_size_t],
     "vds_attn_fwd": [C.POINTER(AttnArgs), c_vp],
     "vds_attn_bwd": [C.POINTER(AttnArgs), c_vp],
     "vds_attn_set_variant": [c_i32],
@@ -178,6 +179,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name in ("vds_last_error", "vds_prof_class_name") else
+                      C.c_double if name == "vds_knob_get" else
                       C.c_size_t if name.endswith("_workspace_bytes") else
                       C.c_int64 if name.endswith("_workspace_floats") else C.c_int)
     _lib = lib

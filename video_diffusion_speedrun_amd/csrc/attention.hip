@@ -25,6 +25,7 @@
 #include "common.h"
 #include <type_traits>
 #include "prof.h"
+#include "config.h"
 #include "../../include/vds.h"
 #include <cstdlib>
 
@@ -1382,275 +1383,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
   }
 }
 
-// ===================================== forward, software-pipelined inside the wave (round 5) =====
-// attn_fwd16_kernel alternates MFMA-only and VALU-only stretches (S = K Q'^T | max, exp2, pack | O^T += V^T P^T), and two
-// waves per SIMD overlap them only by chance: 25 % of the MFMA-busy cycles have a VALU instruction co-executing, the MFMA
-// pipe is 63 % busy (profiles/r05_attn_b6_sq_counters.txt).  An MFMA holds the issue port for 4 of its 16 pipe cycles; the
-// other 12 can issue this wave's own VALU work IF the program order offers it.  Here the S product of 32-key sub-block n + 1
-// is issued between the exp2 / pack instructions of sub-block n (24 MFMAs, 48 VALU: two per MFMA -- v_exp_f32 measures 8
-// cycles, not 16: tools/probes/valu_rate_probe.hip), and the PV product of sub-block n - 1 between the row-maximum
-// instructions of sub-block n; llvm.amdgcn.sched.group.barrier pins the interleaving.  K / V tiles go through a ring of
-// THREE buffers (73.7 KB per workgroup, two workgroups per CU): the V half of tile j is still read (PV of its second
-// sub-block) after the barrier that publishes tile j + 1, so the DMA for tile j + 2 must not land in it.  Same arithmetic
-// in the same order as attn_fwd16_kernel: bit-identical results.  NQ = query blocks of 16 per wave: 3 (a second set of S
-// accumulators beside 4 blocks' O, Q' and S does not fit 256 registers: the compiler keeps 8 of the 12 Q' fragments in
-// scratch and every MFMA waits for a scratch load).  6 blocks per wave with ONE wave per SIMD (512 registers, 256 of them
-// AGPRs) measured 3.35 ms against 1.84 ms: a single wave does not keep the pipe fed.
-template <int HDP, int NQ>
-__global__ __launch_bounds__(256, NQ > 4 ? 1 : 2) void attn_fwd16p_kernel(AttnP p) {
-  static_assert(HDP == 96, "head_dim 72 layout (ones columns at 72, 73 / 72, 76)");
-  constexpr int KS = HDP / 32, NDB = 5, TILE = 64 * HDP * 2, BUF = 2 * TILE;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int bh, qt;
-  if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, qt)) return;
-  const int b = bh / p.H, hh = bh % p.H;
-  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qrow0 = qt * (64 * NQ) + wave * (16 * NQ) + (lane & 15);  // query of block 0; block cb = + 16 cb
-  const int hd_kv = p.hd + 8;
-
-  const __amdgpu_buffer_rsrc_t rq = slice_rsrc(p.q + b * p.q_sb + hh * p.q_sh, p.q_sl, p.Lq, p.hd);
-  const srd_t rk = slice_srd(p.k + b * p.k_sb + hh * p.k_sh, p.k_sl, p.Lk, hd_kv);
-  const srd_t rv = slice_srd(p.v + b * p.v_sb + hh * p.v_sh, p.v_sl, p.Lk, hd_kv);
-  DmaStage<64, HDP, 1> dk, dv;
-  dk.init(p.k_sl, hd_kv, wave, lane);
-  dv.init(p.v_sl, hd_kv, wave, lane);
-  const unsigned k_step = (unsigned)(64 * p.k_sl * 2), v_step = (unsigned)(64 * p.v_sl * 2);
-  const int nkt = (p.Lk + 63) / 64;
-  auto stage = [&](char* buf, int j) {
-    dk.issue(rk, buf, (unsigned)j * k_step, wave);
-    dv.issue(rv, buf + TILE, (unsigned)j * v_step, wave);
-  };
-  stage(smem, 0);
-
-  const float c = p.scale * LOG2E;
-  bf16x8 qf[NQ][KS];
-#pragma unroll
-  for (int cb = 0; cb < NQ; ++cb)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int e = ks * 32 + 8 * g;
-      unsigned off = (unsigned)(((long)(qrow0 + 16 * cb) * p.q_sl + e) * 2);
-      if (e >= p.hd) off = 0xfffffff0u;
-      qf[cb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
-    }
-#pragma unroll
-  for (int cb = 0; cb < NQ; ++cb)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[cb][ks] = scale_frag(qf[cb][ks], c);  // also retires the loads
-
-  f32x4 o[NDB][NQ];
-#pragma unroll
-  for (int db = 0; db < NDB; ++db)
-#pragma unroll
-    for (int cb = 0; cb < NQ; ++cb) o[db][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m[NQ];
-#pragma unroll
-  for (int cb = 0; cb < NQ; ++cb) m[cb] = 0.f;
-  VDS_WAIT_VM(0);
-  __syncthreads();
-  if (nkt > 1) stage(smem + BUF, 1);
-
-  auto body = [&](auto NCBT) {
-    constexpr int NCB = decltype(NCBT)::value;
-    f32x4 sa[2][NQ], sb[2][NQ];
-    u32x4 pf[NQ];  // P^T fragments (bf16 pairs) of the sub-block whose PV product comes next
-#pragma unroll
-    for (int cb = 0; cb < NQ; ++cb) pf[cb] = u32x4{0u, 0u, 0u, 0u};  // (the first PV stage adds 0 x V of tile 0)
-    // S of one 32-key sub-block, alone (the first one of the sequence)
-    auto s_only = [&](const char* kt, int kb, f32x4 (&sn)[2][NQ]) {
-      if constexpr (NCB > 0) {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) sn[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-          for (int rb = 0; rb < 2; ++rb) {
-            const bf16x8 ak = frag16_row<HDP>(kt, kb * 32 + rb * 16, ks, lane);
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) sn[rb][cb] = mfma16(ak, qf[cb][ks], sn[rb][cb]);
-          }
-      }
-    };
-    // Program order is pinned with sched_barrier(0) between the pieces (the sched_group_barrier pipelines were only partly
-    // honoured: the MFMAs stayed in a clump).  An MFMA holds the issue port for 4 of its 16 pipe cycles; the two VALU
-    // instructions behind it (an exp2: 8 cycles, a max / pack: 4) fill the rest.
-    // X: O^T += V^T P^T of the previous sub-block between the row-maximum instructions of `sc`; then the lazy raise of
-    // the running maximum (wave-uniform branch, rare after the first sub-block)
-    // The first two fragments of a stage are read at the end of the stage before it (`pre`): a stage that starts with its
-    // own LDS reads stands for their latency with nothing of this wave to overlap.
-    bf16x8 pre[2];
-    auto x_stage = [&](const char* vt, int kb, f32x4 (&sc)[2][NQ], bool first, const char* kt_next, int kb_next) {
-      if constexpr (NCB > 0) {
-        float t[NQ];  // per query block: the running maximum over its 8 scores (7 dependent instructions, one register)
-        float mxa = 0.f;
-        constexpr int NOPS = 7 * NCB + (NCB - 1);
-        auto max_op = [&](int op) {
-          if (op < 7 * NCB) {
-            const int cb = op / 7, k = op % 7;
-            if (k == 0) t[cb] = fmaxf(sc[0][cb][0], sc[0][cb][1]);
-            else t[cb] = fmaxf(t[cb], sc[(k + 1) >> 2][cb][(k + 1) & 3]);
-          } else if (op < NOPS) {
-            const int i = op - 7 * NCB;  // 0 .. NCB - 2
-            mxa = fmaxf(i == 0 ? t[0] : mxa, t[i + 1]);
-          }
-        };
-        bf16x8 av[NDB];
-        av[0] = pre[0];
-        av[1] = pre[1];
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-          if (db + 2 < NDB) av[db + 2] = frag16_tr<HDP>(vt, kb * 32, (db + 2) * 16, lane);
-          if (db == NDB - 2 && kt_next) {  // (wave-uniform) the first two K fragments of the Y stage that follows
-            pre[0] = frag16_row<HDP>(kt_next, kb_next * 32, 0, lane);
-            pre[1] = frag16_row<HDP>(kt_next, kb_next * 32 + 16, 0, lane);
-          }
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) {
-            __builtin_amdgcn_sched_barrier(0);
-            o[db][cb] = mfma16(av[db], __builtin_bit_cast(bf16x8, pf[cb]), o[db][cb]);
-            __builtin_amdgcn_sched_barrier(0);
-            max_op(2 * (db * NCB + cb));
-            max_op(2 * (db * NCB + cb) + 1);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NCB == 1) mxa = t[0];
-        if (first || __builtin_amdgcn_ballot_w64(mxa > LAZY_THR) != 0) {
-          asm volatile("; rescale" ::: "memory");  // keeps this a real branch (no if-conversion of the O multiplies)
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) {
-            const float mxf = max_over_lane_groups(t[cb]);  // all four lanes of a query agree
-            const float m_new = bf2f(f2bf(m[cb] + (first ? mxf : fmaxf(mxf, 0.f))));
-            const float delta = m_new - m[cb];
-            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-            m[cb] = m_new;
-#pragma unroll
-            for (int db = 0; db < NDB; ++db) o[db][cb] *= alpha;  // includes the denominator rows
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) sc[rb][cb][r] -= delta;
-            if (g == 1) qf[cb][KS - 1][0] = (__bf16)(-m_new);  // column head_dim of Q' (exact: m is a bf16 value)
-          }
-        }
-      }
-    };
-    // Y: S of the next sub-block between the exp2 / pack instructions of `sc` (NEXT = false: the last sub-block)
-    auto y_stage = [&](const char* kt, int kb, f32x4 (&sc)[2][NQ], f32x4 (&sn)[2][NQ], auto NEXT, const char* vt_next, int kb_next) {
-      if constexpr (NCB > 0) {
-        // VALU work of a query block: 8 exp2, then 4 packs of two probabilities (12 instructions; the packs as asm: the
-        // instruction selector otherwise sinks them behind the last sched_barrier, all 16 in a row)
-        auto soft_op = [&](int op) {
-          if (op < 12 * NCB) {
-            const int cb = op / 12, k = op % 12;
-            if (k < 8) sc[k >> 2][cb][k & 3] = __builtin_amdgcn_exp2f(sc[k >> 2][cb][k & 3]);
-            else {
-              const int j = k - 8;  // dword j of the block's fragment: rows 2 (j & 1), + 1 of accumulator j >> 1
-              unsigned w;
-              asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(sc[j >> 1][cb][2 * (j & 1)]), "v"(sc[j >> 1][cb][2 * (j & 1) + 1]));
-              pf[cb][j] = w;
-            }
-          }
-        };
-        if constexpr (decltype(NEXT)::value) {
-#pragma unroll
-          for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) sn[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-          bf16x8 ak[KS * 2];
-          ak[0] = pre[0];
-          ak[1] = pre[1];
-#pragma unroll
-          for (int u = 0; u < KS * 2; ++u) {  // u = 2 ks + rb
-            if (u + 2 < KS * 2) ak[u + 2] = frag16_row<HDP>(kt, kb * 32 + ((u + 2) & 1) * 16, (u + 2) >> 1, lane);
-            if (u == KS * 2 - 2) {  // the first two V^T fragments of the X stage that follows
-              pre[0] = frag16_tr<HDP>(vt_next, kb_next * 32, 0, lane);
-              pre[1] = frag16_tr<HDP>(vt_next, kb_next * 32, 16, lane);
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-              __builtin_amdgcn_sched_barrier(0);
-              sn[u & 1][cb] = mfma16(ak[u], qf[cb][u >> 1], sn[u & 1][cb]);
-              __builtin_amdgcn_sched_barrier(0);
-              soft_op(2 * (u * NCB + cb));
-              soft_op(2 * (u * NCB + cb) + 1);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
-#pragma unroll
-          for (int op = 0; op < 12 * NCB; ++op) soft_op(op);
-        }
-      }
-    };
-    // keys past Lk need no mask: their zero-filled V rows (ones columns included) add nothing to the numerators or to the
-    // denominator, whatever exp2 makes of their scores
-    char *b0 = smem, *b1 = smem + BUF, *b2 = smem + 2 * BUF;  // tile j, j + 1, j + 2 (= j - 1)
-    auto pre_k = [&](const char* kt, int kb) {
-      if constexpr (NCB > 0) {
-        pre[0] = frag16_row<HDP>(kt, kb * 32, 0, lane);
-        pre[1] = frag16_row<HDP>(kt, kb * 32 + 16, 0, lane);
-      }
-    };
-    auto pre_v = [&](const char* vt, int kb) {
-      if constexpr (NCB > 0) {
-        pre[0] = frag16_tr<HDP>(vt, kb * 32, 0, lane);
-        pre[1] = frag16_tr<HDP>(vt, kb * 32, 16, lane);
-      }
-    };
-    s_only(b0, 0, sa);
-    const char* vprev = b0 + TILE;  // (first X stage: P = 0)
-    pre_v(vprev, 1);
-    for (int j = 0; j < nkt; ++j) {
-      const bool last = j + 1 == nkt;
-      x_stage(vprev, 1, sa, j == 0, b0, 1);
-      y_stage(b0, 1, sa, sb, std::true_type{}, b0 + TILE, 0);
-      x_stage(b0 + TILE, 0, sb, false, nullptr, 0);
-      // tile j + 1 has landed (this wave's pieces; the barrier publishes everyone's) and every wave is past its reads of
-      // tile j - 1: its buffer takes tile j + 2
-      VDS_WAIT_VM(0);
-      __syncthreads();
-      pre_k(last ? b0 : b1, 0);
-      if (j + 2 < nkt) stage(b2, j + 2);
-      // (after the last tile there is no next sub-block: the stage then computes an S nobody reads from the tile at hand --
-      // one code path; with two, the compiler hoists the exp2 instructions of both above the branch, in one clump)
-      y_stage(last ? b0 : b1, 0, sb, sa, std::true_type{}, b0 + TILE, 1);
-      vprev = b0 + TILE;
-      char* t = b0; b0 = b1; b1 = b2; b2 = t;
-    }
-    // PV of the last sub-block (its V: the second half of the last tile = vprev)
-    if constexpr (NCB > 0) {
-#pragma unroll
-      for (int db = 0; db < NDB; ++db) {
-        const bf16x8 av = db < 2 ? pre[db] : frag16_tr<HDP>(vprev, 32, db * 16, lane);
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) o[db][cb] = mfma16(av, __builtin_bit_cast(bf16x8, pf[cb]), o[db][cb]);
-      }
-    }
-  };
-  const int ncb = min(NQ, max(0, (p.Lq - (qt * (64 * NQ) + wave * (16 * NQ)) + 15) >> 4));  // wave-uniform
-  if (ncb > 2) body(std::integral_constant<int, NQ>{});
-  else if (ncb == 2) body(std::integral_constant<int, 2>{});
-  else if (ncb == 1) body(std::integral_constant<int, 1>{});
-  else body(std::integral_constant<int, 0>{});
-
-#pragma unroll
-  for (int cb = 0; cb < NQ; ++cb) {
-    const int qrow = qrow0 + 16 * cb;
-    const float lt = __shfl(o[NDB - 1][cb][0], (lane & 15) | 32, 64);
-    float vo[NDB][4];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) vo[db][e] = o[db][cb][e];
-    store_block_bf16_t(vo, 1.0f / lt, p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_sl, p.hd, g, qrow < p.Lq, p.wide_o);
-    if (qrow < p.Lq && g == 0) p.lse[((long)b * p.H + hh) * p.Lq + qrow] = (m[cb] + __builtin_amdgcn_logf(lt)) * LN2;
-  }
-}
-
 // ===================================== dQ on v_mfma_f32_16x16x32_bf16 =========================
 // attn_bwd_dq_kernel<96, 80, true> on the 16x16x32 shape (see attn_bwd_dkv16_kernel).  S'^T = K Q'^T and
 // dP^T = V dO'^T with 16 key rows from LDS as A and 16 queries in registers as B; dQ^T += K^T dS^T with K^T read by
@@ -1826,7 +1558,7 @@ AttnP to_p(const vds_attn_args* a) {
   p.kv_pad_ones = a->kv_pad_ones;
   p.q_split = 1;
   p.dkv_part = nullptr;
-  const bool wide_on = !(getenv("VDS_ATTN_WIDE_STORES") && getenv("VDS_ATTN_WIDE_STORES")[0] == '0');  // A/B knob
+  const bool wide_on = vdscfg::geti(vdscfg::ATTN_WIDE_STORES) != 0;  // A/B knob
   p.wide_o = wide_on && p.hd > 64 && rows16(p.o, p.o_sb, p.o_sh, p.o_sl);
   p.wide_dq = wide_on && p.hd > 64 && rows16(p.dq, p.dq_sb, p.dq_sh, p.dq_sl);
   p.wide_dkv = wide_on && p.hd > 64 && rows16(p.dk, p.dk_sb, p.dk_sh, p.dk_sl) && rows16(p.dv, p.dv_sb, p.dv_sh, p.dv_sl);
@@ -1854,30 +1586,19 @@ bool strides_ok(const vds_attn_args* a, bool bwd) {
 }
 
 // which head-dim-72 kernels run on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (bit 0: dK/dV, bit 1: dQ,
-// bit 2: forward); -1 = read VDS_ATTN_MFMA16 on first use.  vds_attn_set_variant pins it (tests, A/B).
-int g_attn_variant = -1;
-constexpr int ATTN_VARIANT_DEFAULT = 7;  // all three: measured +4 % (dK/dV), +3.4 % (forward), +1.4 % (dQ) on random data, same box
-int attn_variant() {
-  if (g_attn_variant < 0) {
-    const char* e = getenv("VDS_ATTN_MFMA16");
-    g_attn_variant = e ? atoi(e) : ATTN_VARIANT_DEFAULT;
-  }
-  return g_attn_variant;
-}
+// bit 2: forward).  Knob attn_mfma16 (VDS_ATTN_MFMA16 at load, vds_attn_set_variant afterwards: tests, A/B); default 7 =
+// all three: measured +4 % (dK/dV), +3.4 % (forward), +1.4 % (dQ) on random data, same box
+constexpr int ATTN_VARIANT_DEFAULT = 7;
+int attn_variant() { return vdscfg::geti(vdscfg::ATTN_MFMA16) & 7; }
 
 template <typename K>
 void set_lds(K kern, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-// VDS_ATTN_TAIL_LAST=0 keeps the head-major order for ragged lengths too (A/B)
+// knob attn_tail_last = 0 keeps the head-major order for ragged lengths too (A/B)
 static int tail_last_for(int L, int tile) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("VDS_ATTN_TAIL_LAST");
-    on = e ? atoi(e) : 1;
-  }
-  return (on && L > tile && (L % tile) != 0) ? 1 : 0;
+  return (vdscfg::geti(vdscfg::ATTN_TAIL_LAST) && L > tile && (L % tile) != 0) ? 1 : 0;
 }
 
 template <int HDP, int HDQ>
@@ -1889,14 +1610,9 @@ int run_fwd(AttnP p, hipStream_t s) {
     if constexpr (HDP <= 96) set_lds(attn_fwd_wide_kernel<HDP, HDQ, false>, LDS);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_fwd_wide_kernel<HDP, HDQ, true>, LDS);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_fwd16_kernel<HDP>, LDS);
-    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_fwd16p_kernel<HDP, 3>, 6 * 64 * HDP * 2);
     once = true;
   }
-  static int wide = -1;  // VDS_ATTN_FWD_WIDE=0/1 forces (experiments); default: head_dim 64 / 72, long query sequences
-  if (wide < 0) {
-    const char* e = getenv("VDS_ATTN_FWD_WIDE");
-    wide = e ? atoi(e) : 2;
-  }
+  const int wide = vdscfg::geti(vdscfg::ATTN_FWD_WIDE);  // 0 / 1 forces (experiments); 2 (default): head_dim 64 / 72, long query sequences
   bool use_wide = false;
   if constexpr (HDP == 96) use_wide = wide == 1 || (wide == 2 && p.Lq >= 2048);
   if constexpr (HDP == 64) use_wide = wide == 1 || (wide == 2 && p.Lq >= 2048);  // +2.7 % at head_dim 64
@@ -1919,14 +1635,9 @@ int run_fwd(AttnP p, hipStream_t s) {
       bool done = false;
       if constexpr (HDQ == 80) {
         if (p.kv_pad_ones && p.hd == 72) {
-          const char* pe = getenv("VDS_ATTN_FWD_PIPE");  // 0|1, read per call: the software-pipelined form (round 5)
-          const int pipe = pe ? atoi(pe) : 0;
-          if ((attn_variant() & 4) && pipe) {
-            p.n_rt = cdiv(p.Lq, 192);  // 4 waves x 3 blocks of 16 queries
-            p.tail_last = tail_last_for(p.Lq, 192);
-            hipLaunchKernelGGL((attn_fwd16p_kernel<HDP, 3>), dim3(cdiv(p.B * p.H, 8) * 8 * p.n_rt), dim3(256), 6 * 64 * HDP * 2, s, p);
-          }
-          else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd16_kernel<HDP>), dim3(grid), dim3(256), LDS, s, p);
+          // (round 5 measured a form of this kernel software-pipelined inside the wave: +9.5 % slower, removed in round 6;
+          // profiles/r05/attn_fwd_software_pipelined.log)
+          if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd16_kernel<HDP>), dim3(grid), dim3(256), LDS, s, p);
           else hipLaunchKernelGGL((attn_fwd_wide_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS, s, p);
           done = true;
         }
@@ -1963,7 +1674,6 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv16_kernel<HDP>, LDS_DKV);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv16_kernel<HDP, false>, LDS_DKV);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dq16_kernel<HDP>, LDS_DQ);
-    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dq16_kernel<HDP, 3>, LDS_DQ);
     once = true;
   }
   const long rows = (long)p.B * p.H * p.Lq;
@@ -2002,8 +1712,7 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
     if constexpr (HDP == 96 && HDQ == 80) {
       // cross-attention with padded K / V (kv_pad_ones = 2) and enough workgroups to fill the chip once (B*H*n_rt >= 512;
       // the query-range split below exists in the plain kernel only): the 16x16x32 kernel with S started from -lse2
-      const char* e16 = getenv("VDS_CROSS_DKV16");  // (read per call: 0 = plain kernel, 2 = also for small grids; tests)
-      const int x16 = e16 ? atoi(e16) : 1;
+      const int x16 = vdscfg::geti(vdscfg::CROSS_DKV16);  // 0 = plain kernel, 1 = rule, 2 = also for small grids (tests)
       if (!ones_kv && p.kv_pad_ones == 2 && p.hd == 72 && x16 && ((long)grid >= 512 || x16 == 2) && (attn_variant() & 1)) {
         hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false>), dim3(grid), dim3(256), LDS_DKV, s, p);
         done16 = true;
@@ -2014,12 +1723,8 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
       // of 512) or end on a half-filled round (B = 12: 768 = 1.5 rounds).  The query range is then split so that the
       // launch is ~3 rounds of proportionally shorter workgroups; the fp32 partials (q_split x B*H*Lk*2*hd floats, at
       // the end of the caller's workspace) are summed by dkv_reduce_kernel.  Needs the workspace vds_attn_bwd_workspace_
-      // bytes asks for (args->ws_floats); VDS_ATTN_QSPLIT=1 turns it off, =N forces N.
-      static int force = -1;
-      if (force < 0) {
-        const char* e = getenv("VDS_ATTN_QSPLIT");
-        force = e ? atoi(e) : 0;
-      }
+      // bytes asks for (args->ws_floats); knob attn_qsplit = 1 turns it off, = N forces N.
+      const int force = vdscfg::geti(vdscfg::ATTN_QSPLIT);
       const int split = force > 0 ? force : dkv_qsplit(p.B, p.H, p.Lq, p.Lk);
       const size_t need = (size_t)2 * rows + (size_t)split * p.B * p.H * p.Lk * 2 * p.hd;
       if (split > 1 && (p.hd & 3) == 0 && ws_floats >= need && (p.dk_sl & 3) == 0) {
@@ -2045,12 +1750,9 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
     if constexpr (HDP == 96 && HDQ == 80) ones = p.kv_pad_ones && p.hd == 72;
     vdsprof::Scope ps(ones && p.kv_pad_ones == 1 ? VDS_PROF_ATTN_BWD_DQ : VDS_PROF_ATTN_BWD_DQ_PLAIN, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
     if constexpr (HDP == 96 && HDQ == 80) {
-      const char* nqe = getenv("VDS_ATTN_DQ_NQ");  // read per call (experiment): 3 = 48 queries per wave
-      if (ones && (attn_variant() & 2) && nqe && atoi(nqe) == 3) {
-        p.n_rt = cdiv(p.Lq, 192);
-        p.tail_last = tail_last_for(p.Lq, 192);
-        hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP, 3>), dim3(cdiv(p.B * p.H, 8) * 8 * p.n_rt), dim3(256), LDS_DQ, s, p);
-      } else if (ones && (attn_variant() & 2))
+      // (48 queries per wave -- every fragment read feeds 3 MFMAs, two waves per SIMD instead of three -- measured 2-6 %
+      // slower in round 5, removed in round 6; profiles/r05/attn_dq_three_blocks_per_wave.log)
+      if (ones && (attn_variant() & 2))
         hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP>), dim3(grid), dim3(256), LDS_DQ, s, p);
       else if (ones)
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DQ, s, p);
@@ -2101,7 +1803,7 @@ extern "C" int vds_kv_pad_ones(const void* kv, int64_t ld, int32_t k_col0, int32
 extern "C" int vds_attn_set_variant(int32_t mask) {
   const int prev = attn_variant();
   if (mask < -1 || mask > 7) return VDS_ERR_ARG;
-  g_attn_variant = mask;  // -1: re-read VDS_ATTN_MFMA16 / the default on next use
+  vdscfg::g_val[vdscfg::ATTN_MFMA16] = mask < 0 ? ATTN_VARIANT_DEFAULT : mask;  // -1: back to the default
   return prev;
 }
 

@@ -34,6 +34,7 @@
 #include "rope_stage.h"
 #include <type_traits>
 #include "prof.h"
+#include "config.h"
 #include "../../include/vds.h"
 #include <cstdlib>
 
@@ -1204,14 +1205,9 @@ __global__ __launch_bounds__(256) void qkv_rope_fwd_fp8_tile_kernel(const bf16_t
   }
 }
 
-// VDS_ATTN_TAIL_LAST=0 keeps the head-major order for ragged lengths too (A/B)
+// knob attn_tail_last = 0 keeps the head-major order for ragged lengths too (A/B)
 int tail_last_for(int L, int tile) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("VDS_ATTN_TAIL_LAST");
-    on = e ? atoi(e) : 1;
-  }
-  return (on && L > tile && (L % tile) != 0) ? 1 : 0;
+  return (vdscfg::geti(vdscfg::ATTN_TAIL_LAST) && L > tile && (L % tile) != 0) ? 1 : 0;
 }
 
 template <typename K>
@@ -1331,11 +1327,8 @@ extern "C" int vds_attn_fp8_bwd(const vds_attn_fp8_args* a, vds_stream_t stream)
     vdsprof::Scope ps(VDS_PROF_ATTN_FP8_DKV, s, 2.0 * prod, bytes + 4.0 * p.B * p.H * p.hd * (double)p.Lk);
     hipLaunchKernelGGL((attn8_bwd_dkv_kernel<72>), dim3(grid), dim3(256), LDS_DKV, s, p);
   }
-  static int dq_waves = 0;  // VDS_ATTN8_DQ_WAVES=4|6 (experiments)
-  if (!dq_waves) {
-    const char* e = getenv("VDS_ATTN8_DQ_WAVES");
-    dq_waves = (e && atoi(e) == 6) ? 6 : 4;  // measured (B=6, L=8208): 2.0 ms with 4 waves, 2.7 ms with 6
-  }
+  // knob attn8_dq_waves = 4 | 6 (experiments); measured (B=6, L=8208): 2.0 ms with 4 waves, 2.7 ms with 6
+  const int dq_waves = vdscfg::geti(vdscfg::ATTN8_DQ_WAVES) == 6 ? 6 : 4;
   p.n_rt = cdiv(p.Lq, 32 * dq_waves);
   p.tail_last = tail_last_for(p.Lq, 32 * dq_waves);
   grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
@@ -1360,12 +1353,8 @@ extern "C" int vds_qkv_rope_fwd_fp8(const void* qkv, const float* cosb, const fl
   const long n = (long)B * H * L * 8;
   hipStream_t s = (hipStream_t)stream;
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, s, 0.0, (double)B * L * H * (6.0 * hd + 3.0 * ROWB + (v0 ? 2.0 * hd : 0.0)));
-  // token-tile kernel (rope_stage.h) for the model's head size; VDS_ROPE_TILE=0 keeps the element-wise kernel (A/B)
-  static int tile = -1;
-  if (tile < 0) {
-    const char* e = getenv("VDS_ROPE_TILE");
-    tile = e ? atoi(e) : 4;
-  }
+  // token-tile kernel (rope_stage.h) for the model's head size; knob rope_tile = 0 keeps the element-wise kernel (A/B)
+  const int tile = vdscfg::geti(vdscfg::ROPE_TILE);
   if (tile > 0 && hd == 72 && hdp == 96 && H <= 256 && L >= 8 &&
       ropestage::lds_bytes(tile == 2 ? 2 : tile == 8 ? 8 : 4, H * 72) <= 160 * 1024) {  // else: the element-wise kernel
     const long ntok = (long)B * L;

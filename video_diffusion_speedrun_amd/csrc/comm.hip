@@ -24,6 +24,7 @@
 
 #include "../../include/vds.h"
 #include "common.h"
+#include "config.h"
 
 namespace vdserr {
 static thread_local char g_msg[512] = "";
@@ -70,7 +71,7 @@ bool sym(F& f, const char* name) {
 
 bool bind() {
   if (R.lib) return true;
-  const char* cands[] = {getenv("VDS_RCCL_PATH"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+  const char* cands[] = {vdscfg::rccl_path(), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
   // the copy the process already holds (torch links one): a second RCCL in one process only wastes memory
   R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
   for (const char* c : cands)
@@ -153,8 +154,7 @@ extern "C" int vds_comm_init(int32_t rank, int32_t world, const void* unique_id,
   RCCL_TRY(R.CommInitRank(&g_comm, world, id, rank), "ncclCommInitRank");  // on the calling thread's current HIP device
   g_rank = rank;
   g_world = world;
-  const char* s = getenv("VDS_COMM_SCHEDULE");
-  g_allpairs = s && strcmp(s, "allpairs") == 0;
+  g_allpairs = vdscfg::geti(vdscfg::COMM_ALLPAIRS) != 0;  // (VDS_COMM_SCHEDULE=allpairs at load, or vds_knob_set)
   return VDS_OK;
 }
 

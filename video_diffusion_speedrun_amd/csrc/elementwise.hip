@@ -7,6 +7,7 @@
 #include "common.h"
 #include "rope_stage.h"
 #include "prof.h"
+#include "config.h"
 #include "../../include/vds.h"
 
 namespace {
@@ -1271,14 +1272,8 @@ inline int ok() { return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUN
 // rows of one sample per workgroup: ~768 workgroups in total (3 per CU, enough waves to stream HBM)
 // while every workgroup still folds >= 8 rows into its column sums before the atomics
 inline int rows_per_block_for(int L, int B) {
-  static int min_rows = -1, target = 768;
-  if (min_rows < 0) {
-    const char* e = getenv("VDS_EW_MIN_ROWS");
-    min_rows = e ? atoi(e) : 8;
-    if (min_rows < 1) min_rows = 1;
-    const char* t = getenv("VDS_EW_WGS");
-    if (t && atoi(t) > 0) target = atoi(t);
-  }
+  const int min_rows = vdscfg::geti(vdscfg::EW_MIN_ROWS) < 1 ? 1 : vdscfg::geti(vdscfg::EW_MIN_ROWS);
+  const int target = vdscfg::geti(vdscfg::EW_WGS) > 0 ? vdscfg::geti(vdscfg::EW_WGS) : 768;
   const long total = (long)L * B;
   int rpb = (int)((total + target - 1) / target);
   // (round 5) mid-sized problems (C3b at B = 2: 16 416 rows -> 22 per workgroup): the column-sum epilogue -- two LDS passes
@@ -1301,11 +1296,10 @@ inline int rows_per_block_for(int L, int B) {
   } while (0)
 
 // widths whose 16-byte chunk count is a multiple of 16 but not of 64 (D = 384, 768, 1152): the four-rows-per-wave form
-// of the RMSNorm kernels; VDS_RMSNORM_Q4=0 (read per call) keeps the one-row-per-wave form (A/B)
+// of the RMSNorm kernels; knob rmsnorm_q4 = 0 keeps the one-row-per-wave form (A/B)
 static bool rmsnorm_q4(int D) {
   if (D != 384 && D != 768 && D != 1152) return false;
-  const char* e = getenv("VDS_RMSNORM_Q4");
-  return !(e && atoi(e) == 0);
+  return vdscfg::geti(vdscfg::RMSNORM_Q4) != 0;
 }
 
 extern "C" int vds_rmsnorm_mod_fwd(const void* x, int64_t ldx, const void* w, const float* mod, int64_t ldmod,
@@ -1469,13 +1463,9 @@ extern "C" int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M
 }
 
 // the wave-per-token kernels need 16-byte aligned head rows (hdp % 8 == 0), hd/2 a multiple of 4 and D <= 2048;
-// VDS_ROPE_TOK=0 keeps the 8-byte-access backward kernel (A/B)
+// knob rope_tok = 0 keeps the 8-byte-access backward kernel (A/B)
 static bool rope_tok_form(int H, int hd, int hdp) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("VDS_ROPE_TOK");
-    on = e ? atoi(e) : 1;
-  }
+  const int on = vdscfg::geti(vdscfg::ROPE_TOK);
   return on && (hdp & 7) == 0 && (hd & 7) == 0 && H * hd <= 2048;
 }
 
@@ -1487,13 +1477,9 @@ extern "C" int vds_qkv_rope_fwd(const void* qkv, const float* cosb, const float*
   if (((hdp - hd) >> 2) > (hd >> 3)) return VDS_ERR_UNSUPPORTED;
   const long n = (long)B * L * H * (hd >> 3);
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_FWD, (hipStream_t)stream, 0.0, (v0 ? 14.0 : 12.0) * B * L * H * hd);
-  // token-tile kernel (16-byte accesses, LDS staging) for the head sizes the model builds; VDS_ROPE_TILE=0 keeps the
-  // element-wise kernel (A/B), VDS_ROPE_TILE=2|4|8 picks the tokens per workgroup
-  static int tile = -1;
-  if (tile < 0) {
-    const char* e = getenv("VDS_ROPE_TILE");
-    tile = e ? atoi(e) : 4;
-  }
+  // token-tile kernel (16-byte accesses, LDS staging) for the head sizes the model builds; knob rope_tile = 0 keeps the
+  // element-wise kernel (A/B), 2 | 4 | 8 picks the tokens per workgroup
+  const int tile = vdscfg::geti(vdscfg::ROPE_TILE);
   if (tile > 0 && H * hd <= 2048 && H <= 256 && L >= 8) {
     const long ntok = (long)B * L;
 #define ROPE_TILE(HD, HDP, T)                                                                                      \
@@ -1737,11 +1723,7 @@ __global__ __launch_bounds__(64 * SL_FWD_WAVES) void small_linear_fwd_mfma_kerne
 // unsharded comparisons of tests/test_model_gpu.py rely on).  VDS_ADALN_MFMA=0: the row kernel (A/B).
 static bool small_linear_fwd_mfma(const float* x, const bf16_t* W, const bf16_t* bias, float* y, int M, int N, int K,
                                   int act_in, const SLBatch& bt, int nb, hipStream_t s) {
-  static int mfma_on = -1;
-  if (mfma_on < 0) {
-    const char* e = getenv("VDS_ADALN_MFMA");
-    mfma_on = (e && e[0] == '0') ? 0 : 1;
-  }
+  const int mfma_on = vdscfg::geti(vdscfg::ADALN_MFMA);
   const size_t lds = (size_t)SL_FWD_TERMS * 16 * (K * 2 + 16);
   if (!mfma_on || M > 16 || (K & 31) || (N & 15) || lds > 160 * 1024 || N < 1024) return false;  // (small N: the row kernel's finer grid)
   static bool attr = false;

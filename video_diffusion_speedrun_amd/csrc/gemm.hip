@@ -19,11 +19,11 @@
 //   * 1-D grid with an XCD-aware, grouped tile order (8 XCDs, private L2s).
 #include "common.h"
 #include "prof.h"
+#include "config.h"
 #include "../../include/vds.h"
 #include <cmath>
-#include <cstdlib>
+#include <cstdint>
 #include <cstring>
-#include <algorithm>
 #include <mutex>
 #include <type_traits>
 
@@ -51,6 +51,7 @@ struct GemmP {
   int row_base;    // GATE_RES: index of this launch's row 0 in the whole matrix (row-peeled launches; gate row = (row + base) / rows_per_batch)
   int split_k;
   int atomic;
+  long slab_stride;  // deterministic split-K: split y writes its fp32 tile to C + y * slab_stride floats (0: all splits share C)
   unsigned a_bytes, b_bytes;
   int tiles_m, tiles_n;
   int group_m;
@@ -289,7 +290,7 @@ __device__ __forceinline__ void epilogue_64x64(const GemmP& p, float* stg, int r
     const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + c8 * 8 + 4);
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if constexpr (EPI == VDS_EPI_F32) {
-      float* c = reinterpret_cast<float*>(p.C) + grow * p.ldc + gcol;
+      float* c = reinterpret_cast<float*>(p.C) + (long)blockIdx.y * p.slab_stride + grow * p.ldc + gcol;
       *reinterpret_cast<f32x4*>(c) = lo;
       *reinterpret_cast<f32x4*>(c + 4) = hi;
     } else if constexpr (EPI == VDS_EPI_STORE) {
@@ -646,12 +647,7 @@ namespace big {
 constexpr int BM = 256;
 constexpr int HALF = 16384;                                 // one half-tile
 constexpr int LDS_BYTES = 8 * 64 * EPI_LD * 4;               // 139264 >= 2 * BUF (131072)
-// Geometry of the two output-tile widths.  WN = 256: the four-half-tile scheme described above.  WN = 192 (round 4):
-// a wave owns 128 x 48 outputs = 2 quadrant rows x (one 32-column + one 16-column block); B is staged as B0 = the
-// 32-column blocks of the four wave columns (128 rows, 16 KiB) and B1 = their 16-column blocks (64 rows, 8 KiB),
-// and a K tile is consumed in THREE phases of 16 MFMAs  (A0,B0) -> B1 with both A halves -> (A1, B0 from registers).
-// 1152 = 6 x 192 (and 3456 = 18, 4608 = 24): the N = 1152 linears of DiT-XL lose the half-empty fifth column of
-// 256-wide tiles (10 % of their MFMA work).
+// Geometry of the output-tile widths: WN = 256, the four-half-tile scheme described above, and WN = 128 (below).
 template <int WN> struct Geo;
 template <> struct Geo<256> {
   static constexpr int BN = 256, WCOLS = 64, NJ = 4, A0 = 0, A1 = HALF, B0 = 2 * HALF, B1 = 3 * HALF, BUF = 4 * HALF;
@@ -664,30 +660,11 @@ template <> struct Geo<256> {
 template <> struct Geo<128> {
   static constexpr int BN = 128, WCOLS = 32, NJ = 2, A0 = 0, A1 = HALF, B0 = 2 * HALF, B1 = 3 * HALF, BUF = 4 * HALF;
 };
-template <> struct Geo<192> {
-  static constexpr int BN = 192, WCOLS = 48, NJ = 3, A0 = 0, A1 = HALF, B0 = 2 * HALF, B1 = 3 * HALF, BUF = 3 * HALF + HALF / 2;
-};
 
 // local index (row of a k-contiguous half-tile, or 8-column chunk base of a k-major one) -> offset inside the output
-// tile: groups of G consecutive indices, STRIDE apart, starting at OFF (256-wide: halves alternate in groups of 64 rows /
-// 32 columns; 192-wide B: 32-column groups at 48 w, 16-column groups at 48 w + 32)
+// tile: groups of G consecutive indices, STRIDE apart, starting at OFF (halves alternate in groups of 64 rows / 32 columns)
 template <int G, int STRIDE, int OFF>
 __device__ __forceinline__ int to_tile(int local) { return (local / G) * STRIDE + OFF + (local % G); }
-
-// k-major [64 k][64 cols] quarter tile (B1 of the 192-wide tiling in NN problems): 128-byte rows, two k rows per 256-byte
-// bank row; 32-byte segment c of row k is stored at segment c ^ swz_km64(k), which makes the 8 rows x 32 B a
-// ds_read_b64_tr_b16 half-wave touches land on 8 different 32-byte bank groups
-__device__ __forceinline__ int swz_km64(int krow) { return ((krow >> 1) & 1) | (((krow >> 3) & 1) << 1); }
-__device__ __forceinline__ bf16x8 frag_km64(const char* tile, int col0, int ks, int lane) {
-  const int g = lane >> 4, i = lane & 15;
-  const int krow = ks * 32 + 8 * g + (i >> 2);
-  const int seg = (col0 >> 4) ^ swz_km64(krow);
-  const char* p = tile + krow * 128 + seg * 32 + (i & 3) * 8;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 4 * 128));
-  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, r);
-}
 
 // ---- k-major fp8 operands (FMT 3: the weight-gradient product dW = dy^T x read straight from the token-major fp8
 // copies, no transposed copies) -----------------------------------------------------------------------------------
@@ -726,8 +703,7 @@ __device__ __forceinline__ void half_offsets_km8(unsigned (&voff)[2], int (&kchu
   }
 }
 
-// per-lane source byte offsets of the NP 1-KiB pieces this wave stages of one half-tile (NP = 2: 16 KiB) or quarter
-// tile (NP = 1: the 8-KiB B1 of the 192-wide tiling)
+// per-lane source byte offsets of the NP = 2 1-KiB pieces this wave stages of one 16-KiB half-tile
 template <bool KMAJOR, int G, int STRIDE, int OFF, int NP>
 __device__ __forceinline__ void half_offsets(unsigned (&voff)[NP], int (&kchunk)[NP], int wave, int lane, long ld,
                                              int origin) {
@@ -739,16 +715,11 @@ __device__ __forceinline__ void half_offsets(unsigned (&voff)[NP], int (&kchunk)
       const int chunk = swz_kc(row, lane & 7);
       kchunk[j] = chunk * 8;
       voff[j] = (unsigned)(((long)(origin + to_tile<G, STRIDE, OFF>(row)) * ld + chunk * 8) * 2);
-    } else if constexpr (NP == 2) {
+    } else {
+      static_assert(NP == 2, "half-tiles are staged as two 1-KiB pieces per wave");
       const int krow = q * 4 + (lane >> 4);
       const int pc = lane & 15;
       const int chunk = (((pc >> 1) ^ swz_km(krow)) << 1) | (pc & 1);
-      kchunk[j] = 0;
-      voff[j] = (unsigned)(((long)krow * ld + origin + to_tile<G, STRIDE, OFF>(chunk * 8)) * 2);
-    } else {
-      const int krow = q * 8 + (lane >> 3);
-      const int pc = lane & 7;
-      const int chunk = (((pc >> 1) ^ swz_km64(krow)) << 1) | (pc & 1);
       kchunk[j] = 0;
       voff[j] = (unsigned)(((long)krow * ld + origin + to_tile<G, STRIDE, OFF>(chunk * 8)) * 2);
     }
@@ -775,80 +746,26 @@ __device__ __forceinline__ void issue_half(srd_t rsrc, char* slot, const unsigne
 // 128 k instead of 64, one v_mfma_f32_16x16x128_f8f6f4 replaces two 16x16x32 bf16 MFMAs in the same 32 cycles --
 // bytes staged, LDS reads and the phase schedule are identical, the contraction per K tile doubles.  The
 // addressing below counts in 2-byte units (p.K, lda, ldb = bytes / 2).
-#ifndef VDS_GEMM_NPH
-#define VDS_GEMM_NPH 2  // phases per K tile of the 256-wide tiling (4: the loop of rounds 1-3, for A/B builds)
-#endif
-// ---- stream-K (round 5) ------------------------------------------------------------------------------------------
-// The persistent form of the kernel (gemm_sk_kernel below) hands a workgroup SEGMENTS of output tiles: K tiles
-// [kt_begin, kt_end) of one tile.  A segment that does not start at K tile 0 is a PRODUCER: its accumulators go to the
-// workgroup's slab (fp32, in the accumulator register layout: lane-private 16-byte pieces, 1 KiB per wave-instruction)
-// and a flag is raised.  The segment that starts at 0 but ends early is the tile's FINISHER: after its own K tiles it adds
-// the slabs of the `n_follow` workgroups behind it (which computed the later K tiles of the same tile at the START of
-// their ranges, i.e. earlier in time) and runs the fused epilogue.  Hand-off (MI355X_MICROARCH.md, "Valid forms", table
-// row 1): slab stores and loads are all sc1 (write-through / L1-bypassing), every storing wave drains vmcnt, a workgroup
-// barrier, ONE lane raises the flag with an sc1 store; the finisher's lane 0 polls with sc1 loads, a workgroup barrier
-// releases the other waves; the finisher lowers the flag again (each flag has one producer and one consumer per launch,
-// launches on a stream are ordered), so no host-side epoch is needed and a captured HIP graph can replay the launch.
-struct SkSeg {
-  int mode;          // 0 whole tile, 1 producer, 2 finisher
-  int w;             // this workgroup's slab / flag index
-  unsigned long long follow;  // finisher: bit i set = workgroup w + 1 + i produced a slab of this tile
-  float* slab;       // [workgroups][65536] fp32
-  unsigned* flag;    // [workgroups][16] (64-byte pitch)
-  unsigned* status;  // != 0: a poll timed out (results of that launch are wrong; never seen in practice, bounds the spin)
-};
-constexpr int SK_SLAB_FLOATS = 256 * 256;
-constexpr int SK_FLAG_PITCH = 16;
-
-// list index -> output tile: XCD-aware (blocks b, b + 8, .. share an XCD: each XCD gets a contiguous chunk of the list) +
-// grouped order (groups of group_m row tiles, row fastest)
-__host__ __device__ __forceinline__ void tile_of(int L, int nwg, int tiles_m, int tiles_n, int group_m, int& tile_m, int& tile_n) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, idx = L >> 3;
-  const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int group = group_m * tiles_n;
-  const int first_m = (pid / group) * group_m;
-  const int gsz = (tiles_m - first_m) < group_m ? (tiles_m - first_m) : group_m;
-  tile_m = first_m + (pid % group) % gsz;
-  tile_n = (pid % group) / gsz;
-}
-
 // One output tile: rows m0 .. m0 + 255, columns n0 .. n0 + BN - 1, K tiles kt_begin .. kt_end - 1.
-// first: the workgroup's first tile (persistent kernel: later tiles synchronise on the LDS ring first and find the GELU
-// table already staged).
-// CST (persistent kernel, round 5): compact epilogue staging -- 32-row steps through the SECOND ring buffer only (8 waves x
-// 32 x EPI_LD floats = 69632 B behind the first buffer's 65536) -- so that the NEXT tile's first K tile (`nx`: its four
-// half-tiles, issued here right after the ring has drained) can land in the first ring buffer while this tile's epilogue
-// runs; the next call (`pre`) then only adds the second K tile's three half-tiles.  The stores of the epilogue are
-// younger than those DMAs and older than the second K tile's, so the ordinary counted wait still retires the first K tile.
-struct NextTile { int m0, n0, narrow; };  // m0 < 0: none
-// persistent kernel (gemm_pk_kernel): what gemm_tile needs to start the NEXT tile of the workgroup's list under this tile's
-// epilogue -- its list index (< 0: this was the last one) and the geometry tile_of wants
-struct PkCtx { int T; int next; int tiles_m, tiles_n, group_m, narrow; };
-template <int LAYOUT, int EPI, int FMT, int WN, int NPH, bool CST = false>
+template <int LAYOUT, int EPI, int FMT, int WN>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int m0, const int n0, const int kt_begin,
-                                          const int kt_end, const SkSeg& sk, const bool first, const bool pre = false,
-                                          const PkCtx* pk = nullptr) {
-  static_assert(FMT == 0 || (FMT != 3 && LAYOUT == VDS_NT) || (FMT == 3 && LAYOUT == VDS_TN && WN != 192),
+                                          const int kt_end) {
+  static_assert(FMT == 0 || (FMT != 3 && LAYOUT == VDS_NT) || (FMT == 3 && LAYOUT == VDS_TN),
                 "fp8 operands: k-contiguous (FMT 1 / 2, NT) or both k-major (FMT 3, TN: the weight gradient)");
   using G = Geo<WN>;
   constexpr int WCOLS = G::WCOLS, NJ = G::NJ, BUF = G::BUF;
   constexpr int SLOT_A0 = G::A0, SLOT_A1 = G::A1, SLOT_B0 = G::B0, SLOT_B1 = G::B1;
-  constexpr int NPB1 = WN == 192 ? 1 : 2;  // 1-KiB pieces per wave of the B1 half / quarter tile
+  constexpr int NPB1 = 2;  // 1-KiB pieces per wave of the B1 half-tile
   constexpr bool A_KM = (LAYOUT == VDS_TN);
   constexpr bool B_KM = (LAYOUT != VDS_NT);
-  int tid_ = threadIdx.x;
-  // (persistent kernel: without this the compiler hoists every lane-derived address of the tile body out of the tile loop
-  // and keeps them live across it -- 170-430 spilled VGPRs; opaque per call, they are recomputed per tile and die)
-  asm volatile("" : "+v"(tid_));
-  const int tid = tid_, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const srd_t ra = make_srd(p.A, p.a_bytes);
   const srd_t rb = make_srd(p.B, p.b_bytes);
   constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
   char* const ring = smem + (USE_LUT ? LUT_BYTES : 0);  // stage ring / epilogue staging area
-  if (!first) __syncthreads();  // the previous tile's epilogue is done with the ring (its stores may still be in flight)
-  if (USE_LUT && first) {
+  if (USE_LUT) {
     // the GELU table (16 KiB) sits at LDS address 0, in front of the ring: two 1-KiB pieces per wave, older than
     // every operand DMA, so the counted waits of the main loop cover them
     const srd_t rl = make_srd(g_gelu_lut[EPI == VDS_EPI_DGELU ? 1 : 0], LUT_BYTES);
@@ -874,12 +791,9 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   if constexpr (FMT == 3) {
   } else if constexpr (WN == 128) {
     half_offsets<B_KM, 32, 32, 0, 2>(vb0, cb0, wave, lane, p.ldb, n0);
-  } else if constexpr (WN == 256) {
+  } else {
     half_offsets<B_KM, 32, 64, 0, 2>(vb0, cb0, wave, lane, p.ldb, n0);
     half_offsets<B_KM, 32, 64, 32, 2>(vb1, cb1, wave, lane, p.ldb, n0);
-  } else {
-    half_offsets<B_KM, 32, 48, 0, 2>(vb0, cb0, wave, lane, p.ldb, n0);
-    half_offsets<B_KM, 16, 48, 32, 1>(vb1, cb1, wave, lane, p.ldb, n0);
   }
   // (FMT 3: a K tile is 128 token rows of lda / ldb BYTES = 2 BK rows in the 2-byte units the addressing counts in)
   const unsigned a_step = A_KM ? (unsigned)((FMT == 3 ? 2 * BK : BK) * p.lda * 2) : BK * 2;
@@ -904,9 +818,9 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
       acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       // pins the 128 zeroing moves HERE, before the pipeline fill below: hipcc otherwise sinks them behind the first
       // vmcnt wait + barrier, onto the critical path of every tile (the wait hides them for free): fp8 NT + dgrad per
-      // block 4.13 -> 4.03 ms, bf16 unchanged.  (Not in the 192-wide tiling nor in the TN kernels: there the pin costs
-      // registers -- 85-104 spilled VGPRs, 7.9 -> 12.8 ms per block resp. the fp8 weight-gradient GEMMs 2.5x slower.)
-      if constexpr (WN != 192 && LAYOUT != VDS_TN) asm volatile("" : "+v"(acc[i][j]));
+      // block 4.13 -> 4.03 ms, bf16 unchanged.  (Not in the TN kernels: there the pin costs registers -- 85-104 spilled
+      // VGPRs, the fp8 weight-gradient GEMMs 2.5x slower.)
+      if constexpr (LAYOUT != VDS_TN) asm volatile("" : "+v"(acc[i][j]));
     }
 
   constexpr int KS = FMT == 0 ? 2 : 1;  // MFMA k-steps per K tile
@@ -944,15 +858,15 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
       }
   };
 
-  if constexpr (WN == 256 && NPH == 2) {
-  // ---- round 4 (default): TWO phases of 32 MFMAs per K tile -- quadrant row 0 <- A0, B0, B1; quadrant row 1 <- A1 with
+  if constexpr (WN == 256) {
+  // ---- TWO phases of 32 MFMAs per K tile -- quadrant row 0 <- A0, B0, B1; quadrant row 1 <- A1 with
   // both B halves kept in registers -- i.e. 4 barriers per K tile instead of 8 and the same fragment registers.  Issue
   // order per K tile: A0 B0 B1 | A1; A1(T+1) is issued in phase 0 of tile T, A0 B0 B1 of tile T+2 in phase 1; each wait
   // leaves 8 pieces (four half-tiles) in flight and retires a half-tile one phase before it is read; a slot is
-  // re-staged one phase after its last read (the distances of the four-phase loop below, which NPH = 4 keeps for A/B:
-  // VDS_GEMM_PHASES=4).  Same-process A/B, B = 12 (profiles/r04/gemm_2phase_vs_4phase.log): qkv forward 0.705 -> 0.668
-  // ms, q_cross 0.252 -> 0.237, fc1 dgrad 0.945 -> 0.908, 8192^3 1.40 -> 1.50 PFLOP/s; results bit-identical.
-  if (!(CST && pre)) { issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0); }
+  // re-staged one phase after its last read.  Against the four-phase loop of rounds 1-3 (one quadrant per phase; removed in
+  // round 6), same-process A/B, B = 12 (profiles/r04/gemm_2phase_vs_4phase.log): qkv forward 0.705 -> 0.668 ms, q_cross
+  // 0.252 -> 0.237, fc1 dgrad 0.945 -> 0.908, 8192^3 1.40 -> 1.50 PFLOP/s; results bit-identical.
+  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0);
   issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1); issue(kt_begin + 1, 2, 1);
   VDS_WAIT_VM(8);
   __builtin_amdgcn_s_barrier();
@@ -1000,10 +914,11 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
     k_tile(T, std::integral_constant<int, 0>{});
     if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
   }
-  } else if constexpr (WN == 128) {
+  } else {
+  static_assert(WN == 128, "tile widths: 256, and 128 for a narrow last tile column");
   // ---- narrow last tile column: A0 B0 | A1 per K tile (6 pieces per wave), two phases of 16 MFMAs; the waits leave 6
   // pieces (three half-tiles) in flight; retire / re-stage distances as in the two-phase loop above
-  if (!(CST && pre)) { issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 3, 0); }
+  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 3, 0);
   issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1);
   VDS_WAIT_VM(6);
   __builtin_amdgcn_s_barrier();
@@ -1045,161 +960,12 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
     k_tile(T, std::integral_constant<int, 0>{});
     if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
   }
-  } else if constexpr (WN == 256) {
-  // ---- prologue: 7 half-tiles in flight, A0 / B0 of the first tile landed -------------------
-  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 2, 0); issue(kt_begin, 3, 0);
-  issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1); issue(kt_begin + 1, 2, 1);
-  VDS_WAIT_VM(10);
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
-
-  frag_t fa[4][KS], fb0[2][KS], fb1[2][KS];
-#define VDS_QUADRANT(QA, QB, FB)                                                                      \
-  do {                                                                                                \
-    __builtin_amdgcn_s_setprio(1);                                                                    \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                 \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
-          acc[(QA) * 4 + i][(QB) * 2 + j] = mma(fa[i][ks], FB[j][ks], acc[(QA) * 4 + i][(QB) * 2 + j]); \
-    __builtin_amdgcn_s_setprio(0);                                                                    \
-  } while (0)
-
-  // one K tile = 4 phases; unrolled by two so that the buffer parity is a compile-time constant
-  auto k_tile = [&](int T, auto PAR) {
-    constexpr int par = decltype(PAR)::value;
-    const char* buf = ring + par * BUF;
-    // ---- phase 0: quadrant (0,0) <- A0, B0 ----
-    read_a4(buf + SLOT_A0, fa);
-    read_b2(buf + SLOT_B0, fb0);
-    issue(T + 1, 3, par ^ 1);
-    VDS_WAIT_LGKM0();
-    VDS_WAIT_VM(10);  // B1(T) landed
-    __builtin_amdgcn_s_barrier();
-    VDS_QUADRANT(0, 0, fb0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 1: quadrant (0,1) <- B1 ----
-    read_b2(buf + SLOT_B1, fb1);
-    issue(T + 2, 0, par);
-    VDS_WAIT_LGKM0();
-    VDS_WAIT_VM(10);  // A1(T) landed
-    __builtin_amdgcn_s_barrier();
-    VDS_QUADRANT(0, 1, fb1);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 2: quadrant (1,1) <- A1 ----
-    read_a4(buf + SLOT_A1, fa);
-    issue(T + 2, 1, par);
-    VDS_WAIT_LGKM0();
-    __builtin_amdgcn_s_barrier();
-    VDS_QUADRANT(1, 1, fb1);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 3: quadrant (1,0) <- B0 (registers) ----
-    issue(T + 2, 2, par);
-    VDS_WAIT_VM(10);  // A0(T+1), B0(T+1) landed
-    __builtin_amdgcn_s_barrier();
-    VDS_QUADRANT(1, 0, fb0);
-    __builtin_amdgcn_s_barrier();
-  };
-  for (int T = kt_begin; T < kt_end; T += 2) {
-    k_tile(T, std::integral_constant<int, 0>{});
-    if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
-  }
-#undef VDS_QUADRANT
-  } else {
-  // ---- 256 x 192: pieces per wave A0 2, B0 2, A1 2, B1 1, issued in the order A0 B0 (A1 B1) of every K tile --------
-  // prologue: the first tile and A0 / B0 of the second in flight (11 pieces), A0 / B0 of the first landed
-  issue(kt_begin, 0, 0); issue(kt_begin, 1, 0); issue(kt_begin, 3, 0); issue(kt_begin, 2, 0);
-  issue(kt_begin + 1, 0, 1); issue(kt_begin + 1, 1, 1);
-  VDS_WAIT_VM(7);
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
-
-  frag_t fa0[4][KS], fa1[4][KS], fb0[2][KS], fb1[KS];
-  auto read_b1 = [&](const char* slot) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if constexpr (FMT != 0) fb1[ks] = frag_kc8(slot, wc * 16, lane);
-      else if constexpr (B_KM) fb1[ks] = frag_km64(slot, wc * 16, ks, lane);
-      else fb1[ks] = frag_kc(slot, wc * 16, ks, lane);
-    }
-  };
-  // one K tile = 3 phases of 16 MFMAs; a wait retires a piece one phase before it is read, a slot is re-staged at the
-  // earliest one phase after its last read (same distances as the four-phase loop above)
-  auto k_tile = [&](int T, auto PAR) {
-    constexpr int par = decltype(PAR)::value;
-    const char* buf = ring + par * BUF;
-    // ---- phase 0: rows of A0 x the 32-column blocks ----
-    read_a4(buf + SLOT_A0, fa0);
-    read_b2(buf + SLOT_B0, fb0);
-    issue(T + 1, 3, par ^ 1);
-    issue(T + 1, 2, par ^ 1);
-    VDS_WAIT_LGKM0();
-    VDS_WAIT_VM(7);  // A1(T), B1(T) landed
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mma(fa0[i][ks], fb0[j][ks], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 1: the 16-column block x both row halves ----
-    read_b1(buf + SLOT_B1);
-    read_a4(buf + SLOT_A1, fa1);
-    issue(T + 2, 0, par);
-    VDS_WAIT_LGKM0();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][2] = mma(fa0[i][ks], fb1[ks], acc[i][2]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[4 + i][2] = mma(fa1[i][ks], fb1[ks], acc[4 + i][2]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 2: rows of A1 x the 32-column blocks (both operands in registers) ----
-    issue(T + 2, 1, par);
-    VDS_WAIT_VM(7);  // A0(T+1), B0(T+1) landed
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[4 + i][j] = mma(fa1[i][ks], fb0[j][ks], acc[4 + i][j]);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-  };
-  for (int T = kt_begin; T < kt_end; T += 2) {
-    k_tile(T, std::integral_constant<int, 0>{});
-    if (T + 1 < kt_end) k_tile(T + 1, std::integral_constant<int, 1>{});
-  }
   }
   // ---- epilogue: two 64-row quadrant rows per wave through the wave's private staging area ----
   // The aux tiles (residual / pre-activation) of BOTH quadrant rows are requested here, before the drain of the
   // operand pipeline: one exposed HBM round trip per output tile instead of one per quadrant row (with one workgroup
   // per CU nothing else hides it).  The drain waits for everything but these 16 loads (loads return in order).
-  if (sk.mode == 1) {
-    // ---- stream-K producer: accumulators -> slab (sc1 stores), flag ----
-    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave groups
-    VDS_WAIT_VM(0);                              // (the zero-fill tail DMAs: the next tile re-stages the ring)
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(sk.slab + (long)sk.w * SK_SLAB_FLOATS, SK_SLAB_FLOATS * 4);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
-                                               (unsigned)(((wave * 32 + i * NJ + j) * 64 + lane) * 16), 0, 16 /* sc1 */);
-    VDS_WAIT_VM(0);
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(sk.flag + sk.w * SK_FLAG_PITCH, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  constexpr int NIT = CST ? 4 : 8;        // row groups of 8 rows per staging step
+  constexpr int NIT = 8;                  // row groups of 8 rows per staging step
   constexpr int NSTEP = 16 / NIT;         // steps per wave tile of 128 rows
   constexpr int RSTEP = 8 * NIT;          // rows per step
   u32x4 auxr2[NSTEP][NIT];
@@ -1215,62 +981,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   else VDS_WAIT_VM(0);
   __builtin_amdgcn_s_barrier();
 
-  if constexpr (CST && FMT != 3) {
-    NextTile nx = NextTile{-1, -1, 0};
-    if (pk && pk->next >= 0) {
-      int tm2, tn2;
-      tile_of(pk->next, pk->T, pk->tiles_m, pk->tiles_n, pk->group_m, tm2, tn2);
-      nx = NextTile{tm2 * BM, tn2 * 256, (pk->narrow && tn2 == pk->tiles_n - 1) ? 1 : 0};
-    }
-    if (nx.m0 >= 0) {
-      // the ring has drained and every wave is past its last fragment read: the next tile's first K tile goes into ring
-      // buffer 0 now (the epilogue below stages behind it); offsets of THIS tile are dead, their registers are reused
-      half_offsets<A_KM, 64, 128, 0, 2>(va[0], ca[0], wave, lane, p.lda, nx.m0);
-      half_offsets<A_KM, 64, 128, 64, 2>(va[1], ca[1], wave, lane, p.lda, nx.m0);
-      char* buf0 = ring;
-      const int krem0 = p.K;
-      if (nx.narrow) {
-        unsigned vn[2];
-        int cn[2];
-        half_offsets<B_KM, 32, 32, 0, 2>(vn, cn, wave, lane, p.ldb, nx.n0);
-        issue_half<A_KM>(ra, buf0 + SLOT_A0, va[0], ca[0], 0u, krem0, wave);
-        issue_half<B_KM>(rb, buf0 + SLOT_B0, vn, cn, 0u, krem0, wave);
-        issue_half<A_KM>(ra, buf0 + SLOT_A1, va[1], ca[1], 0u, krem0, wave);
-      } else {
-        unsigned vn0[2], vn1[2];
-        int cn0[2], cn1[2];
-        half_offsets<B_KM, 32, 64, 0, 2>(vn0, cn0, wave, lane, p.ldb, nx.n0);
-        half_offsets<B_KM, 32, 64, 32, 2>(vn1, cn1, wave, lane, p.ldb, nx.n0);
-        issue_half<A_KM>(ra, buf0 + SLOT_A0, va[0], ca[0], 0u, krem0, wave);
-        issue_half<B_KM>(rb, buf0 + SLOT_B0, vn0, cn0, 0u, krem0, wave);
-        issue_half<B_KM>(rb, buf0 + SLOT_B1, vn1, cn1, 0u, krem0, wave);
-        issue_half<A_KM>(ra, buf0 + SLOT_A1, va[1], ca[1], 0u, krem0, wave);
-      }
-    }
-  }
-
-  // ---- stream-K finisher (sk.follow != 0): wait for the workgroups that computed the later K tiles of this tile; their
-  // slabs are added while the accumulators are staged below.  (The accumulators themselves are never modified: an add
-  // loop over them -- or an add behind an `if` -- makes the register allocator copy all 128 and spill 150-400 VGPRs.)
-  const unsigned long long follow = sk.follow;
-  if (follow != 0ull) {
-    if (tid == 0) {
-      for (unsigned long long rest = follow; rest != 0ull; rest &= rest - 1ull) {
-        const unsigned* fl = sk.flag + (sk.w + 1 + __builtin_ctzll(rest)) * SK_FLAG_PITCH;
-        int spins = 0;
-        while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-          __builtin_amdgcn_s_sleep(16);
-          if (++spins > (1 << 24)) {  // ~ seconds: give up instead of hanging the GPU
-            __hip_atomic_store(sk.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  constexpr int STG_BASE = CST ? 65536 : 0, STG_WAVE = RSTEP * EPI_LD;  // (floats per wave)
+  constexpr int STG_BASE = 0, STG_WAVE = RSTEP * EPI_LD;  // (floats per wave)
   float* stg = reinterpret_cast<float*>(ring + STG_BASE) + wave * STG_WAVE;
   float dq = 1.0f;
   if constexpr (FMT != 0) dq = (p.sa ? *p.sa : 1.0f) * (p.sb ? *p.sb : 1.0f);
@@ -1298,14 +1009,6 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {  // lane (c, g): row i * 16 + c, columns j * 16 + 4 g .. + 3 (see `mma`)
         f32x4 v = acc[qa * (RSTEP / 16) + i][j];
-        if (follow != 0ull) {  // (wave-uniform; sc1 loads: the hand-off's rule is that EVERY load of a slab bypasses L1)
-          for (unsigned long long rest = follow; rest != 0ull; rest &= rest - 1ull) {
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(sk.slab + (long)(sk.w + 1 + __builtin_ctzll(rest)) * SK_SLAB_FLOATS,
-                                                        SK_SLAB_FLOATS * 4);
-            v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                     rs, (unsigned)(((wave * 32 + (qa * (RSTEP / 16) + i) * NJ + j) * 64 + lane) * 16), 0, 16 /* sc1 */));
-          }
-        }
         if constexpr (FMT != 0) v *= dq;
         *reinterpret_cast<f32x4*>(stg + (i * 16 + (lane & 15)) * EPI_LD + j * 16 + 4 * (lane >> 4)) = v;
       }
@@ -1320,13 +1023,6 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
     if (!done) epilogue_64x64<EPI, EMIT, USE_LUT, WCOLS, NIT>(p, stg, row0, col0, lane, cs, ew[qa], auxr, lut);
     __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next quadrant row
   }
-  if (follow != 0ull) {  // every wave has read its slab values: lower the producers' flags for the next launch
-    __syncthreads();
-    if (tid == 0)
-      for (unsigned long long rest = follow; rest != 0ull; rest &= rest - 1ull)
-        __hip_atomic_store(sk.flag + (sk.w + 1 + __builtin_ctzll(rest)) * SK_FLAG_PITCH, 0u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-  }
   if constexpr (EMIT) {
     if ((p.e_q || p.e_qt) && p.e_amax_out) {
 #pragma unroll
@@ -1336,8 +1032,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
     }
   }
   if constexpr (EMIT) {
-    // (the transposed copy's byte tile needs 9216 B of staging per wave: not in the compact layout; its launcher avoids it)
-    if (!CST && p.e_qt) {
+    if (p.e_qt) {
       // transposed fp8 copy of the wave's 128 x 64 outputs: the staging area (fp32 tiles consumed) becomes a
       // [128 m][64 k] byte tile (72-byte rows), read back as 4x4 byte blocks, transposed in registers (v_perm_b32)
       // and stored as 128 contiguous bytes per k row and instruction
@@ -1399,7 +1094,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, char* smem, const int 
   }
 }
 
-template <int LAYOUT, int EPI, int FMT = 0, int WN = 256, int NPH = VDS_GEMM_NPH>
+template <int LAYOUT, int EPI, int FMT = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // ---- tile id: XCD-aware + grouped order (as the 128^2 kernel) ---------------------------
@@ -1414,7 +1109,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
   const int gsz = min(p.tiles_m - first_m, p.group_m);
   const int tile_m = first_m + (pid % group) % gsz;
   const int tile_n = (pid % group) / gsz;
-  const int m0 = tile_m * BM, n0 = tile_n * Geo<WN>::BN;
+  const int m0 = tile_m * BM, n0 = tile_n * 256;
 
   const int kt_total = (p.K + BK - 1) / BK;
   int kt_begin = 0, kt_end = kt_total;
@@ -1424,78 +1119,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmP p) {
     kt_end = min(kt_total, kt_begin + per);
     if (kt_begin >= kt_end) return;
   }
-  const SkSeg none = {0, 0, 0ull, nullptr, nullptr, nullptr};
-  if constexpr (WN == 256 && NPH == 2) {
-    if (p.narrow && tile_n == p.tiles_n - 1) {
-      gemm_tile<LAYOUT, EPI, FMT, 128, NPH>(p, smem, m0, n0, kt_begin, kt_end, none, true);
-      return;
-    }
+  if (p.narrow && tile_n == p.tiles_n - 1) {
+    gemm_tile<LAYOUT, EPI, FMT, 128>(p, smem, m0, n0, kt_begin, kt_end);
+    return;
   }
-  gemm_tile<LAYOUT, EPI, FMT, WN, NPH>(p, smem, m0, n0, kt_begin, kt_end, none, true);
+  gemm_tile<LAYOUT, EPI, FMT, 256>(p, smem, m0, n0, kt_begin, kt_end);
 }
 
-// ---- persistent stream-K kernel: one workgroup per CU -----------------------------------------------------------------
-// The tile list (XCD-aware grouped order, narrow last column included) is cut into  dp = T / G  rounds that the G
-// workgroups take data-parallel -- workgroup b computes tiles b, b + G, ..: at any time the chip works on G consecutive
-// tiles of the list, the L2 locality of the plain launch -- and the remaining  T % G  tiles, whose K iterations are
-// divided evenly (by cost: a narrow tile's iteration counts 3/4) over the workgroups: every workgroup first computes its
-// iteration range [it_start[b], it_start[b + 1]) of that region (producer / finisher segments, see SkSeg), then its
-// whole tiles.  The launch takes  work / G + one hand-off  instead of  ceil(T / G)  tile times: the last, partly filled
-// round of the plain launch (N = 1152 at B = 12: 7.1 rounds of work run as ~7.8) is gone, and small problems (B = 1 .. 4:
-// 0.6 .. 2.5 rounds) fill the chip.
-constexpr int SK_MAX_WG = 256;
-struct SkSched {
-  int G, dp, t_dp, kt;         // workgroups, whole rounds, dp * G, K tiles per output tile
-  float* slab; unsigned* flag; unsigned* status;
-  int it_start[SK_MAX_WG + 2];  // iteration range starts in the region's iteration space (tile-major, kt per tile)
-};
-
-template <int LAYOUT, int EPI, int FMT>
-__global__ __launch_bounds__(512, 2) void gemm_sk_kernel(GemmP p, SkSched sc) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.x;
-  const int nwg = p.tiles_m * p.tiles_n;
-  int it = sc.it_start[b];
-  const int it_end = sc.it_start[b + 1];
-  bool first = true;
-  for (int r = 0; it < it_end || r < sc.dp;) {
-    int L, k0, k1;
-    SkSeg seg = {0, b, 0ull, sc.slab, sc.flag, sc.status};
-    if (it < it_end) {  // a segment of the stream-K region
-      const int ti = it / sc.kt;
-      k0 = it - ti * sc.kt;
-      k1 = min(sc.kt, k0 + (it_end - it));
-      L = sc.t_dp + ti;
-      if (k0 > 0) seg.mode = 1;
-      else if (k1 < sc.kt) {
-        seg.mode = 2;
-        const int tile_end = (ti + 1) * sc.kt;
-        for (int wp = b + 1; wp < sc.G && wp <= b + 64 && sc.it_start[wp] < tile_end; ++wp)
-          if (sc.it_start[wp + 1] > sc.it_start[wp]) seg.follow |= 1ull << (wp - b - 1);  // (empty ranges produce nothing)
-      }
-      it += k1 - k0;
-    } else {  // a whole tile of the data-parallel rounds
-      L = r * sc.G + b;
-      k0 = 0;
-      k1 = sc.kt;
-      ++r;
-    }
-    int tile_m, tile_n;
-    tile_of(L, nwg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * 256;
-    if (p.narrow && tile_n == p.tiles_n - 1) gemm_tile<LAYOUT, EPI, FMT, 128, 2>(p, smem, m0, n0, k0, k1, seg, first);
-    else gemm_tile<LAYOUT, EPI, FMT, 256, 2>(p, smem, m0, n0, k0, k1, seg, first);
-    first = false;
-  }
-}
-
-template <int LAYOUT, int EPI, int FMT = 0, int WN = 256, int NPH = VDS_GEMM_NPH>
+template <int LAYOUT, int EPI, int FMT = 0>
 int launch(const GemmP& p, hipStream_t s) {
   constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
   constexpr int LDS_TOTAL = LDS_BYTES + (USE_LUT ? LUT_BYTES : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI, FMT, WN, NPH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<LAYOUT, EPI, FMT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     attr_set = true;
   }
@@ -1507,279 +1144,10 @@ int launch(const GemmP& p, hipStream_t s) {
   vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : LAYOUT == VDS_NN ? VDS_PROF_GEMM_NN
                                                                                                        : VDS_PROF_GEMM_TN,
                     s, 2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
-  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT, WN, NPH>), grid, dim3(512), LDS_TOTAL, s, p);
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, EPI, FMT>), grid, dim3(512), LDS_TOTAL, s, p);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 
-// ---- persistent kernel with the next tile's first K tile under the epilogue (round 5) ---------------------------------
-// One workgroup per CU, each with its own list of tiles, built on the host (pk_schedule below) and copied into LDS when the
-// kernel starts: no tile counter.  (The first version drew tiles from per-XCD atomic counters.  A returning atomic is a
-// poor fit for this kernel: hipcc waits for it where its value is formed -- the drawing wave, and behind it the workgroup
-// at its next barrier, stands for the 1-2 us round trip, as much as the overlap saves -- and issued from inline asm, to be
-// collected a tile later, its destination register gets copied by the compiler between the two tile bodies before the value
-// has landed.  profiles/r05/gemm_persistent_overlap.log has both measurements.)
-struct PkSched { int T; const int* lists; int pitch; };  // lists[b * pitch]: n_b, then the n_b list indices of workgroup b
-constexpr int PK_MAX_PITCH = 1024;                       // (4096 B of LDS are free behind the compact staging area)
-
-template <int LAYOUT, int EPI, int FMT>
-__global__ __launch_bounds__(512, 2) void gemm_pk_kernel(GemmP p, PkSched sc) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
-  int* lst = reinterpret_cast<int*>(smem + (USE_LUT ? LUT_BYTES : 0) + 65536 + 8 * 32 * EPI_LD * 4);  // behind the staging area
-  for (int i = threadIdx.x; i < sc.pitch; i += 512) lst[i] = sc.lists[(long)blockIdx.x * sc.pitch + i];
-  __syncthreads();
-  const int n = __builtin_amdgcn_readfirstlane(lst[0]);
-  PkCtx pk = {sc.T, -1, p.tiles_m, p.tiles_n, p.group_m, p.narrow};
-  const SkSeg none = {0, 0, 0ull, nullptr, nullptr, nullptr};
-  const int kt = (p.K + BK - 1) / BK;
-  bool first = true, pre = false;
-  for (int k = 0; k < n; ++k) {
-    const int cur = __builtin_amdgcn_readfirstlane(lst[1 + k]);
-    pk.next = k + 1 < n ? __builtin_amdgcn_readfirstlane(lst[2 + k]) : -1;
-    int tile_m, tile_n;
-    tile_of(cur, sc.T, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * 256;
-    if (p.narrow && tile_n == p.tiles_n - 1) gemm_tile<LAYOUT, EPI, FMT, 128, 2, true>(p, smem, m0, n0, 0, kt, none, first, pre, &pk);
-    else gemm_tile<LAYOUT, EPI, FMT, 256, 2, true>(p, smem, m0, n0, 0, kt, none, first, pre, &pk);
-    first = false;
-    pre = pk.next >= 0;
-  }
-}
-
-// ---- stream-K launch ----------------------------------------------------------------------------------------------
-// Workspace of the stream-K hand-offs, one per device, allocated on first use and kept: [flags 256 x 64 B | status |
-// slabs n_cu x 256 KiB].  (Not during a stream capture: the caller then takes the plain launch.)  GEMMs of one device must
-// not run stream-K launches concurrently on two streams (they would share slabs); the package issues them on one.
-struct SkWs { char* base; int n_cu; };
-constexpr size_t SK_HDR = 32768;
-static std::mutex g_sk_mu;
-static SkWs g_sk_ws[64] = {};
-static bool g_sk_tried[64] = {};
-inline SkWs* sk_workspace(hipStream_t s) {
-  std::mutex& mu = g_sk_mu;
-  SkWs* ws = g_sk_ws;
-  bool* tried = g_sk_tried;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  if (!tried[dev]) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-      (void)hipGetLastError();
-      return nullptr;  // (not remembered: the next eager call allocates)
-    }
-    tried[dev] = true;
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) return nullptr;
-    if (ncu > SK_MAX_WG) ncu = SK_MAX_WG;
-    void* b = nullptr;
-    if (hipMalloc(&b, SK_HDR + (size_t)ncu * SK_SLAB_FLOATS * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipMemsetAsync(b, 0, SK_HDR, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(b); return nullptr; }
-    ws[dev].base = (char*)b;
-    ws[dev].n_cu = ncu;
-  }
-  return ws[dev].base ? &ws[dev] : nullptr;
-}
-
-constexpr int SK_MIN_SEG = 4;    // K tiles: shorter segments do not amortise their pipeline fill and slab
-constexpr int SK_MAX_SPLIT = 4;  // segments per output tile (each but the first costs a 256-KiB slab round trip)
-constexpr int SK_SNAP = 2;       // a range boundary this close to a tile boundary moves onto it
-
-// the schedule of one launch (see gemm_sk_kernel); false: nothing to gain (the plain launch is taken)
-inline bool sk_schedule(const GemmP& p, int G, SkSched& sc) {
-  const int T = p.tiles_m * p.tiles_n;
-  sc.G = G;
-  sc.dp = T / G;
-  sc.t_dp = sc.dp * G;
-  sc.kt = (p.K + BK - 1) / BK;
-  const int tsk = T - sc.t_dp;
-  const long total = (long)tsk * sc.kt;
-  if (total >= (1l << 30)) return false;
-  for (int w = 0; w <= G + 1; ++w) sc.it_start[w] = 0;
-  if (tsk == 0) return sc.dp > 0;
-  long cu[SK_MAX_WG + 1];  // cumulative cost of the region's tiles: 4 per K tile, 3 for a narrow tile's
-  cu[0] = 0;
-  for (int j = 0; j < tsk; ++j) {
-    int tm, tn;
-    tile_of(sc.t_dp + j, T, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-    cu[j + 1] = cu[j] + (long)((p.narrow && tn == p.tiles_n - 1) ? 3 : 4) * sc.kt;
-  }
-  const int min_seg = std::max(SK_MIN_SEG, (sc.kt + SK_MAX_SPLIT - 1) / SK_MAX_SPLIT);
-  long W = std::max<long>(total / min_seg, tsk);
-  W = std::min<long>(std::max<long>(W, 1), G);
-  int j = 0;
-  for (int w = 0; w <= G + 1; ++w) {
-    if (w >= W) { sc.it_start[w] = (int)total; continue; }
-    const long pos = cu[tsk] * w / W;
-    while (j + 1 < tsk && cu[j + 1] <= pos) ++j;
-    const long wgt = (cu[j + 1] - cu[j]) / sc.kt;
-    long it = (long)j * sc.kt + (pos - cu[j] + wgt - 1) / wgt;
-    const long r = it % sc.kt;
-    if (r != 0 && r <= SK_SNAP) it -= r;
-    else if (r != 0 && sc.kt - r <= SK_SNAP) it += sc.kt - r;
-    if (w > 0 && it < sc.it_start[w - 1]) it = sc.it_start[w - 1];
-    sc.it_start[w] = (int)std::min(it, total);
-  }
-  return true;
-}
-
-// returns VDS_OK / an error, or 1 when the stream-K launch is not available here (caller takes the plain launch)
-template <int LAYOUT, int EPI, int FMT = 0>
-int launch_sk(const GemmP& p, hipStream_t s) {
-  SkWs* ws = sk_workspace(s);
-  if (!ws) return 1;
-  SkSched sc;
-  if (!sk_schedule(p, ws->n_cu, sc)) return 1;
-  sc.flag = reinterpret_cast<unsigned*>(ws->base);
-  sc.status = reinterpret_cast<unsigned*>(ws->base + SK_MAX_WG * SK_FLAG_PITCH * 4);
-  sc.slab = reinterpret_cast<float*>(ws->base + SK_HDR);
-  constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
-  constexpr int LDS_TOTAL = LDS_BYTES + (USE_LUT ? LUT_BYTES : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<LAYOUT, EPI, FMT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-    attr_set = true;
-  }
-  if constexpr (USE_LUT) {
-    if (!ensure_gelu_lut()) return VDS_ERR_LAUNCH;
-  }
-  const double k = FMT != 0 ? p.prof_k : (double)p.K;
-  vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : VDS_PROF_GEMM_NN, s,
-                    2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
-  hipLaunchKernelGGL((gemm_sk_kernel<LAYOUT, EPI, FMT>), dim3(sc.G), dim3(512), LDS_TOTAL, s, p, sc);
-  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
-}
-
-// The lists of gemm_pk_kernel: what the hardware's greedy dispatch of the plain launch would do, simulated with the
-// measured tile times (7.3 us + 1.44 us per K tile for a full tile; the 128-column tile of a narrow last column costs 0.83
-// of that: it saves 5 us of 31 at K = 1152; VDS_PK_NARROW_COST overrides).  List index L belongs to XCD L & 7 (tile_of gives each XCD a contiguous chunk of the grouped tile order) and so
-// do the workgroups b with b & 7 == L & 7: every XCD's chunk is dealt, in list order, to whichever of its workgroups is free
-// first.  Depends on the shape only: built once per (tiles_m, tiles_n, narrow, K tiles, workgroups), kept on the device.
-inline int device_cus() {
-  static int cus[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  if (cus[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    cus[dev] = n;
-  }
-  return cus[dev];
-}
-struct PkLists { int tiles_m, tiles_n, narrow, kt, G, dev; int pitch; int* d; std::vector<int> h; };
-static std::mutex g_pk_mu;
-static std::vector<PkLists*> g_pk_lists;
-inline void pk_schedule(PkLists& e, int group_m) {
-  const int T = e.tiles_m * e.tiles_n, G = e.G;
-  std::vector<std::vector<int>> per(G);
-  static const double narrow_cost = [] {
-    const char* v = getenv("VDS_PK_NARROW_COST");
-    const double x = v ? atof(v) : 0.0;
-    return x > 0.0 && x <= 1.0 ? x : 0.83;
-  }();
-  const double full = 7.3 + 1.44 * e.kt, narrow = narrow_cost * full;
-  for (int x = 0; x < 8; ++x) {
-    std::vector<int> wgs;
-    for (int b = x; b < G; b += 8) wgs.push_back(b);
-    if (wgs.empty()) continue;
-    std::vector<double> free_at(wgs.size(), 0.0);
-    for (int L = x; L < T; L += 8) {
-      size_t w = 0;
-      for (size_t i = 1; i < wgs.size(); ++i)
-        if (free_at[i] < free_at[w]) w = i;  // (ties: the lowest workgroup, as the dispatcher)
-      int tm, tn;
-      tile_of(L, T, e.tiles_m, e.tiles_n, group_m, tm, tn);
-      free_at[w] += (e.narrow && tn == e.tiles_n - 1) ? narrow : full;
-      per[wgs[w]].push_back(L);
-    }
-  }
-  size_t longest = 0;
-  for (auto& v : per) longest = v.size() > longest ? v.size() : longest;
-  e.pitch = (int)longest + 1;
-  e.h.assign((size_t)G * e.pitch, -1);
-  for (int b = 0; b < G; ++b) {
-    e.h[(size_t)b * e.pitch] = (int)per[b].size();
-    for (size_t i = 0; i < per[b].size(); ++i) e.h[(size_t)b * e.pitch + 1 + i] = per[b][i];
-  }
-}
-// the device copy of the lists for this problem, or nullptr (too long for LDS / allocation failed / first use inside a
-// stream capture: the caller takes the plain launch)
-inline const PkLists* pk_lists(const GemmP& p, int G, hipStream_t s) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  const int kt = (p.K + BK - 1) / BK;
-  std::lock_guard<std::mutex> lk(g_pk_mu);
-  for (PkLists* e : g_pk_lists)
-    if (e->tiles_m == p.tiles_m && e->tiles_n == p.tiles_n && e->narrow == p.narrow && e->kt == kt && e->G == G && e->dev == dev)
-      return e->d ? e : nullptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return nullptr;  // (not remembered: the next eager call builds them)
-  }
-  PkLists* e = new PkLists{p.tiles_m, p.tiles_n, p.narrow, kt, G, dev, 0, nullptr, {}};
-  pk_schedule(*e, p.group_m);
-  g_pk_lists.push_back(e);
-  if (e->pitch > PK_MAX_PITCH) return nullptr;
-  int* d = nullptr;
-  if (hipMalloc(&d, e->h.size() * sizeof(int)) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  // (synchronous on purpose: once per shape, and the lists are then valid for every stream of the device)
-  if (hipMemcpy(d, e->h.data(), e->h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipFree(d);
-    return nullptr;
-  }
-  e->d = d;
-  return e;
-}
-
-// returns VDS_OK / an error, or 1 when the persistent launch is not available here (caller takes the plain launch)
-template <int LAYOUT, int EPI, int FMT = 0>
-int launch_pk(const GemmP& p, hipStream_t s) {
-  if (p.e_qt) return 1;  // (the transposed fp8 copy stages a byte tile that the compact staging has no room for)
-  const int T = p.tiles_m * p.tiles_n;
-  const int n_cu = device_cus();
-  if (n_cu <= 0) return 1;
-  const int G = T < n_cu ? T : n_cu;
-  const PkLists* pl = pk_lists(p, G, s);
-  if (!pl) return 1;
-  PkSched sc = {T, pl->d, pl->pitch};
-  constexpr bool USE_LUT = EPI == VDS_EPI_BIAS_GELU || EPI == VDS_EPI_DGELU;
-  constexpr int LDS_TOTAL = LDS_BYTES + (USE_LUT ? LUT_BYTES : 0);
-  static_assert(65536 + 8 * 32 * EPI_LD * 4 + PK_MAX_PITCH * 4 <= LDS_BYTES, "staging + tile list fit behind ring buffer 0");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<LAYOUT, EPI, FMT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-    attr_set = true;
-  }
-  if constexpr (USE_LUT) {
-    if (!ensure_gelu_lut()) return VDS_ERR_LAUNCH;
-  }
-  const double k = FMT != 0 ? p.prof_k : (double)p.K;
-  vdsprof::Scope ps(FMT != 0 ? VDS_PROF_GEMM_FP8 : LAYOUT == VDS_NT ? VDS_PROF_GEMM_NT : VDS_PROF_GEMM_NN, s,
-                    2.0 * p.M * p.N * k, (FMT != 0 ? 1.0 : 2.0) * ((double)p.M * k + (double)p.N * k) + 2.0 * (double)p.M * p.N);
-  hipLaunchKernelGGL((gemm_pk_kernel<LAYOUT, EPI, FMT>), dim3(G), dim3(512), LDS_TOTAL, s, p, sc);
-  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
-}
-
-// the current device's "a hand-off poll timed out" word, cleared; synchronises the device (tests / debugging)
-inline int sk_status_and_clear() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  std::lock_guard<std::mutex> lk(g_sk_mu);
-  if (!g_sk_ws[dev].base) return 0;  // (a device that never ran a stream-K launch has nothing to report)
-  unsigned v = 0, zero = 0;
-  char* st = g_sk_ws[dev].base + SK_MAX_WG * SK_FLAG_PITCH * 4;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpy(&v, st, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (v) (void)hipMemcpy(st, &zero, 4, hipMemcpyHostToDevice);
-  return (int)v;
-}
 }  // namespace big
 
 // =====================================================================================
@@ -2008,76 +1376,93 @@ int launch(const GemmP& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 
-}  // namespace
 
-static int g_force_tile = -1;  // -1: read VDS_GEMM_TILE on first use; 0 auto; 128 | 256 | 192 (= 256 x 192) | 2 (= 256 x 128) forced
-
-// 256 x 192 against 256 x 256 tiles on an NT / NN problem: rounds of 256 workgroups (one per CU) x time per tile.
-// Measured (tools/bench_gemm_w192.py, profiles/r04/gemm_w192_vs_256_b12.log, DiT-XL shapes, B = 12, same box): a
-// 192-wide tile takes 0.87 of the time of a 256-wide one for 0.75 of its MFMA work -- 22 instead of 24 fragment reads and
-// 7 instead of 8 LDS-DMA pieces per K tile feed 48 instead of 64 MFMAs, three barrier pairs instead of four, and the
-// epilogue issues the same number of store instructions with a quarter of their lanes idle -- so at B = 12 (385 row
-// tiles) it LOSES everywhere: N = 1152: 6 column tiles -> 10 rounds x 0.87 = 8.7 against 5 -> 8 rounds (measured 0.255
-// against 0.235 ms); N = 3456: 28 x 0.87 against 22.  Where the round count does not grow (per-GPU batches of 1-2: 325
-// tiles of 256 and 390 of 192 are both two rounds) the whole step measured equal within noise (B = 1: 103.9 vs 104.6
-// ms, B = 2: 175.1 vs 174.7 ms, profiles/r04/).  So the tiling is NOT chosen by default: VDS_GEMM_W192_FACTOR=f
-// enables the cost model with f = time per unit of MFMA work relative to the 256-wide tile (measured 1.16),
-// vds_gemm_force_tile(192) / VDS_GEMM_TILE=192 force it (tests run it on every GEMM case).
-static bool prefer_w192(long M, long N) {
-  static double f = -1.0;
-  if (f < 0) {
-    const char* e = getenv("VDS_GEMM_W192_FACTOR");
-    f = e ? atof(e) : 0.0;
-  }
-  if (f <= 0.0) return false;
-  const long tm = (M + 255) / 256;
-  const double c256 = (double)((tm * ((N + 255) / 256) + 255) / 256);
-  const double c192 = (double)((tm * ((N + 191) / 192) + 255) / 256) * 0.75 * f;
-  return c192 < c256;
+// ---- fixed-order split-K (deterministic mode, round 6) --------------------------------------------------------------------
+// vds_set_deterministic(1, workspace, bytes): a split-K weight gradient writes one dense fp32 slab [M, N] per split into the
+// caller's workspace with plain stores (GemmP::slab_stride; the epilogue offsets C by blockIdx.y slabs) and this kernel
+// adds the slabs to C in split order: C = ((C + s0) + s1) + ..  -- the same words every run, where the fp32 atomics of the
+// default mode commit in whatever order the workgroups finish.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int n_slabs, long slab_stride, float* C, long ldc,
+                                                            int M, int N) {
+  const long i4 = (long)blockIdx.x * 256 + threadIdx.x;  // one 16-byte piece of a row per thread
+  const int n4 = N >> 2;
+  if (i4 >= (long)M * n4) return;
+  const long row = i4 / n4;
+  const int col = (int)(i4 % n4) * 4;
+  float* c = C + row * ldc + col;
+  f32x4 v = *reinterpret_cast<const f32x4*>(c);
+  const float* w = ws + row * N + col;
+  for (int sidx = 0; sidx < n_slabs; ++sidx) v += *reinterpret_cast<const f32x4*>(w + (long)sidx * slab_stride);
+  *reinterpret_cast<f32x4*>(c) = v;
 }
 
-// 256-wide tiling: the last tile column runs the 256 x 128 body when it holds at most 128 columns (VDS_GEMM_NARROW=0: off,
-// read per call for same-process A/B)
-static int narrow_last_column(long N) {
-  const char* e = getenv("VDS_GEMM_NARROW");
-  if (e && atoi(e) == 0) return 0;
+static float* g_det_ws = nullptr;  // deterministic mode: caller-allocated workspace (vds_set_deterministic)
+static size_t g_det_ws_bytes = 0;
+
+}  // namespace
+
+namespace vdsdet {
+float* workspace(size_t* bytes) {
+  if (bytes) *bytes = g_det_ws_bytes;
+  return g_det_ws;
+}
+}  // namespace vdsdet
+
+extern "C" int vds_set_deterministic(int32_t on, void* workspace, size_t workspace_bytes) {
+  const int prev = vdscfg::geti(vdscfg::DETERMINISTIC);
+  if (on != 0 && on != 1) return VDS_ERR_ARG;
+  if (on && workspace && ((uintptr_t)workspace & 15)) return VDS_ERR_ARG;
+  vdscfg::g_val[vdscfg::DETERMINISTIC] = on;
+  g_det_ws = on ? (float*)workspace : nullptr;
+  g_det_ws_bytes = on && workspace ? workspace_bytes : 0;
+  return prev;
+}
+
+namespace {
+
+// `tile` of vds_gemm_force_tile / VDS_GEMM_TILE: 0 = cost model | 128 | 256 | 2 (= 256 x 128)
+inline int force_tile() { return vdscfg::geti(vdscfg::GEMM_TILE); }
+
+// 256-wide tiling: the last tile column runs the 256 x 128 body when it holds at most 128 columns
+inline int narrow_last_column(long N) {
+  if (!vdscfg::geti(vdscfg::GEMM_NARROW)) return 0;
   const long rem = N % 256;
   return rem > 0 && rem <= 128;
 }
 
-// stream-K launches of the 256^2 kernel (NT / NN): -1 = VDS_GEMM_SK (default OFF; read per call), 0 off, 1 on.
-// Measured a net loss at the DiT-XL shapes (profiles/r05/negative_gemm_stream_k_*.log): the plain launch's greedy hardware
-// dispatch does not pay a whole round for a partly filled last one (its tiles run faster on the emptier chip), the
-// persistent tile loop saves nothing over the hardware's workgroup dispatch (1.00-1.02x on whole rounds), and a seam moves
-// a 256 KiB fp32 slab through HBM at ~50-65 GB/s per CU (~10 us against a 28-33 us K = 1152 tile): +5.5 % per block at
-// B = 12, +9 % at B = 2; only K = 4608 launches at B = 2 gain (3-9 %).  Kept as a tested experiment.  (Also: a persistent
-// one-workgroup-per-CU grid with a static share of the work assumes the whole chip -- never under overlapped collectives.)
-static int g_sk_mode = -1;
-static bool sk_enabled() {
-  if (g_sk_mode >= 0) return g_sk_mode != 0;
-  const char* e = getenv("VDS_GEMM_SK");
-  return e && atoi(e) == 1;
+// a split-K launch in deterministic mode: slabs in the workspace + the fixed-order reduction.  `launch_fn` launches the
+// GEMM kernel on `p`.  The split count is lowered until its slabs fit the workspace (1 = no slabs needed).
+template <typename F>
+int launch_split_det(GemmP& p, float* C, long ldc, hipStream_t s, F launch_fn) {
+  const int kt_total = cdiv(p.K, 64);
+  int split = p.split_k;
+  const size_t slab = (size_t)p.M * p.N * 4;
+  while (split > 1 && (g_det_ws == nullptr || (size_t)split * slab > g_det_ws_bytes)) --split;
+  if (split <= 1) {  // one workgroup per output tile: a single (atomic) add per element and call is order-free
+    p.split_k = 1;
+    return launch_fn(p);
+  }
+  const int per = cdiv(kt_total, split);
+  const int n_eff = cdiv(kt_total, per);  // splits that own K tiles (the others return at once and write nothing)
+  p.split_k = split;
+  p.atomic = 0;
+  p.C = g_det_ws;
+  p.ldc = p.N;
+  p.slab_stride = (long)p.M * p.N;
+  const int rc = launch_fn(p);
+  if (rc != VDS_OK) return rc;
+  const long n4 = (long)p.M * (p.N >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)g_det_ws, n_eff,
+                     p.slab_stride, C, ldc, p.M, p.N);
+  return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
-constexpr int SK_MIN_TILES = 64;  // fewer 256^2 tiles: the hand-offs cost more than the idle CUs they fill
-// persistent launches with the next tile's first K tile under the epilogue (gemm_pk_kernel): VDS_GEMM_PK (read per call)
-static bool pk_enabled() {
-  const char* e = getenv("VDS_GEMM_PK");
-  return e && atoi(e) == 1;
-}
-constexpr int PK_MIN_TILES = 256;  // at least one tile per CU
 
-extern "C" int vds_gemm_stream_k(int32_t mode) {
-  const int prev = g_sk_mode;
-  if (mode < -1 || mode > 1) return VDS_ERR_ARG;
-  g_sk_mode = mode;
-  return prev;
-}
-extern "C" int vds_gemm_stream_k_status(void) { return big::sk_status_and_clear(); }
+}  // namespace
 
 extern "C" int vds_gemm_force_tile(int32_t tile) {
-  const int prev = g_force_tile < 0 ? 0 : g_force_tile;
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 2 && tile != 192) return VDS_ERR_ARG;
-  g_force_tile = tile;
+  const int prev = force_tile();
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 2) return VDS_ERR_ARG;
+  vdscfg::g_val[vdscfg::GEMM_TILE] = tile;
   return prev;
 }
 
@@ -2094,9 +1479,10 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   p.gate = a->gate; p.ldgate = a->ldgate;
   p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
   p.row_base = 0;
+  p.slab_stride = 0;
   // split_k: > 1 that many K splits (atomic accumulation into a pre-zeroed C); 1 none; <= -2: |split_k| splits and
   // atomic accumulation; 0 / -1 (TN + F32 only): the library picks tiling and split count itself (-1: and always
-  // accumulates atomically, so that several calls can sum into one C)
+  // accumulates, so that several calls can sum into one C)
   const bool auto_split = (a->split_k == 0 || a->split_k == -1) && a->layout == VDS_TN && a->epilogue == VDS_EPI_F32;
   p.split_k = a->split_k > 1 ? a->split_k : (a->split_k < -1 ? -a->split_k : 1);
   p.atomic = (a->split_k > 1 || a->split_k < 0) ? 1 : 0;
@@ -2134,79 +1520,51 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (p.atomic && !(a->layout == VDS_TN && a->epilogue == VDS_EPI_F32)) return VDS_ERR_ARG;
   if (!a->C && a->epilogue != VDS_EPI_GATE_RES) return VDS_ERR_ARG;
+  const bool det = vdscfg::geti(vdscfg::DETERMINISTIC) != 0;
+  // deterministic mode: the fc1 bias gradient is a separate fixed-order column sum, not the epilogue's per-tile atomics
+  const float* fused_colsum = det ? nullptr : a->colsum;
   // tile choice: 256^2 (one workgroup per CU, deep LDS-DMA pipeline) for problems that fill the chip
-  // with such tiles; 128^2 otherwise.  VDS_GEMM_TILE=128|256 forces one (experiments).
-  if (g_force_tile < 0) {
-    const char* e = getenv("VDS_GEMM_TILE");
-    g_force_tile = e ? atoi(e) : 0;
-  }
-  const int force_tile = g_force_tile;
+  // with such tiles; 128^2 otherwise.  vds_gemm_force_tile / VDS_GEMM_TILE = 128 | 256 | 2 forces one (experiments).
+  const int ft = force_tile();
   // model: a 256^2 workgroup (alone on its CU) sustains ~1.24x the rate of two co-resident 128^2
   // workgroups; compare the number of rounds each tiling needs (wave quantisation dominates at
-  // these sizes).  Weight gradients (TN, split-K + atomics) stay on the 128^2 kernel.
+  // these sizes).  Weight gradients (TN, split-K) run on the 256 x 128 or the 128^2 kernel.
   const int tm = cdiv(a->M, 256), tn = cdiv(a->N, 256);
   const long rounds_big = ((long)tm * tn + 255) / 256;
   const long rounds_small = ((long)p.tiles_m * p.tiles_n + 511) / 512;
-  // stream-K (round 5): the 256^2 launch costs its work (+ one hand-off) instead of whole rounds
-  // With no explicit choice (neither vds_gemm_stream_k nor VDS_GEMM_SK): stream-K for the one case it measured faster in --
-  // long contractions (K >= 4608) of launches between one and two rounds of tiles (C3b at B = 2: fc2 forward 0.206 -> 0.187 ms,
-  // fc1 input gradient 0.184 -> 0.179 ms; profiles/r05/negative_gemm_stream_k_b2.log): the seam's slab round trip is paid
-  // once per 72 K tiles instead of once per 18.
-  static int sk_lo = -1, sk_hi = 512, sk_k = 4608;
-  if (sk_lo < 0) {
-    const char* e;
-    sk_lo = (e = getenv("VDS_SK_AUTO_LO")) ? atoi(e) : 256;
-    if ((e = getenv("VDS_SK_AUTO_HI"))) sk_hi = atoi(e);
-    if ((e = getenv("VDS_SK_AUTO_K"))) sk_k = atoi(e);
-  }
-  const bool sk_auto = g_sk_mode < 0 && !getenv("VDS_GEMM_SK") && a->K >= sk_k && (long)tm * tn > sk_lo && (long)tm * tn < sk_hi;
-  const bool sk_ok = (sk_enabled() || sk_auto) && a->layout != VDS_TN && (force_tile == 0 || force_tile == 256) && p.split_k == 1 &&
-                     (long)tm * tn >= SK_MIN_TILES;
-  const double rounds_big_eff = sk_ok ? (double)tm * tn / 256.0 + 0.3 : (double)rounds_big;
-  bool use_big = a->layout != VDS_TN && a->K >= 256 && rounds_big_eff * (2.0 / 1.24) < (double)rounds_small;
-  if (force_tile == 128) use_big = false;
-  if (force_tile == 256 || force_tile == 192) use_big = true;
-  static int group_m = -1;
-  if (group_m < 0) {
-    const char* e = getenv("VDS_GEMM_GROUP_M");
-    group_m = e ? atoi(e) : 4;  // groups of 4 row tiles (1024 rows) measured best at the DiT shapes
-  }
-  p.group_m = group_m;
+  bool use_big = a->layout != VDS_TN && a->K >= 256 && (double)rounds_big * (2.0 / 1.24) < (double)rounds_small;
+  if (ft == 128) use_big = false;
+  if (ft == 256 && a->layout != VDS_TN) use_big = true;
+  p.group_m = vdscfg::geti(vdscfg::GEMM_GROUP_M);  // groups of 4 row tiles (1024 rows) measured best at the DiT shapes
+  if (p.group_m < 1) p.group_m = 4;
   p.joint_xcd = 0;
+  const int group_m_tn = vdscfg::geti(vdscfg::GEMM_GROUP_M_TN) > 0 ? vdscfg::geti(vdscfg::GEMM_GROUP_M_TN) : 0;
   if (a->layout == VDS_TN) {
     // weight gradients: few output tiles, every tile of a split streams the same token range.  Fixed groups of 2 row
     // tiles measured 4-5 % faster than 4 at the DiT-XL shapes (106.4 -> 101.5 ms per step); 0 (default) = sized at the
-    // launch so that one XCD's chunk of the joint (split, tile) list is one group (tn_group below): 97 ms
-    static int group_m_tn = -1;
-    if (group_m_tn < 0) {
-      const char* e = getenv("VDS_GEMM_GROUP_M_TN");
-      group_m_tn = e ? atoi(e) : 0;
-      if (group_m_tn < 0) group_m_tn = 0;
-    }
+    // launch so that one XCD's chunk of the joint (split, tile) list is one group (below): 97 ms
     p.group_m = group_m_tn ? group_m_tn : 2;
-    static int joint = -1;
-    if (joint < 0) {
-      const char* e = getenv("VDS_GEMM_TN_JOINT");
-      joint = e ? atoi(e) : 1;
-    }
-    p.joint_xcd = joint;
+    p.joint_xcd = vdscfg::geti(vdscfg::GEMM_TN_JOINT);
   }
+  // the split-K launch of a weight gradient: atomics (default) or slabs + fixed-order reduction (deterministic mode)
+  auto launch_tn = [&](auto fn) -> int {
+    if (det && p.split_k > 1) return launch_split_det(p, (float*)a->C, a->ldc, s, fn);
+    return fn(p);
+  };
   if (auto_split) {
     // weight gradient dW[M = out features, N = in features] = dy^T x over K = tokens: few output tiles, long K.
-    // Candidates: 128^2 tiles (two workgroups per CU) and 256 x 128 tiles (two per CU, ~g_mid_tn x the per-CU rate:
+    // Candidates: 128^2 tiles (two workgroups per CU) and 256 x 128 tiles (two per CU, ~mid_tn x the per-CU rate:
     // half the transposing LDS reads per MFMA).  Cost of (tiling, s splits) in units of one 128^2 tile x 64-token
     // step: rounds of 512 co-resident workgroups x K steps per split x tile size, plus the fp32-atomic traffic of
     // the partial tiles (64 KB per 128^2 tile at the chip-wide ~1.3 TB/s, ~0.034 units each).
-    static double mid_tn = -1.0;
-    if (mid_tn < 0) {
-      const char* e = getenv("VDS_GEMM_MID_TN");
-      mid_tn = e ? atof(e) : 0.75;  // relative time per unit of work of the 256 x 128 kernel on TN problems
-    }
+    // (Round 5 measured the 256^2 tiling as a third candidate: 1395 TFLOP/s at 8192^3, -4..-5 % on the fc1 / fc2 weight
+    // gradients in a loop of launches, nothing inside the step -- removed in round 6, profiles/r05/gemm_tn_on_256_tiling.log.)
+    const double mid_tn = vdscfg::get(vdscfg::GEMM_MID_TN);
     const long kt = cdiv(a->K, 64);
     double best = 1e300;
     int best_tile = 128, best_s = 1;
     for (int cand = 0; cand < 2; ++cand) {
-      if ((cand == 0 && force_tile == 2) || (cand == 1 && (force_tile == 128 || force_tile == 256))) continue;
+      if ((cand == 0 && ft == 2) || (cand == 1 && ft == 128)) continue;
       const long tiles = cand == 0 ? (long)cdiv(a->M, 128) * cdiv(a->N, 128) : (long)cdiv(a->M, 256) * cdiv(a->N, 128);
       const double unit = cand == 0 ? 1.0 : 2.0 * mid_tn, atom = cand == 0 ? 0.034 : 0.068;
       for (int sp = 1; sp <= 32; ++sp) {
@@ -2216,148 +1574,69 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
         if (cost < best - 1e-9) { best = cost; best_tile = cand == 0 ? 128 : 2; best_s = sp; }
       }
     }
-    // round 5: the 256^2 tiling as a third candidate (one workgroup per CU).  Its TN main loop is as good as its NT / NN
-    // ones (1395 TFLOP/s at 8192^3 against 1300 for the 256 x 128 tiling); what made it lose on weight gradients was the
-    // split it was given.  Priced from its measured launches (tools/bench_gemm_tn_square.py): a 64-token step of a tile
-    // costs 1.29 units, a workgroup 8 units of prologue + fp32-atomic epilogue; it has to win by 3 % (the two models
-    // above run 0-14 % pessimistic).  At the DiT-XL shapes it takes the fc1 / fc2 weight gradients (18 x 5 / 5 x 18
-    // tiles x 8 splits: 0.907 -> 0.871 and 0.956 -> 0.909 ms at B = 12 in a loop of launches) and leaves qkv and the
-    // 1152^2 ones alone.  Inside the train step the gain is not there (gemm_tn 1096 -> 1084 TFLOP/s, step 818.5 / 819.2
-    // -> 818.2 / 820.1 ms, same box): OFF by default, VDS_GEMM_BIG_TN=1 enables it; VDS_GEMM_TILE=256 uses its split.
-    static int big_tn = -1;
-    if (big_tn < 0) {
-      const char* e = getenv("VDS_GEMM_BIG_TN");
-      big_tn = e ? atoi(e) : 0;
-    }
-    bool tn_big = false;
-    if ((big_tn || force_tile == 256) && (force_tile == 0 || force_tile == 256) && a->K >= 256) {
-      const long tiles = (long)tm * tn;
-      double bb = 1e300;
-      int bs = 1;
-      for (int sp = 1; sp <= 32; ++sp) {
-        if (sp > 1 && kt / sp < 8) break;
-        const long rounds = (tiles * sp + 255) / 256;
-        const double cost = (double)rounds * ((double)((kt + sp - 1) / sp) * 1.29 + 8.0);
-        if (cost < bb - 1e-9) { bb = cost; bs = sp; }
-      }
-      if (force_tile == 256 || bb < 0.97 * best) { tn_big = true; best_s = bs; }
-    }
     p.split_k = best_s;
     p.atomic = (best_s > 1 || a->split_k == -1) ? 1 : 0;
-    if (tn_big) use_big = true;
-    else if (force_tile != 256) {
-      if (best_tile == 2) {
-        p.tiles_m = cdiv(a->M, 256);
-        p.tiles_n = cdiv(a->N, 128);
-        if (p.joint_xcd && !getenv("VDS_GEMM_GROUP_M_TN")) {
-          // one XCD's chunk = (tiles x splits) / 8 consecutive entries of the split-major list: make it a block of
-          // whole tile rows of one split (qkv weight gradient: 14 x 9 tiles x 4 splits -> 7 rows x 9 columns per XCD)
-          const long chunk = ((long)p.tiles_m * p.tiles_n * p.split_k + 7) / 8;
-          long g = (chunk + p.tiles_n / 2) / p.tiles_n;
-          p.group_m = (int)(g < 1 ? 1 : (g > p.tiles_m ? p.tiles_m : g));
-        }
-        return mid::launch<VDS_TN, VDS_EPI_F32>(p, s);
+    if (best_tile == 2) {
+      p.tiles_m = cdiv(a->M, 256);
+      p.tiles_n = cdiv(a->N, 128);
+      if (p.joint_xcd && !group_m_tn) {
+        // one XCD's chunk = (tiles x splits) / 8 consecutive entries of the split-major list: make it a block of
+        // whole tile rows of one split (qkv weight gradient: 14 x 9 tiles x 4 splits -> 7 rows x 9 columns per XCD)
+        const long chunk = ((long)p.tiles_m * p.tiles_n * p.split_k + 7) / 8;
+        long g = (chunk + p.tiles_n / 2) / p.tiles_n;
+        p.group_m = (int)(g < 1 ? 1 : (g > p.tiles_m ? p.tiles_m : g));
       }
-      return launch<VDS_TN, VDS_EPI_F32>(p, s);
+      return launch_tn([&](GemmP& q) { return mid::launch<VDS_TN, VDS_EPI_F32>(q, s); });
     }
+    return launch_tn([&](GemmP& q) { return launch<VDS_TN, VDS_EPI_F32>(q, s); });
   }
   // 256 x 128 tiles, two workgroups per CU: no padded half tile when N is a multiple of 128 but not of 256, and the
   // epilogue of one workgroup runs under the main loop of the other.  Measured (tools/bench_gemm_tiles.py, DiT-XL
   // shapes, B = 12): its LDS-DMA issue rate (1.5x the bytes per FLOP of a 256^2 tile, from half as many waves) caps
   // it at ~0.8x the 256^2 kernel on NT / NN problems, so a round of 512 such tiles is priced at 1.3 rounds of 256^2
   // tiles and it only wins where tile quantisation is severe; on weight gradients (TN) it beats the 128^2 kernel
-  // by 7-24 % (see auto_split above).  VDS_GEMM_TILE=2 forces it.
+  // by 7-24 % (see auto_split above).  tile = 2 forces it.
   {
     const int tmm = cdiv(a->M, 256), tnm = cdiv(a->N, 128);
-    const double rounds_mid = (double)((long)tmm * tnm + 511) / 512;  // not rounded up: the tail round is half-price per tile
-    static double mid_factor = -1.0;
-    if (mid_factor < 0) {
-      const char* e = getenv("VDS_GEMM_MID_FACTOR");
-      mid_factor = e ? atof(e) : 1.3;
-    }
-    const double cost_mid = (double)(((long)tmm * tnm + 511) / 512) * mid_factor;
-    const double cost_big = rounds_big_eff, cost_small = (double)rounds_small * (1.24 / 2.0);
+    const double cost_mid = (double)(((long)tmm * tnm + 511) / 512) * vdscfg::get(vdscfg::GEMM_MID_FACTOR);
+    const double cost_big = (double)rounds_big, cost_small = (double)rounds_small * (1.24 / 2.0);
     bool use_mid = a->K >= 128 && cost_mid < (use_big ? cost_big : cost_small) && a->layout != VDS_TN;
-    (void)rounds_mid;
-    if (force_tile == 2) use_mid = true;
+    if (ft == 2) use_mid = true;
     if (a->colsum && a->layout != VDS_NN) use_mid = false;
-    if (force_tile == 128 || force_tile == 256 || force_tile == 192) use_mid = false;
-    if (use_mid && a->colsum) {  // no fused column sums in this tiling either
-      p.tiles_m = tmm;
-      p.tiles_n = tnm;
-      const int rc = mid::launch<VDS_NN, VDS_EPI_DGELU>(p, s);
-      return rc != VDS_OK ? rc : vds_colsum_bf16(a->C, a->ldc, a->colsum, a->M, a->N, stream);
-    }
+    if (ft == 128 || ft == 256) use_mid = false;
     if (use_mid) {
       p.tiles_m = tmm;
       p.tiles_n = tnm;
+      if (a->colsum) {  // no fused column sums in this tiling: a pass over the result follows the GEMM
+        const int rc = mid::launch<VDS_NN, VDS_EPI_DGELU>(p, s);
+        return rc != VDS_OK ? rc : vds_colsum_bf16(a->C, a->ldc, a->colsum, a->M, a->N, stream);
+      }
 #define GOM(L, E) if (a->layout == L && a->epilogue == E) return mid::launch<L, E>(p, s);
       GOM(VDS_NT, VDS_EPI_STORE)
       GOM(VDS_NT, VDS_EPI_BIAS_GELU)
       GOM(VDS_NT, VDS_EPI_GATE_RES)
       GOM(VDS_NN, VDS_EPI_STORE)
       GOM(VDS_NN, VDS_EPI_DGELU)
-      GOM(VDS_TN, VDS_EPI_F32)
 #undef GOM
-    }
-  }
-  if (use_big && a->layout != VDS_TN && (force_tile == 192 || (force_tile == 0 && prefer_w192(a->M, a->N)))) {
-    p.tiles_m = tm;
-    p.tiles_n = cdiv(a->N, 192);
-    p.e_colsum = a->colsum;
-#define GOW(L, E) if (a->layout == L && a->epilogue == E) return big::launch<L, E, 0, 192>(p, s);
-    GOW(VDS_NT, VDS_EPI_STORE)
-    GOW(VDS_NT, VDS_EPI_BIAS_GELU)
-    GOW(VDS_NT, VDS_EPI_GATE_RES)
-    GOW(VDS_NN, VDS_EPI_STORE)
-    GOW(VDS_NN, VDS_EPI_DGELU)
-#undef GOW
-  }
-  if (use_big && a->epilogue == VDS_EPI_STORE && a->layout != VDS_TN) {
-    const char* e = getenv("VDS_GEMM_PHASES");  // A/B knob, read per call: 4 = the four-phase K tile of rounds 1-3
-    if (e && atoi(e) == 4) {
-      p.tiles_m = tm;
-      p.tiles_n = tn;
-      return a->layout == VDS_NT ? big::launch<VDS_NT, VDS_EPI_STORE, 0, 256, 4>(p, s)
-                                 : big::launch<VDS_NN, VDS_EPI_STORE, 0, 256, 4>(p, s);
+      if (a->layout == VDS_TN && a->epilogue == VDS_EPI_F32)
+        return launch_tn([&](GemmP& q) { return mid::launch<VDS_TN, VDS_EPI_F32>(q, s); });
     }
   }
   if (use_big) {
     p.tiles_m = tm;
     p.tiles_n = tn;
     p.narrow = narrow_last_column(a->N);
-    p.e_colsum = a->colsum;  // DGELU only (checked above): column sums of the result in the epilogue
-    if (sk_ok) {
-      int rc = 1;
-#define GOSK(L, E) if (a->layout == L && a->epilogue == E) rc = big::launch_sk<L, E>(p, s);
-      GOSK(VDS_NT, VDS_EPI_STORE)
-      GOSK(VDS_NT, VDS_EPI_BIAS_GELU)
-      GOSK(VDS_NT, VDS_EPI_GATE_RES)
-      GOSK(VDS_NN, VDS_EPI_STORE)
-      // (not the GELU' epilogue: with its table, column sums and pre-activation tile the persistent form spills ~100 VGPRs)
-#undef GOSK
-      if (rc != 1) return rc;
-    }
-    if (pk_enabled() && a->layout != VDS_TN && (force_tile == 0 || force_tile == 256) && p.split_k == 1 &&
-        (long)tm * tn >= PK_MIN_TILES) {
-      int rc = 1;
-#define GOPK(L, E) if (a->layout == L && a->epilogue == E) rc = big::launch_pk<L, E>(p, s);
-      GOPK(VDS_NT, VDS_EPI_STORE)
-      GOPK(VDS_NT, VDS_EPI_BIAS_GELU)
-      GOPK(VDS_NT, VDS_EPI_GATE_RES)
-      GOPK(VDS_NN, VDS_EPI_STORE)
-      GOPK(VDS_NN, VDS_EPI_DGELU)
-#undef GOPK
-      if (rc != 1) return rc;
-    }
-#define GOB(L, E) if (a->layout == L && a->epilogue == E) return big::launch<L, E>(p, s);
+    p.e_colsum = const_cast<float*>(fused_colsum);  // DGELU only (checked above): column sums of the result in the epilogue
+    int rc = VDS_ERR_UNSUPPORTED;
+#define GOB(L, E) if (a->layout == L && a->epilogue == E) rc = big::launch<L, E>(p, s);
     GOB(VDS_NT, VDS_EPI_STORE)
     GOB(VDS_NT, VDS_EPI_BIAS_GELU)
     GOB(VDS_NT, VDS_EPI_GATE_RES)
     GOB(VDS_NN, VDS_EPI_STORE)
     GOB(VDS_NN, VDS_EPI_DGELU)
-    GOB(VDS_TN, VDS_EPI_F32)
 #undef GOB
+    if (rc == VDS_OK && a->colsum && !fused_colsum) return vds_colsum_bf16(a->C, a->ldc, a->colsum, a->M, a->N, stream);
+    return rc;
   }
   p.tiles_m = cdiv(a->M, BM);
   p.tiles_n = cdiv(a->N, BN);
@@ -2371,8 +1650,9 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   GO(VDS_NT, VDS_EPI_GATE_RES)
   GO(VDS_NN, VDS_EPI_STORE)
   GO(VDS_NN, VDS_EPI_DGELU)
-  GO(VDS_TN, VDS_EPI_F32)
 #undef GO
+  if (a->layout == VDS_TN && a->epilogue == VDS_EPI_F32)
+    return launch_tn([&](GemmP& q) { return launch<VDS_TN, VDS_EPI_F32>(q, s); });
   return VDS_ERR_UNSUPPORTED;
 }
 
@@ -2395,6 +1675,7 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   p.gate = a->gate; p.ldgate = a->ldgate;
   p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
   p.row_base = 0;
+  p.slab_stride = 0;
   p.split_k = a->split_k > 1 ? a->split_k : (a->split_k < -1 ? -a->split_k : 1);
   p.atomic = (a->split_k > 1 || a->split_k < 0) ? 1 : 0;
   p.sa = scale_a; p.sb = scale_b;
@@ -2423,44 +1704,12 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   if (p.atomic && a->epilogue != VDS_EPI_F32) return VDS_ERR_ARG;
   if (!a->C && a->epilogue != VDS_EPI_GATE_RES && !(emit && a->epilogue == VDS_EPI_DGELU)) return VDS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (g_force_tile < 0) {
-    const char* e = getenv("VDS_GEMM_TILE");
-    g_force_tile = e ? atoi(e) : 0;
+  if (tn) {
+    if (vdscfg::geti(vdscfg::DETERMINISTIC) && p.split_k > 1)
+      return launch_split_det(p, (float*)a->C, a->ldc, s, [&](GemmP& q) { return big::launch<VDS_TN, VDS_EPI_F32, 3>(q, s); });
+    return big::launch<VDS_TN, VDS_EPI_F32, 3>(p, s);
   }
-  if (tn) return big::launch<VDS_TN, VDS_EPI_F32, 3>(p, s);
-  // 256 x 192 tiles where they save rounds (N = 1152 / 3456: see prefer_w192); not for the split-K weight gradients
-  if (p.split_k == 1 && (g_force_tile == 192 || (g_force_tile == 0 && prefer_w192(a->M, a->N)))) {
-    p.tiles_n = cdiv(a->N, 192);
-#define GOFW(E, F) if (a->epilogue == E && a_fmt == F - 1) return big::launch<VDS_NT, E, F, 192>(p, s);
-    GOFW(VDS_EPI_STORE, 1)
-    GOFW(VDS_EPI_BIAS_GELU, 1)
-    GOFW(VDS_EPI_GATE_RES, 1)
-    GOFW(VDS_EPI_STORE, 2)
-    GOFW(VDS_EPI_DGELU, 2)
-#undef GOFW
-    p.tiles_n = cdiv(a->N, 256);
-  }
-  if (sk_enabled() && p.split_k == 1 && (g_force_tile == 0 || g_force_tile == 256) && (long)p.tiles_m * p.tiles_n >= SK_MIN_TILES) {
-    int rc = 1;
-#define GOFS(E, F) if (a->epilogue == E && a_fmt == F - 1) rc = big::launch_sk<VDS_NT, E, F>(p, s);
-    GOFS(VDS_EPI_STORE, 1)
-    GOFS(VDS_EPI_BIAS_GELU, 1)
-    GOFS(VDS_EPI_GATE_RES, 1)
-    GOFS(VDS_EPI_STORE, 2)
-#undef GOFS
-    if (rc != 1) return rc;
-  }
-  if (pk_enabled() && p.split_k == 1 && (g_force_tile == 0 || g_force_tile == 256) && (long)p.tiles_m * p.tiles_n >= PK_MIN_TILES) {
-    int rc = 1;
-#define GOFP(E, F) if (a->epilogue == E && a_fmt == F - 1) rc = big::launch_pk<VDS_NT, E, F>(p, s);
-    GOFP(VDS_EPI_STORE, 1)
-    GOFP(VDS_EPI_BIAS_GELU, 1)
-    GOFP(VDS_EPI_GATE_RES, 1)
-    GOFP(VDS_EPI_STORE, 2)
-    GOFP(VDS_EPI_DGELU, 2)
-#undef GOFP
-    if (rc != 1) return rc;
-  }
+  if (vdscfg::geti(vdscfg::DETERMINISTIC) && p.e_colsum) return VDS_ERR_UNSUPPORTED;  // (fused column sums are atomic)
 #define GOF(E, F) if (a->epilogue == E && a_fmt == F - 1) return big::launch<VDS_NT, E, F>(p, s);
   GOF(VDS_EPI_STORE, 1)
   GOF(VDS_EPI_BIAS_GELU, 1)

@@ -39,59 +39,10 @@ _NO_EMIT = os.environ.get("VDS_FP8_NO_EMIT") == "1"  # experiments: quantise eve
 _NO_PRODUCER_EMIT = os.environ.get("VDS_FP8_PRODUCER_EMIT") == "0"  # experiments: only the GEMM epilogues emit fp8
 _NO_ATTN_EMIT = os.environ.get("VDS_FP8_ATTN_EMIT") == "0"  # experiments: attention results quantised in a separate pass
 _CROSS_ONES = os.environ.get("VDS_CROSS_ONES", "1") != "0"  # head_dim 72: cross-attention forward / dQ on the ones-column kernels
-_WGRAD_STREAM = os.environ.get("VDS_WGRAD_STREAM", "0") == "1"  # weight-gradient GEMMs of the blocks on a second stream
 # residual-V: d v_0 = sum over the mixed blocks of (1 - lambda_i) dv_i, summed in ONE pass before block 0's RoPE backward
 # (ops.dv0_reduce) instead of an fp32 read-modify-write of the accumulator in every block (0: the per-block form)
 _DV0_DEFER = os.environ.get("VDS_DV0_DEFER", "1") != "0"
 
-
-class _WgradLane:
-    """The weight-gradient GEMMs of the DiT blocks on a second HIP stream (round 5).
-
-    dW = dy^T x depends on nothing but dy and a saved activation and nothing in the backward pass depends on it: issued on
-    a side stream it runs beside the input-gradient chain -- under the HBM-bound kernels between the GEMMs (gate / RMSNorm /
-    RoPE backward), which leave the matrix cores idle, and in the partly filled last round of the MFMA kernels.  The side
-    stream waits for an event behind the producer of dy; the operands are kept alive here until the main stream has waited
-    for the GEMMs that read them (the caching allocator would otherwise hand their memory to the next main-stream
-    kernel); the main stream joins `lag` blocks later (0: at the end of every block -- the sharded runtime reduces a
-    block's gradients right behind its backward) and at the end of the pass.
-
-    MEASURED (MI355X, C3b B=12, same box, interleaved): 846.6-851.8 ms per step against 819.3-822.1 ms in stream order,
-    also with the pass on a high-priority stream (ROCm offers two levels).  Two MFMA kernels sharing the chip lose more
-    than the overlap with the HBM-bound kernels and the filled last rounds give back: a CU holding one 74-KiB workgroup
-    of the weight-gradient tiling cannot take a 139-KiB workgroup of the 256^2 tiling and runs half empty.  Off by
-    default (VDS_WGRAD_STREAM=1); kept as a tested experiment switch (profiles/r05/wgrad_side_stream_ab.log)."""
-    _streams = {}
-
-    def __init__(self, dev, lag: int):
-        self.main = torch.cuda.current_stream(dev)
-        key = (dev.index if dev.index is not None else torch.cuda.current_device())
-        if key not in _WgradLane._streams:
-            _WgradLane._streams[key] = torch.cuda.Stream(device=dev)
-        self.side = _WgradLane._streams[key]
-        self.lag = lag
-        self.refs, self.pending = [], []
-
-    def run(self, fn, *args):
-        ev = torch.cuda.Event()
-        ev.record(self.main)
-        self.side.wait_event(ev)
-        with torch.cuda.stream(self.side):
-            fn(*args)
-        self.refs.append(args)
-
-    def end_block(self, lag=None):
-        if self.refs:
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-            self.pending.append((ev, self.refs))
-            self.refs = []
-        while len(self.pending) > (self.lag if lag is None else lag):
-            ev, _ = self.pending.pop(0)
-            self.main.wait_event(ev)
-
-    def join(self):
-        self.end_block(0)
 
 bf16, f32 = torch.bfloat16, torch.float32
 N_REG = 16  # register tokens (model.py:316,362,386)
@@ -579,9 +530,9 @@ class DiTBlock(nn.Module):
         dev = dX.device
         mod = bs.mod
         batched_adaln = dmod is not None  # DiT.backward: the adaLN weight gradients of all blocks in one launch at the end
-        lane = getattr(sv, "wgrad_lane", None)
-        wgrad = ops.linear_wgrad if lane is None else (lambda *a: lane.run(ops.linear_wgrad, *a))
-        wgrad8 = F8.wgrad if lane is None else (lambda *a: lane.run(F8.wgrad, *a))
+        # (round 5 measured the weight-gradient GEMMs on a second stream: +3.3 % slower -- two MFMA kernels with different LDS
+        # footprints fragment the CUs; removed in round 6, profiles/r05/wgrad_side_stream_ab.log)
+        wgrad, wgrad8 = ops.linear_wgrad, F8.wgrad
         if dmod is None:
             dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
         # --- MLP
@@ -747,8 +698,6 @@ class DiTBlock(nn.Module):
         if not batched_adaln:
             ops.small_linear_bwd(dmod, sv.cvec, W("adaLN_modulation.1.weight"), Gr("adaLN_modulation.1.weight"),
                                  Gr("adaLN_modulation.1.bias"), dc, 1)
-        if lane is not None:
-            lane.end_block()
         return dX0
 
 
@@ -1056,7 +1005,6 @@ class DiT(nn.Module):
                              R.g("final_modulation.1.bias"), dc, 1)
         hdp = HDP_OF[hd]
         dv0 = torch.zeros(B, H, L, hdp, dtype=f32, device=dev) if (self.residual_v and self.depth > 1) else None
-        sv.wgrad_lane = _WgradLane(dev, 0 if fs is not None else 1) if _WGRAD_STREAM else None
         sv.dv_terms = [] if (_DV0_DEFER and dv0 is not None) else None
         for i in reversed(range(self.depth)):
             if fs is not None:
@@ -1067,9 +1015,6 @@ class DiT(nn.Module):
             sv.blocks[i] = None
             if fs is not None:
                 fs.post_backward_block(i)
-        if sv.wgrad_lane is not None:
-            sv.wgrad_lane.join()
-            sv.wgrad_lane = None
         if dmods is not None:  # adaLN weight / bias gradients of all blocks and their fan-in to dc: one launch each
             wt, _, gwt, gbt = self._adaln_tables()
             ops.small_linear_bwd_batched(dmods, sv.cvec, wt, gwt, gbt, dc, 1)

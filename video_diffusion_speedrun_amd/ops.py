@@ -61,17 +61,39 @@ def gemm_force_tile(tile: int) -> int:
     return prev
 
 
-def gemm_stream_k(mode: int) -> int:
-    """stream-K launches of the 256^2 GEMM kernel: 1 on, 0 off, -1 = VDS_GEMM_SK (default on); returns the previous mode"""
-    prev = _lib.load().vds_gemm_stream_k(int(mode))
-    if prev < -1:
-        raise ValueError(f"vds_gemm_stream_k({mode})")
+def knob_set(name: str, value: float) -> float:
+    """set one entry of the library's knob table (csrc/config.h); returns the previous value"""
+    lib = _lib.load()
+    prev = lib.vds_knob_get(name.encode())
+    check(lib.vds_knob_set(name.encode(), float(value)), f"vds_knob_set({name})")
     return prev
 
 
-def gemm_stream_k_status() -> int:
-    """1 when a stream-K hand-off timed out on the current device since the last call (synchronises), else 0"""
-    return _lib.load().vds_gemm_stream_k_status()
+def knob_get(name: str) -> float:
+    v = _lib.load().vds_knob_get(name.encode())
+    if v != v:
+        raise KeyError(name)
+    return v
+
+
+_det_ws = [None]
+
+
+def set_deterministic(on: bool, workspace_bytes: int = 1 << 30, device="cuda") -> bool:
+    """fixed-order reductions in every backward kernel (include/vds.h: vds_set_deterministic); the workspace for the
+    partial results is a torch allocation this module keeps alive while the mode is on.  Returns the previous mode."""
+    lib = _lib.load()
+    if on:
+        ws = torch.empty(int(workspace_bytes), dtype=torch.uint8, device=device)
+        prev = lib.vds_set_deterministic(1, ws.data_ptr(), ws.numel())
+        _det_ws[0] = ws
+    else:
+        torch.cuda.synchronize()
+        prev = lib.vds_set_deterministic(0, None, 0)
+        _det_ws[0] = None
+    if prev < 0:
+        raise ValueError("vds_set_deterministic")
+    return bool(prev)
 
 
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
