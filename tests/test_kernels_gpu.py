@@ -936,3 +936,81 @@ def test_dv0_reduce_equals_the_per_block_accumulation(ops, hd, hdp, n):
     ops.dv0_reduce([b[2] for b in blocks[:1]], [b[4] for b in blocks[:1]], out, B, H, L, hd, hdp, accumulate=True)
     want = acc[..., :hd] + (1.0 - blocks[0][4].float()) * blocks[0][2][..., :hd].float()
     close("dv0.accumulate", out[..., :hd], want, 1e-6)
+
+
+# ------------------------------------------------------------------ deterministic mode ----
+@pytest.fixture
+def deterministic(ops):
+    """vds_set_deterministic(1) with a 256-MiB workspace for the duration of one test"""
+    ops.set_deterministic(True, 256 << 20)
+    yield
+    ops.set_deterministic(False)
+
+
+@pytest.mark.parametrize("tile_", [0, 128, 2], ids=["auto", "t128", "t256x128"])
+@pytest.mark.parametrize("M,N,K,split", [(1152, 1152, 8208, 0), (384, 128, 4112, 5), (1152, 4608, 16416, -1), (264, 72, 1000, 3)])
+def test_gemm_tn_fixed_order_split_k(ops, deterministic, M, N, K, split, tile_):
+    """deterministic mode: a split-K weight gradient writes one fp32 slab per split and a second pass adds the slabs to C in
+    split order.  On small integers every sum is exact: C must be the exact product plus what was there; on random
+    operands two launches must give identical bits and agree with the default (atomic) mode to fp32 rounding."""
+    from video_diffusion_speedrun_amd._lib import EPI_F32, VDS_TN
+    dy, x = _ints((K, M), 301), _ints((K, N), 302)
+    c0 = _ints((M, N), 303, -5, 5, f32)
+    ops.gemm_force_tile(tile_)
+    try:
+        C = c0.clone().cuda()
+        ops.gemm(VDS_TN, EPI_F32, M, N, K, dy.cuda(), M, x.cuda(), N, C, N, split_k=split if split else -1)
+        torch.cuda.synchronize()
+        assert torch.equal(C.cpu(), c0 + dy.float().t() @ x.float())
+        dyr, xr = gen(K, M, seed=304), gen(K, N, seed=305)
+        outs = []
+        for _ in range(2):
+            C = c0.clone().cuda()
+            ops.gemm(VDS_TN, EPI_F32, M, N, K, dyr.cuda(), M, xr.cuda(), N, C, N, split_k=split if split else -1)
+            outs.append(C)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1])
+        ops.set_deterministic(False)
+        Ca = c0.clone().cuda()
+        ops.gemm(VDS_TN, EPI_F32, M, N, K, dyr.cuda(), M, xr.cuda(), N, Ca, N, split_k=split if split else -1)
+        ops.set_deterministic(True, 256 << 20)
+        close("det.tn_vs_atomic", outs[0], Ca, 1e-5)
+    finally:
+        ops.gemm_force_tile(0)
+
+
+def test_row_kernels_fixed_order_column_sums(ops, deterministic):
+    """deterministic mode: the column sums of rmsnorm_mod_bwd (d shift, d scale, d weight), gate_bwd (d gate, d bias),
+    colsum and the lambda gradient of the RoPE backward are per-workgroup partials + one fixed-order pass: two runs give
+    identical bits, and the values agree with the default (atomic) mode."""
+    B, L, D = 3, 1100, 1152
+    dy, x, w = gen(B * L, D, seed=311), gen(B * L, D, seed=312), gen(D, seed=313)
+    mod = gen(B, 9 * D, seed=314, dtype=f32)
+    dres, y = gen(B * L, D, seed=315), gen(B * L, D, seed=316)
+
+    def run():
+        out = {}
+        _, rstd = ops.rmsnorm_mod_fwd(x.cuda(), w.cuda(), mod.cuda(), 0, D, B, L)
+        dmod = torch.zeros(B, 9 * D, dtype=f32, device="cuda")
+        dw = torch.zeros(D, dtype=f32, device="cuda")
+        out["dx"] = ops.rmsnorm_mod_bwd(dy.cuda(), x.cuda(), w.cuda(), mod.cuda(), 0, D, rstd, dres.cuda(), dmod, dw, B, L)
+        db = torch.zeros(D, dtype=f32, device="cuda")
+        out["dyg"] = ops.gate_bwd(dy.cuda(), y.cuda(), mod.cuda(), 2 * D, dmod, db, B, L)
+        cs = torch.zeros(D, dtype=f32, device="cuda")
+        ops.colsum(dy.cuda(), cs)
+        out.update(dmod=dmod, dw=dw, db=db, cs=cs)
+        torch.cuda.synchronize()
+        return out
+
+    a, b = run(), run()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    ops.set_deterministic(False)
+    c = run()
+    ops.set_deterministic(True, 256 << 20)
+    for k in a:
+        if a[k].dtype == f32:
+            close("det.rows." + k, a[k], c[k], 2e-5)
+        else:
+            assert torch.equal(a[k], c[k]), k  # (the row results do not depend on the mode)
+    close("det.cs", a["cs"], dy.float().sum(0), 1e-5)

@@ -3,6 +3,7 @@
 // (vds_knob_set / vds_knob_get, include/vds.h) -- explicit, process-wide, documented state instead of hidden reads.
 // Defaults are the measured-best settings; every knob exists for same-process A/B measurements and tests.
 #pragma once
+#include <cstddef>
 
 namespace vdscfg {
 enum Knob {
@@ -42,3 +43,11 @@ inline int geti(Knob k) { return (int)g_val[k]; }
 // VDS_RCCL_PATH (a string: not in the table), or nullptr
 const char* rccl_path();
 }  // namespace vdscfg
+
+// deterministic mode (vds_set_deterministic): the caller's workspace for partial results
+namespace vdsdet {
+inline bool on() { return vdscfg::g_val[vdscfg::DETERMINISTIC] != 0; }
+// the workspace if it holds `floats` floats, else nullptr (and the error message is set)
+float* workspace(size_t floats, const char* who);
+size_t workspace_bytes();
+}  // namespace vdsdet

@@ -1,7 +1,9 @@
 // The knob table of config.h: names, defaults, and the ONE place where the library reads its environment.
 #include "config.h"
+#include "common.h"
 #include "../../include/vds.h"
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
@@ -51,10 +53,33 @@ static Init g_init;  // runs when the library is loaded
 const char* rccl_path() { return g_rccl_path; }
 }  // namespace vdscfg
 
+namespace vdsdet {
+static float* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+float* workspace(size_t floats, const char* who) {
+  if (g_ws && floats * 4 <= g_ws_bytes) return g_ws;
+  vdserr::set("%s: deterministic mode needs %zu bytes of workspace, vds_set_deterministic was given %zu", who, floats * 4,
+              g_ws_bytes);
+  return nullptr;
+}
+size_t workspace_bytes() { return g_ws ? g_ws_bytes : 0; }
+}  // namespace vdsdet
+
+extern "C" int vds_set_deterministic(int32_t on, void* workspace, size_t workspace_bytes) {
+  const int prev = vdscfg::geti(vdscfg::DETERMINISTIC);
+  if (on != 0 && on != 1) return VDS_ERR_ARG;
+  if (on && (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < 4096)) return VDS_ERR_ARG;
+  vdscfg::g_val[vdscfg::DETERMINISTIC] = on;
+  vdsdet::g_ws = on ? (float*)workspace : nullptr;
+  vdsdet::g_ws_bytes = on ? workspace_bytes : 0;
+  return prev;
+}
+
 extern "C" int vds_knob_set(const char* name, double value) {
   if (!name) return VDS_ERR_ARG;
   for (int i = 0; i < vdscfg::N_KNOBS; ++i)
     if (strcmp(name, vdscfg::kDefs[i].name) == 0) {
+      if (i == vdscfg::DETERMINISTIC) return VDS_ERR_ARG;  // (needs its workspace: vds_set_deterministic)
       vdscfg::g_val[i] = value;
       return VDS_OK;
     }

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
                                                               int shift_col, int scale_col, const float* rstd,
                                                               const bf16_t* dres, long lddres, bf16_t* dx, long lddx,
                                                               float* dmod, float* dw, int B, int L, int D,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, float* det) {
   __shared__ float red[4][64 * NC * 8 + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mo
       const int col = (ln + 64 * i) * 8 + e;
       if (col < D) {
         const float sm = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
-        if (pass == 0) atomicAdd(drow + shift_col + col, sm);
+        // deterministic mode: the workgroup's partial goes to det[pass][b][blockIdx.x][D]; det_finish_kernel sums in order
+        if (det) det[(((long)pass * gridDim.y + b) * gridDim.x + blockIdx.x) * D + col] = sm;
+        else if (pass == 0) atomicAdd(drow + shift_col + col, sm);
         else if (pass == 1) atomicAdd(drow + scale_col + col, sm);
         else atomicAdd(dw + col, sm);
       }
@@ -349,7 +351,7 @@ template <int NC, int QF = -1>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long lddxn, const bf16_t* y, long ldy,
                                                        const float* mod, long ldmod, int gate_col, bf16_t* dy,
                                                        long lddy, float* dmod, float* dbias, int B, int L, int D,
-                                                       int rows_per_block, QOut qo) {
+                                                       int rows_per_block, QOut qo, float* det) {
   __shared__ float red[4][64 * NC * 8 + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -401,7 +403,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
       const int col = (ln + 64 * i) * 8 + e;
       if (col < D) {
         const float s = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
-        if (pass == 0) atomicAdd(dmod + (long)b * ldmod + gate_col + col, s);
+        if (det) det[(((long)pass * gridDim.y + b) * gridDim.x + blockIdx.x) * D + col] = s;  // (as rmsnorm_mod_bwd_kernel)
+        else if (pass == 0) atomicAdd(dmod + (long)b * ldmod + gate_col + col, s);
         else atomicAdd(dbias + col, s);
       }
     }
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dxn, long l
 // column sums of a bf16 matrix (bias gradients): block = 64 column-chunks x 4 row lanes
 // rps > 0: only rows r with (r % rps) >= roff are summed (token rows of the [B*L] buffer, register rows skipped)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, long ldx, float* out, int M, int N,
-                                                     int rows_per_block, int rps, int roff) {
+                                                     int rows_per_block, int rps, int roff, float* det) {
   __shared__ float red[4][64 * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -432,8 +435,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, long ldx, 
   __syncthreads();
   for (int idx = threadIdx.x; idx < 512; idx += 256) {
     const int col = blockIdx.x * 512 + idx;
-    if (col < N) atomicAdd(out + col, red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx]);
+    if (col >= N) continue;
+    const float sm = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+    if (det) det[(long)blockIdx.y * N + col] = sm;
+    else atomicAdd(out + col, sm);
   }
+}
+
+// ---- deterministic mode (vds_set_deterministic): the second stage of every column / scalar sum -------------------------
+// target[g * tstride + c] += sum over p < n_parts of part[(g * n_parts + p) * width + c], p in index order (8 loads in
+// flight, the adds strictly sequential): the same words every run.
+__global__ __launch_bounds__(256) void det_finish_kernel(const float* part, int n_parts, int width, float* target, long tstride,
+                                                         int groups) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)groups * width) return;
+  const int g = (int)(i / width), c = (int)(i % width);
+  const float* p = part + (long)g * n_parts * width + c;
+  float v = target[(long)g * tstride + c];
+  int k = 0;
+  for (; k + 8 <= n_parts; k += 8) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = p[(long)(k + j) * width];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += t[j];
+  }
+  for (; k < n_parts; ++k) v += p[(long)k * width];
+  target[(long)g * tstride + c] = v;
+}
+// a scalar with many partials (the lambda gradient: one per workgroup of the RoPE backward): thread t sums partials t,
+// t + 256, .. in order, then a fixed butterfly over the lanes and a fixed sum over the four waves
+__global__ __launch_bounds__(256) void det_finish_scalar_kernel(const float* part, int n_parts, float* target) {
+  __shared__ float red[4];
+  float v = 0.f;
+  for (int k = threadIdx.x; k < n_parts; k += 256) v += part[k];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) target[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------- qkv split + RoPE + residual-V (fwd) ---
@@ -599,7 +638,7 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* dq, con
                                                            const bf16_t* qkv_raw, const bf16_t* v0,
                                                            const bf16_t* lamp, float* dv0_acc, float* dlam,
                                                            bf16_t* dqkv, int mix, int add_dv0, int B, int L, int H,
-                                                           int hd, int hdp) {
+                                                           int hd, int hdp, float* det) {
   __shared__ float red[4];
   const int upt = H * (hd >> 3);
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -676,7 +715,10 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* dq, con
     dl = wave_sum(dl);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dl;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dlam, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+      if (det) det[blockIdx.x] = red[0] + red[1] + red[2] + red[3];  // deterministic mode: det_finish_scalar_kernel sums in order
+      else atomicAdd(dlam, red[0] + red[1] + red[2] + red[3]);
+    }
   }
 }
 
@@ -696,7 +738,7 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
                                                                const bf16_t* qkv_raw, const bf16_t* v0,
                                                                const bf16_t* lamp, float* dv0_acc, float* dlam,
                                                                bf16_t* dqkv, int mix, int add_dv0, int B, int L,
-                                                               int H, int hd, int hdp, QOut qo) {
+                                                               int H, int hd, int hdp, QOut qo, float* det) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -806,7 +848,10 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_tok_kernel(const bf16_t* dq,
     dl = wave_sum(dl);
     if (lane == 0) red[wave] = dl;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dlam, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+      if (det) det[blockIdx.x] = red[0] + red[1] + red[2] + red[3];  // deterministic mode: det_finish_scalar_kernel sums in order
+      else atomicAdd(dlam, red[0] + red[1] + red[2] + red[3]);
+    }
   }
 }
 
@@ -979,7 +1024,7 @@ constexpr int SL_DX_ROWS = 384;  // rows of W per workgroup at most (the host pi
 template <int MB>
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* dy, const float* x, const bf16_t* W,
                                                               float* dx, int M, int N, int K, int act_in,
-                                                              int rows_per_block, SLBatch bt) {
+                                                              int rows_per_block, SLBatch bt, float* det) {
   __shared__ float red[4][8][MB][8];
   __shared__ __attribute__((aligned(16))) float dyt[SL_DX_ROWS][MB];
   if (bt.W) {
@@ -1040,7 +1085,8 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* dy, c
     if (b >= M || k >= K) continue;
     float v = red[0][cc][b][e] + red[1][cc][b][e] + red[2][cc][b][e] + red[3][cc][b][e];
     if (act_in) v *= dsilu_f(x[(long)b * K + k]);
-    atomicAdd(dx + (long)b * K + k, v);
+    if (det) det[(((long)blockIdx.z * gridDim.y + blockIdx.y) * M + b) * K + k] = v;  // deterministic mode: [z][y][M][K] partials
+    else atomicAdd(dx + (long)b * K + k, v);
   }
 }
 
@@ -1269,6 +1315,12 @@ __global__ void rope_rows_kernel(const float* tab_t_cos, const float* tab_t_sin,
 }
 
 inline int ok() { return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH; }
+// deterministic mode: second stage of a column sum (see det_finish_kernel)
+inline void det_finish(const float* part, int n_parts, int width, float* target, long tstride, int groups, hipStream_t s) {
+  const long n = (long)groups * width;
+  hipLaunchKernelGGL(det_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, n_parts, width, target,
+                     tstride, groups);
+}
 // rows of one sample per workgroup: ~768 workgroups in total (3 per CU, enough waves to stream HBM)
 // while every workgroup still folds >= 8 rows into its column sums before the atomics
 inline int rows_per_block_for(int L, int B) {
@@ -1388,21 +1440,29 @@ extern "C" int vds_rmsnorm_mod_bwd(const void* dy, int64_t lddy, const void* x, 
   const int rpb = rows_per_block_for(L, B);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((L + rpb - 1) / rpb, B);
+  float* det = nullptr;
+  if (vdsdet::on() && !(det = vdsdet::workspace((size_t)(w ? 3 : 2) * B * grid.x * D, "vds_rmsnorm_mod_bwd"))) return VDS_ERR_ARG;
   vdsprof::Scope ps(VDS_PROF_RMSNORM_BWD, s, 0.0, (dres ? 8.0 : 6.0) * B * L * D + 4.0 * B * L);
 #define CALL(NC)                                                                                                  \
   do {                                                                                                            \
     if (w)                                                                                                        \
       hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NC, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, (long)lddy, \
                          (const bf16_t*)x, (long)ldx, (const bf16_t*)w, mod, (long)ldmod, shift_col, scale_col,   \
-                         rstd, (const bf16_t*)dres, (long)lddres, (bf16_t*)dx, (long)lddx, dmod, dw, B, L, D, rpb); \
+                         rstd, (const bf16_t*)dres, (long)lddres, (bf16_t*)dx, (long)lddx, dmod, dw, B, L, D, rpb, det); \
     else                                                                                                          \
       hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NC, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (long)lddy, \
                          (const bf16_t*)x, (long)ldx, (const bf16_t*)nullptr, mod, (long)ldmod, shift_col,        \
                          scale_col, rstd, (const bf16_t*)dres, (long)lddres, (bf16_t*)dx, (long)lddx, dmod,       \
-                         (float*)nullptr, B, L, D, rpb);                                                          \
+                         (float*)nullptr, B, L, D, rpb, det);                                                     \
   } while (0)
   NC_DISPATCH(D, CALL);
 #undef CALL
+  if (det) {
+    const long plane = (long)B * grid.x * D;
+    det_finish(det, (int)grid.x, D, dmod + shift_col, ldmod, B, s);
+    det_finish(det + plane, (int)grid.x, D, dmod + scale_col, ldmod, B, s);
+    if (w) det_finish(det + 2 * plane, (int)(B * grid.x), D, dw, 0, 1, s);
+  }
   return ok();
 }
 
@@ -1413,13 +1473,19 @@ extern "C" int vds_gate_bwd(const void* dxn, int64_t lddxn, const void* y, int64
   const int rpb = rows_per_block_for(L, B);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((L + rpb - 1) / rpb, B);
+  float* det = nullptr;
+  if (vdsdet::on() && !(det = vdsdet::workspace((size_t)2 * B * grid.x * D, "vds_gate_bwd"))) return VDS_ERR_ARG;
   vdsprof::Scope ps(VDS_PROF_GATE_BWD, s, 0.0, 6.0 * B * L * D);
 #define CALL(NC)                                                                                             \
   hipLaunchKernelGGL((gate_bwd_kernel<NC>), grid, dim3(256), 0, s, (const bf16_t*)dxn, (long)lddxn,           \
                      (const bf16_t*)y, (long)ldy, mod, (long)ldmod, gate_col, (bf16_t*)dy, (long)lddy, dmod, \
-                     dbias, B, L, D, rpb, QOut{})
+                     dbias, B, L, D, rpb, QOut{}, det)
   NC_DISPATCH(D, CALL);
 #undef CALL
+  if (det) {
+    det_finish(det, (int)grid.x, D, dmod + gate_col, ldmod, B, s);
+    if (dbias) det_finish(det + (long)B * grid.x * D, (int)(B * grid.x), D, dbias, 0, 1, s);
+  }
   return ok();
 }
 
@@ -1432,20 +1498,26 @@ extern "C" int vds_gate_bwd_fp8(const void* dxn, int64_t lddxn, const void* y, i
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((L + rpb - 1) / rpb, B);
   const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_part, dq_out};
+  float* det = nullptr;
+  if (vdsdet::on() && !(det = vdsdet::workspace((size_t)2 * B * grid.x * D, "vds_gate_bwd_fp8"))) return VDS_ERR_ARG;
   vdsprof::Scope ps(VDS_PROF_GATE_BWD, s, 0.0, 5.0 * B * L * D);
 #define CALL(NC)                                                                                                   \
   do {                                                                                                             \
     if (fmt == 0)                                                                                                  \
       hipLaunchKernelGGL((gate_bwd_kernel<NC, 0>), grid, dim3(256), 0, s, (const bf16_t*)dxn, (long)lddxn,          \
                          (const bf16_t*)y, (long)ldy, mod, (long)ldmod, gate_col, (bf16_t*)nullptr, 0L, dmod, dbias, \
-                         B, L, D, rpb, qo);                                                                        \
+                         B, L, D, rpb, qo, det);                                                                   \
     else                                                                                                           \
       hipLaunchKernelGGL((gate_bwd_kernel<NC, 1>), grid, dim3(256), 0, s, (const bf16_t*)dxn, (long)lddxn,          \
                          (const bf16_t*)y, (long)ldy, mod, (long)ldmod, gate_col, (bf16_t*)nullptr, 0L, dmod, dbias, \
-                         B, L, D, rpb, qo);                                                                        \
+                         B, L, D, rpb, qo, det);                                                                   \
   } while (0)
   NC_DISPATCH(D, CALL);
 #undef CALL
+  if (det) {
+    det_finish(det, (int)grid.x, D, dmod + gate_col, ldmod, B, s);
+    if (dbias) det_finish(det + (long)B * grid.x * D, (int)(B * grid.x), D, dbias, 0, 1, s);
+  }
   return ok();
 }
 
@@ -1454,8 +1526,11 @@ extern "C" int vds_colsum_bf16_rows(const void* x, int64_t ldx, float* out, int3
   if (!x || !out || (N & 7) || (ldx & 7) || rows_per_sample < 0 || row_offset < 0) return VDS_ERR_ARG;
   const int rpb = M > 8192 ? (M + 127) / 128 : 64;
   dim3 grid((N / 8 + 63) / 64, (M + rpb - 1) / rpb);
+  float* det = nullptr;
+  if (vdsdet::on() && !(det = vdsdet::workspace((size_t)grid.y * N, "vds_colsum_bf16"))) return VDS_ERR_ARG;
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ldx, out, M, N, rpb,
-                     rows_per_sample, row_offset);
+                     rows_per_sample, row_offset, det);
+  if (det) det_finish(det, (int)grid.y, N, out, 0, 1, (hipStream_t)stream);
   return ok();
 }
 extern "C" int vds_colsum_bf16(const void* x, int64_t ldx, float* out, int32_t M, int32_t N, vds_stream_t stream) {
@@ -1586,23 +1661,28 @@ extern "C" int vds_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, 
   if (add_dv0 && !dv0_acc) return VDS_ERR_ARG;
   const long n = (long)B * L * H * (hd >> 3);
   vdsprof::Scope ps(VDS_PROF_QKV_ROPE_BWD, (hipStream_t)stream, 0.0, (mix ? 24.0 : 12.0) * B * L * H * hd);
-  if (rope_tok_form(H, hd, hdp)) {
+  const bool tok = rope_tok_form(H, hd, hdp);
+  const unsigned nblk = tok ? (unsigned)(((long)B * L + 3) / 4) : (unsigned)((n + 255) / 256);
+  float* det = nullptr;  // deterministic mode: the lambda gradient as per-workgroup partials + one fixed-order sum
+  if (mix && vdsdet::on() && !(det = vdsdet::workspace(nblk, "vds_qkv_rope_bwd"))) return VDS_ERR_ARG;
+  if (tok) {
     const int D = H * hd, lds = 4 * (4 * D + 4 * hd);
-    const dim3 grid((unsigned)(((long)B * L + 3) / 4));
+    const dim3 grid(nblk);
 #define ROPE_BWD(NI)                                                                                                \
   hipLaunchKernelGGL(qkv_rope_bwd_tok_kernel<NI>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dq,    \
                      (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw, (const bf16_t*)v0,  \
-                     (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp, QOut{})
+                     (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp, QOut{}, det)
     if (D <= 512) ROPE_BWD(1);
     else if (D <= 1024) ROPE_BWD(2);
     else if (D <= 1536) ROPE_BWD(3);
     else ROPE_BWD(4);
 #undef ROPE_BWD
-    return ok();
+  } else {
+    hipLaunchKernelGGL(qkv_rope_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw,
+                       (const bf16_t*)v0, (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp, det);
   }
-  hipLaunchKernelGGL(qkv_rope_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw,
-                     (const bf16_t*)v0, (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)dqkv, mix, add_dv0, B, L, H, hd, hdp);
+  if (det) hipLaunchKernelGGL(det_finish_scalar_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)det, (int)nblk, dlam);
   return ok();
 }
 
@@ -1621,10 +1701,12 @@ extern "C" int vds_qkv_rope_bwd_fp8(const void* dq, const void* dk, const void* 
   const int D = H * hd, lds = 4 * (4 * D + 4 * hd);
   const dim3 grid((unsigned)(((long)B * L + 3) / 4));
   const QOut qo{(unsigned char*)q, (long)ldq, amax_in, amax_part, dq_out};
+  float* det = nullptr;
+  if (mix && vdsdet::on() && !(det = vdsdet::workspace(grid.x, "vds_qkv_rope_bwd_fp8"))) return VDS_ERR_ARG;
 #define ROPE_BWD_Q(NI, F)                                                                                             \
   hipLaunchKernelGGL((qkv_rope_bwd_tok_kernel<NI, F>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dq, \
                      (const bf16_t*)dk, (const bf16_t*)dv, cosb, sinb, (const bf16_t*)qkv_raw, (const bf16_t*)v0,    \
-                     (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)nullptr, mix, add_dv0, B, L, H, hd, hdp, qo)
+                     (const bf16_t*)lam, dv0_acc, dlam, (bf16_t*)nullptr, mix, add_dv0, B, L, H, hd, hdp, qo, det)
 #define ROPE_BWD_F(F)              \
   do {                             \
     if (D <= 512) ROPE_BWD_Q(1, F); \
@@ -1636,6 +1718,7 @@ extern "C" int vds_qkv_rope_bwd_fp8(const void* dq, const void* dk, const void* 
   else ROPE_BWD_F(1);
 #undef ROPE_BWD_F
 #undef ROPE_BWD_Q
+  if (det) hipLaunchKernelGGL(det_finish_scalar_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)det, (int)grid.x, dlam);
   return ok();
 }
 
@@ -1776,17 +1859,20 @@ extern "C" int vds_small_linear_bwd(const float* dy, const float* x, const void*
     const int rows = ((N + ny - 1) / ny + 31) / 32 * 32;
     ny = (N + rows - 1) / rows;
     const dim3 grid(gx, ny);
+    float* det = nullptr;
+    if (vdsdet::on() && !(det = vdsdet::workspace((size_t)ny * 16 * K, "vds_small_linear_bwd"))) return VDS_ERR_ARG;
     for (int r0 = 0; r0 < M; r0 += 16) {  // <= 16 rows per launch (rows are independent; dx accumulates)
       const int m = min(16, M - r0);
       const float* dys = dy + (long)r0 * N;
       const float* xs = x + (long)r0 * K;
       float* dxs = dx + (long)r0 * K;
       if (m <= 4)
-        hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows, SLBatch{});
+        hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows, SLBatch{}, det);
       else if (m <= 8)
-        hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows, SLBatch{});
+        hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows, SLBatch{}, det);
       else
-        hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows, SLBatch{});
+        hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dys, xs, (const bf16_t*)W, dxs, m, N, K, act_in, rows, SLBatch{}, det);
+      if (det) det_finish(det, ny, m * K, dxs, 0, 1, s);
     }
   }
   return ok();
@@ -1829,9 +1915,12 @@ extern "C" int vds_small_linear_bwd_batched(const float* dy, int64_t dy_stride, 
     ny = (N + rows - 1) / rows;
     const dim3 grid(gx, ny, nb);
     const SLBatch bt{W_ptrs, nullptr, nullptr, nullptr, (long)dy_stride};
-    if (M <= 4) hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)nullptr, dx, M, N, K, act_in, rows, bt);
-    else if (M <= 8) hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)nullptr, dx, M, N, K, act_in, rows, bt);
-    else hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)nullptr, dx, M, N, K, act_in, rows, bt);
+    float* det = nullptr;
+    if (vdsdet::on() && !(det = vdsdet::workspace((size_t)nb * ny * M * K, "vds_small_linear_bwd_batched"))) return VDS_ERR_ARG;
+    if (M <= 4) hipLaunchKernelGGL(small_linear_dx_kernel<4>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)nullptr, dx, M, N, K, act_in, rows, bt, det);
+    else if (M <= 8) hipLaunchKernelGGL(small_linear_dx_kernel<8>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)nullptr, dx, M, N, K, act_in, rows, bt, det);
+    else hipLaunchKernelGGL(small_linear_dx_kernel<16>, grid, dim3(256), 0, s, dy, x, (const bf16_t*)nullptr, dx, M, N, K, act_in, rows, bt, det);
+    if (det) det_finish(det, nb * ny, M * K, dx, 0, 1, s);
   }
   return ok();
 }

@@ -1396,30 +1396,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
   *reinterpret_cast<f32x4*>(c) = v;
 }
 
-static float* g_det_ws = nullptr;  // deterministic mode: caller-allocated workspace (vds_set_deterministic)
-static size_t g_det_ws_bytes = 0;
-
-}  // namespace
-
-namespace vdsdet {
-float* workspace(size_t* bytes) {
-  if (bytes) *bytes = g_det_ws_bytes;
-  return g_det_ws;
-}
-}  // namespace vdsdet
-
-extern "C" int vds_set_deterministic(int32_t on, void* workspace, size_t workspace_bytes) {
-  const int prev = vdscfg::geti(vdscfg::DETERMINISTIC);
-  if (on != 0 && on != 1) return VDS_ERR_ARG;
-  if (on && workspace && ((uintptr_t)workspace & 15)) return VDS_ERR_ARG;
-  vdscfg::g_val[vdscfg::DETERMINISTIC] = on;
-  g_det_ws = on ? (float*)workspace : nullptr;
-  g_det_ws_bytes = on && workspace ? workspace_bytes : 0;
-  return prev;
-}
-
-namespace {
-
 // `tile` of vds_gemm_force_tile / VDS_GEMM_TILE: 0 = cost model | 128 | 256 | 2 (= 256 x 128)
 inline int force_tile() { return vdscfg::geti(vdscfg::GEMM_TILE); }
 
@@ -1431,28 +1407,32 @@ inline int narrow_last_column(long N) {
 }
 
 // a split-K launch in deterministic mode: slabs in the workspace + the fixed-order reduction.  `launch_fn` launches the
-// GEMM kernel on `p`.  The split count is lowered until its slabs fit the workspace (1 = no slabs needed).
+// GEMM kernel on `p`, `bk` is that kernel's K-tile depth (how it cuts K into splits).  The split count is lowered until
+// its slabs fit the workspace (1 = no slabs needed).
 template <typename F>
-int launch_split_det(GemmP& p, float* C, long ldc, hipStream_t s, F launch_fn) {
-  const int kt_total = cdiv(p.K, 64);
+int launch_split_det(GemmP& p, float* C, long ldc, hipStream_t s, int bk, F launch_fn) {
+  const int kt_total = cdiv(p.K, bk);
   int split = p.split_k;
   const size_t slab = (size_t)p.M * p.N * 4;
-  while (split > 1 && (g_det_ws == nullptr || (size_t)split * slab > g_det_ws_bytes)) --split;
+  while (split > 1 && (size_t)split * slab > vdsdet::workspace_bytes()) --split;
   if (split <= 1) {  // one workgroup per output tile: a single (atomic) add per element and call is order-free
     p.split_k = 1;
     return launch_fn(p);
   }
   const int per = cdiv(kt_total, split);
   const int n_eff = cdiv(kt_total, per);  // splits that own K tiles (the others return at once and write nothing)
+  float* ws = vdsdet::workspace((size_t)split * p.M * p.N, "vds_gemm (split-K)");
+  if (!ws) return VDS_ERR_ARG;
   p.split_k = split;
   p.atomic = 0;
-  p.C = g_det_ws;
+  p.joint_xcd = 0;  // (the slab index is blockIdx.y)
+  p.C = ws;
   p.ldc = p.N;
   p.slab_stride = (long)p.M * p.N;
   const int rc = launch_fn(p);
   if (rc != VDS_OK) return rc;
   const long n4 = (long)p.M * (p.N >> 2);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)g_det_ws, n_eff,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)ws, n_eff,
                      p.slab_stride, C, ldc, p.M, p.N);
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
@@ -1547,8 +1527,8 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
     p.joint_xcd = vdscfg::geti(vdscfg::GEMM_TN_JOINT);
   }
   // the split-K launch of a weight gradient: atomics (default) or slabs + fixed-order reduction (deterministic mode)
-  auto launch_tn = [&](auto fn) -> int {
-    if (det && p.split_k > 1) return launch_split_det(p, (float*)a->C, a->ldc, s, fn);
+  auto launch_tn = [&](int bk, auto fn) -> int {
+    if (det && p.split_k > 1) return launch_split_det(p, (float*)a->C, a->ldc, s, bk, fn);
     return fn(p);
   };
   if (auto_split) {
@@ -1586,9 +1566,9 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
         long g = (chunk + p.tiles_n / 2) / p.tiles_n;
         p.group_m = (int)(g < 1 ? 1 : (g > p.tiles_m ? p.tiles_m : g));
       }
-      return launch_tn([&](GemmP& q) { return mid::launch<VDS_TN, VDS_EPI_F32>(q, s); });
+      return launch_tn(mid::BK, [&](GemmP& q) { return mid::launch<VDS_TN, VDS_EPI_F32>(q, s); });
     }
-    return launch_tn([&](GemmP& q) { return launch<VDS_TN, VDS_EPI_F32>(q, s); });
+    return launch_tn(BK, [&](GemmP& q) { return launch<VDS_TN, VDS_EPI_F32>(q, s); });
   }
   // 256 x 128 tiles, two workgroups per CU: no padded half tile when N is a multiple of 128 but not of 256, and the
   // epilogue of one workgroup runs under the main loop of the other.  Measured (tools/bench_gemm_tiles.py, DiT-XL
@@ -1619,7 +1599,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
       GOM(VDS_NN, VDS_EPI_DGELU)
 #undef GOM
       if (a->layout == VDS_TN && a->epilogue == VDS_EPI_F32)
-        return launch_tn([&](GemmP& q) { return mid::launch<VDS_TN, VDS_EPI_F32>(q, s); });
+        return launch_tn(mid::BK, [&](GemmP& q) { return mid::launch<VDS_TN, VDS_EPI_F32>(q, s); });
     }
   }
   if (use_big) {
@@ -1652,7 +1632,7 @@ extern "C" int vds_gemm_bf16(const vds_gemm_args* a, vds_stream_t stream) {
   GO(VDS_NN, VDS_EPI_DGELU)
 #undef GO
   if (a->layout == VDS_TN && a->epilogue == VDS_EPI_F32)
-    return launch_tn([&](GemmP& q) { return launch<VDS_TN, VDS_EPI_F32>(q, s); });
+    return launch_tn(BK, [&](GemmP& q) { return launch<VDS_TN, VDS_EPI_F32>(q, s); });
   return VDS_ERR_UNSUPPORTED;
 }
 
@@ -1706,7 +1686,7 @@ extern "C" int vds_gemm_fp8(const vds_gemm_args* a, const float* scale_a, const 
   hipStream_t s = (hipStream_t)stream;
   if (tn) {
     if (vdscfg::geti(vdscfg::DETERMINISTIC) && p.split_k > 1)
-      return launch_split_det(p, (float*)a->C, a->ldc, s, [&](GemmP& q) { return big::launch<VDS_TN, VDS_EPI_F32, 3>(q, s); });
+      return launch_split_det(p, (float*)a->C, a->ldc, s, BK, [&](GemmP& q) { return big::launch<VDS_TN, VDS_EPI_F32, 3>(q, s); });
     return big::launch<VDS_TN, VDS_EPI_F32, 3>(p, s);
   }
   if (vdscfg::geti(vdscfg::DETERMINISTIC) && p.e_colsum) return VDS_ERR_UNSUPPORTED;  // (fused column sums are atomic)

@@ -537,7 +537,9 @@ class DiTBlock(nn.Module):
             dmod = torch.zeros(B, 9 * D, dtype=f32, device=dev)
         # --- MLP
         hist = fp8_hist if bs.f8 else None
-        emit = hist is not None and hist.ready and not _NO_EMIT
+        # (deterministic mode: the fc2 input gradient keeps its separate, fixed-order bias-gradient pass -- the GEMM epilogue's
+        # fused column sums are per-tile atomics -- so the producers do not emit fp8 in backward)
+        emit = hist is not None and hist.ready and not _NO_EMIT and not ops.is_deterministic()
         pemit = emit and not _NO_PRODUCER_EMIT
         if pemit:  # the fc2 output gradient leaves gate_bwd as e5m2
             fq, fs = ops.gate_bwd_fp8(dX, bs.y_mlp, mod, 8 * D, dmod, Gr("mlp.2.bias"), B, L, F8.E5M2,

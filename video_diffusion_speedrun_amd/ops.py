@@ -79,6 +79,10 @@ def knob_get(name: str) -> float:
 _det_ws = [None]
 
 
+def is_deterministic() -> bool:
+    return _det_ws[0] is not None
+
+
 def set_deterministic(on: bool, workspace_bytes: int = 1 << 30, device="cuda") -> bool:
     """fixed-order reductions in every backward kernel (include/vds.h: vds_set_deterministic); the workspace for the
     partial results is a torch allocation this module keeps alive while the mode is on.  Returns the previous mode."""
