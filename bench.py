@@ -67,7 +67,7 @@ import torch.distributed as dist
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_JSON = "r05_traffic.json"  # committed rocprofv3 PMC passes over whole train steps, per kernel class (tools/collect_profiles.sh)
+TRAFFIC_JSONS = ("r06_traffic.json", "r05_traffic.json")  # committed rocprofv3 PMC passes over whole train steps, per kernel class (tools/collect_profiles.sh); newest first
 FP8_CLASSES = ("gemm_fp8", "attn_fp8_fwd", "attn_fp8_dkv", "attn_fp8_dq")
 # What a dense bf16 MFMA stream reaches on THIS chip on random data: a bare v_mfma_f32_16x16x32_bf16 loop, all operands in
 # registers, no LDS / memory traffic, runs 1.79-1.84 PFLOP/s at the board's power limit (tools/mfma_power.hip,
@@ -291,6 +291,23 @@ def measure(one_step, steps, warmup, world, kw, args, fs=None, graphed=None):
     return r
 
 
+_CSRC_DIGEST = []
+
+
+def csrc_digest():
+    """sha256 over csrc/*.hip, *.h of this tree (the same digest tools/pmc_class_traffic.py stamps a traffic file with)"""
+    if not _CSRC_DIGEST:
+        import glob
+        import hashlib
+        root = os.path.join(REPO, "video_diffusion_speedrun_amd", "csrc")
+        h = hashlib.sha256()
+        for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+        _CSRC_DIGEST.append(h.hexdigest())
+    return _CSRC_DIGEST[0]
+
+
 def roofline_of(dominant, dom, workload, B):
     """the JSON `roofline` object of one kernel class measured live (dom = its launches in the timed region)"""
     mfma_bound = dom["flops"] > 0
@@ -304,8 +321,8 @@ def roofline_of(dominant, dom, workload, B):
     # HBM bytes per launch: PMC counters cannot be read from inside this process (rocprofv3 wraps the command in
     # separate --pmc passes), so the figure is the committed pass of this kernel at this workload and batch,
     # stamped with the commit and kernel symbol it was taken on; null when there is none
-    traffic, traffic_src = None, None
-    for tjname in (TRAFFIC_JSON, "r04_traffic.json"):
+    traffic, traffic_src, traffic_stale = None, None, None
+    for tjname in TRAFFIC_JSONS:
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", tjname)))
             # round 5: one section per workload ("c3b", "c5"), every kernel class of the step, averaged over the class's
@@ -316,11 +333,16 @@ def roofline_of(dominant, dom, workload, B):
                 traffic = (2 * k["fetch_kb"] + k["write_kb"]) * 1024
                 traffic_src = (f"profiles/{tjname}: rocprofv3 PMC passes ({k.get('launches_averaged', 1)} launches of "
                                f"{k['symbol']}) at commit {tj['commit']}")
+                # stale = the kernel sources of this tree are not the ones the passes were measured on (sha256 over
+                # csrc/*.hip, *.h recorded by tools/pmc_class_traffic.py; files without it predate round 6: stale)
+                traffic_stale = tj.get("csrc_sha256") != csrc_digest()
+                if traffic_stale:
+                    traffic_src = "stale: " + traffic_src
                 break
         except (OSError, KeyError, ValueError, TypeError):
             pass
     out = {"bound": "mfma" if mfma_bound else "hbm", "achieved": ach, "peak": peak, "unit": unit,
-           "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+           "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
            "algorithmic_bytes": dom["bytes"] / dom["launches"],
            "kernel": dominant, "launches": dom["launches"], "avg_ms": dom["ms"] / dom["launches"]}
     if mfma_bound:
@@ -382,6 +404,8 @@ def small_batch_leg(make_step, kw, args, flops, latent_shape, device, gen, B=2):
     out = {"per_gpu_batch": B, "value": value, "unit": "samples/s", "steps": steps, "warmup": warmup,
            "ms_per_step": r["dt"] / steps * 1e3, "ms_per_step_median": r["median_ms"],
            "mfma_util_step": value * flops / (PEAK_BF16_TFLOPS * 1e12), "loss": float(r["loss"].item())}
+    if r["dom"]:  # its own dominant kernel, timed live like the headline's (traffic: the file's section for this batch, if any)
+        out["roofline"] = roofline_of(r["dominant"], r["dom"], "c3b_b2" if B == 2 else "c3b", B)
     if r["breakdown"]:
         bd = r["breakdown"]
         out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(bd.items(), key=lambda kv: -kv[1]["ms"])}
@@ -502,6 +526,8 @@ def build_parser():
     ap.add_argument("--no-small-batch", action="store_true",
                     help="c3b on 1 GPU: skip the `small_batch` measurement (the same model at a per-GPU batch of 2, the batch "
                          "SURVEY 8(d) names)")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="run with vds_set_deterministic(1): fixed-order reductions in every backward kernel (its cost on the step)")
     ap.add_argument("--no-fp8-cross-attention", action="store_true",
                     help="c5: keep the cross-attention products in bf16 (fp8 self-attention only)")
     return ap
@@ -533,6 +559,8 @@ def main():
     B = args.batch or B_default
     flops = step_flops(kw, latent_shape)
 
+    if args.deterministic:
+        ops.set_deterministic(True, 2 << 30, device)
     model = build_model(kw, device, seed=1234)  # same init on every rank
     if args.workload == "c5":
         model.enable_fp8(attention=not args.no_fp8_attention, cross_attention=not args.no_fp8_cross_attention)
@@ -624,6 +652,7 @@ def main():
             "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"fsdp{world}" if world > 1 else "single",
                        "launch": "hip-graph replay" if graphed is not None else "eager",
+                       "deterministic": bool(args.deterministic),
                        "step_tflop_per_sample": flops / 1e12},
             "mfma_util_step": value * flops / (world * PEAK_BF16_TFLOPS * 1e12),
             "loss": loss_val,

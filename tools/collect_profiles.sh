@@ -3,7 +3,7 @@
 #     bash tools/collect_profiles.sh r02        (writes gpurun_out/prof_r02/..., summaries are then copied into profiles/)
 # Counter passes are separate runs (--pmc with --kernel-trace only), as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -27,8 +27,10 @@ find "$OUT/stats7" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/step_c3b/$c" -o x --output-format csv -- $PY bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-small-batch --no-prof > "$OUT/step_c3b_$c.log" 2>&1
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/step_c5/$c" -o x --output-format csv -- $PY bench.py --workload c5 --steps 1 --warmup 3 --no-cpu-baseline --no-prof > "$OUT/step_c5_$c.log" 2>&1
+  # (round 6) the batch SURVEY 8(d) names: bench.py's `small_batch` leg has its own roofline object
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/step_c3b_b2/$c" -o x --output-format csv -- $PY bench.py --batch 2 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-small-batch --no-prof > "$OUT/step_c3b_b2_$c.log" 2>&1
 done
-$PY tools/pmc_class_traffic.py "$(git rev-parse --short HEAD 2>/dev/null || echo ${COMMIT:-unknown})" "c3b:$OUT/step_c3b" "c5:$OUT/step_c5" > "$OUT/${TAG}_traffic.json" 2> "$OUT/traffic_json.err"
+$PY tools/pmc_class_traffic.py "$(git rev-parse --short HEAD 2>/dev/null || echo ${COMMIT:-unknown})" "c3b:$OUT/step_c3b" "c5:$OUT/step_c5" "c3b_b2:$OUT/step_c3b_b2:2" > "$OUT/${TAG}_traffic.json" 2> "$OUT/traffic_json.err"
 # 2. HBM-side bytes of the attention kernels at the bench shape (B = 12): FETCH_SIZE and WRITE_SIZE cannot share a pass
 for c in FETCH_SIZE WRITE_SIZE; do
   B=12 REPS=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o x --output-format csv -- $PY tools/prof_attn.py > "$OUT/pmc_$c.log" 2>&1

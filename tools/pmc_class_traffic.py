@@ -88,14 +88,31 @@ def section(d: str, batch: int):
     return {"per_gpu_batch": batch, "kernels": kernels}
 
 
+def csrc_digest():
+    """sha256 over the kernel sources the numbers were measured on (bench.py marks the file stale when they differ from the
+    tree it runs in: the GPU box has no .git to ask)"""
+    import glob
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video_diffusion_speedrun_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 if __name__ == "__main__":
     commit = sys.argv[1]
     out = {"_comment": "HBM-side KiB per launch (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 --pmc passes of `bench.py --steps 1 "
                        "--warmup 1` resp. `--workload c5 --warmup 3`), averaged over every dispatch of a kernel class in the "
                        "profiled run; bytes = (2*fetch_kb + write_kb)*1024 (gfx950 FETCH_SIZE reports half of a 16-B/lane "
                        "streaming read). tools/collect_profiles.sh, tools/pmc_class_traffic.py.",
-           "commit": commit, "workloads": {}}
+           "commit": commit, "csrc_sha256": csrc_digest(), "workloads": {}}
     for arg in sys.argv[2:]:
         wl, d = arg.split(":", 1)
-        out["workloads"][wl] = section(d, int(os.environ.get("B", 12)))
+        batch = int(os.environ.get("B", 12))
+        if d.rsplit(":", 1)[-1].isdigit():  # name:dir:per-GPU batch (the B = 2 section "c3b_b2" of bench.py's small_batch)
+            d, b = d.rsplit(":", 1)
+            batch = int(b)
+        out["workloads"][wl] = section(d, batch)
     print(json.dumps(out, indent=1))
