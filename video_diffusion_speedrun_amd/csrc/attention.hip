@@ -1703,6 +1703,9 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
     if constexpr (HDP == 96 && HDQ == 80) ones_kv = p.kv_pad_ones == 1 && p.hd == 72;
     vdsprof::Scope ps(ones_kv ? VDS_PROF_ATTN_BWD_DKV : VDS_PROF_ATTN_BWD_DKV_PLAIN, s, 2.0 * prod, 2.0 * qb + 4.0 * kb);
     if constexpr (HDP == 96 && HDQ == 80) {
+      // (round 6 measured this kernel as an explicit MFMA / VALU ping-pong -- one 512-thread workgroup per CU, the two wave
+      // groups in alternating MFMA and VALU / LDS segments under s_barrier: bit-identical, +5 % slower; the kernel executes 77 %
+      // of what a bare MFMA loop reaches at the board's power limit.  profiles/r06/negative_attn_dkv_pingpong.log)
       if (ones_kv && (attn_variant() & 1))
         hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP>), dim3(grid), dim3(256), LDS_DKV, s, p);
       else if (ones_kv)
