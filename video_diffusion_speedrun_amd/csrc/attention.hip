@@ -1388,13 +1388,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(AttnP p) {
 // dP^T = V dO'^T with 16 key rows from LDS as A and 16 queries in registers as B; dQ^T += K^T dS^T with K^T read by
 // transposing reads and the stacked dS^T accumulators used in place as B.  Per 32 x 32 block: 34 MFMAs of 16 cycles
 // (544) against 16 of 32 (512) -- the contraction pads 72 -> 96 instead of 80 -- in exchange for the higher clock.
-// NQ: 16-query blocks per wave.  2 (three waves per SIMD) reads every K / V fragment for 2 MFMAs: at the full MFMA rate the
+// NQ = 2 16-query blocks per wave (three waves per SIMD) reads every K / V fragment for 2 MFMAs: at the full MFMA rate the
 // 12 waves of a CU would keep the LDS 100 % busy (136 LDS cycles per wave and 32-key sub-block against 544 MFMA cycles per
-// SIMD and wave) -- the kernel is LDS-bound.  3 (two waves per SIMD, experiment: VDS_ATTN_DQ_NQ=3) reads them for 3.
-template <int HDP, int NQ = 2>
-__global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void attn_bwd_dq16_kernel(AttnP p) {
+// SIMD and wave) -- the kernel is LDS-bound.
+// FOLD (round 6): the kernel is its own preprocess.  It holds the dO rows of its queries as fragments anyway; with the O
+// rows loaded beside them (once per workgroup: 18 KiB) every lane forms  -delta = -rowsum(dO o O)  of its query (24 products,
+// two cross-lane adds), writes -delta and lse * log2(e) to the workspace and the (hi, lo) pair of -lse2 into the pad of its
+// Q row -- what attn_delta_*_kernel did in a pass of its own over O and dO (6.5 ms per C3b step).  The host then runs this
+// kernel BEFORE the dK/dV kernel, which reads those statistics.
+template <int HDP, bool FOLD = false>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq16_kernel(AttnP p) {
   static_assert(HDP == 96, "head_dim 72 layout");
-  constexpr int KS = HDP / 32, NDB = 5, TILE = 64 * HDP * 2;
+  constexpr int KS = HDP / 32, NDB = 5, TILE = 64 * HDP * 2, NQ = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh, qt;
   if (!decode_block(p.n_rt, p.tail_last, p.B * p.H, bh, qt)) return;
@@ -1431,8 +1436,31 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void attn_bwd_dq16_kernel(Att
       dof[cb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rdo, off2, 0, 0));
     }
     const long srow = ((long)b * p.H + hh) * p.Lq + min(qrow, p.Lq - 1);
-    const float ndl = p.delta[srow];           // -delta of this lane's query
-    const float lse2 = p.delta[nrows + srow];  // lse * log2(e)
+    float ndl, lse2;
+    if constexpr (FOLD) {
+      const __amdgpu_buffer_rsrc_t ro = slice_rsrc(p.o + b * p.o_sb + hh * p.o_sh, p.o_sl, p.Lq, p.hd);
+      float acc = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int e = ks * 32 + 8 * g;
+        const unsigned off3 = e >= p.hd ? 0xfffffff0u : (unsigned)(((long)qrow * p.o_sl + e) * 2);
+        const bf16x8 of = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ro, off3, 0, 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_fmaf((float)of[j], (float)dof[cb][ks][j], acc);
+      }
+      acc += __shfl_xor(acc, 16);  // the four lanes l, l + 16, l + 32, l + 48 hold the column chunks of one query
+      acc += __shfl_xor(acc, 32);
+      ndl = -acc;
+      lse2 = p.lse[srow] * LOG2E;
+      if (g == 0 && qrow < p.Lq) {
+        p.delta[srow] = ndl;
+        p.delta[nrows + srow] = lse2;
+        if (p.kv_pad_ones == 1) annotate_q(p, b, hh, qrow, lse2);
+      }
+    } else {
+      ndl = p.delta[srow];           // -delta of this lane's query
+      lse2 = p.delta[nrows + srow];  // lse * log2(e)
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) { qf[cb][ks] = scale_frag(qf[cb][ks], c); retire(dof[cb][ks]); }
     if (g == 1) {  // ks = 2, g = 1: columns 72 .. 79 (K holds 1.0 at 72, 73; V at 72, 76)
@@ -1674,6 +1702,7 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv16_kernel<HDP>, LDS_DKV);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dkv16_kernel<HDP, false>, LDS_DKV);
     if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dq16_kernel<HDP>, LDS_DQ);
+    if constexpr (HDP == 96 && HDQ == 80) set_lds(attn_bwd_dq16_kernel<HDP, true>, LDS_DQ);
     once = true;
   }
   const long rows = (long)p.B * p.H * p.Lq;
@@ -1682,7 +1711,31 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
   // kernel 2 (dP, dQ).  The kernels EXECUTE 4 + 3 = 7 products (and head-dim padding on top).
   const double prod = 2.0 * p.B * p.H * (double)p.Lq * p.Lk * p.hd;
   const double qb = 2.0 * p.B * p.H * p.hd * (double)p.Lq, kb = 2.0 * p.B * p.H * p.hd * (double)p.Lk;
-  {
+  // the 16x16x32 dQ kernel of the ones-column path computes the statistics itself and runs first (attn_bwd_dq16_kernel, FOLD)
+  bool fold = false;
+  if constexpr (HDP == 96 && HDQ == 80) fold = p.kv_pad_ones && p.hd == 72 && (attn_variant() & 2) && vdscfg::geti(vdscfg::ATTN_DELTA_FOLD);
+  auto launch_dq = [&]() {
+    p.n_rt = cdiv(p.Lq, 128);
+    p.tail_last = tail_last_for(p.Lq, 128);
+    const int grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
+    bool ones = false;
+    if constexpr (HDP == 96 && HDQ == 80) ones = p.kv_pad_ones && p.hd == 72;
+    vdsprof::Scope ps(ones && p.kv_pad_ones == 1 ? VDS_PROF_ATTN_BWD_DQ : VDS_PROF_ATTN_BWD_DQ_PLAIN, s, 2.0 * prod,
+                      (fold ? 4.0 : 3.0) * qb + 2.0 * kb);
+    if constexpr (HDP == 96 && HDQ == 80) {
+      // (48 queries per wave -- every fragment read feeds 3 MFMAs, two waves per SIMD instead of three -- measured 2-6 %
+      // slower in round 5, removed in round 6; profiles/r05/attn_dq_three_blocks_per_wave.log)
+      if (fold)
+        hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP, true>), dim3(grid), dim3(256), LDS_DQ, s, p);
+      else if (ones && (attn_variant() & 2))
+        hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP>), dim3(grid), dim3(256), LDS_DQ, s, p);
+      else if (ones)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DQ, s, p);
+    }
+    if (!ones) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS_DQ, s, p);
+  };
+  if (fold) launch_dq();
+  else {
     vdsprof::Scope ps(VDS_PROF_ATTN_BWD_DELTA, s, 2.0 * rows * p.hd, 2.0 * qb);
     const bool tokmajor = p.o_sh == p.hd && p.do_sh == p.hd && p.o_sl == (long)p.H * p.hd && p.do_sl == p.o_sl &&
                           (p.o_sl & 7) == 0 && (p.o_sb & 7) == 0 && (p.do_sb & 7) == 0 && p.H * p.hd <= 1536 && p.H <= 64;
@@ -1745,23 +1798,7 @@ int run_bwd(AttnP p, hipStream_t s, size_t ws_floats) {
       }
     }
   }
-  p.n_rt = cdiv(p.Lq, 128);
-  p.tail_last = tail_last_for(p.Lq, 128);
-  grid = cdiv(p.B * p.H, 8) * 8 * p.n_rt;
-  {
-    bool ones = false;
-    if constexpr (HDP == 96 && HDQ == 80) ones = p.kv_pad_ones && p.hd == 72;
-    vdsprof::Scope ps(ones && p.kv_pad_ones == 1 ? VDS_PROF_ATTN_BWD_DQ : VDS_PROF_ATTN_BWD_DQ_PLAIN, s, 2.0 * prod, 3.0 * qb + 2.0 * kb);
-    if constexpr (HDP == 96 && HDQ == 80) {
-      // (48 queries per wave -- every fragment read feeds 3 MFMAs, two waves per SIMD instead of three -- measured 2-6 %
-      // slower in round 5, removed in round 6; profiles/r05/attn_dq_three_blocks_per_wave.log)
-      if (ones && (attn_variant() & 2))
-        hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP>), dim3(grid), dim3(256), LDS_DQ, s, p);
-      else if (ones)
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, true>), dim3(grid), dim3(256), LDS_DQ, s, p);
-    }
-    if (!ones) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, HDQ, false>), dim3(grid), dim3(256), LDS_DQ, s, p);
-  }
+  if (!fold) launch_dq();
   return hipGetLastError() == hipSuccess ? VDS_OK : VDS_ERR_LAUNCH;
 }
 

@@ -17,6 +17,7 @@ enum Knob {
   GEMM_MID_FACTOR,   // VDS_GEMM_MID_FACTOR: price of a round of 256 x 128 tiles in rounds of 256^2 tiles (default 1.3)
   // ---- attention (csrc/attention.hip, csrc/attention_fp8.hip)
   ATTN_MFMA16,       // VDS_ATTN_MFMA16: bit mask, which head-dim-72 kernels run on v_mfma_f32_16x16x32_bf16 (default 7)
+  ATTN_DELTA_FOLD,   // VDS_ATTN_DELTA_FOLD: the head-dim-72 dQ kernel computes -delta / lse2 itself and runs before dK/dV (default 1)
   ATTN_TAIL_LAST,    // VDS_ATTN_TAIL_LAST: the ragged tile of every head is scheduled after all full tiles (default 1)
   ATTN_FWD_WIDE,     // VDS_ATTN_FWD_WIDE: 64 queries per wave in the forward: 0 never | 1 always | 2 from 2048 queries (default)
   ATTN_WIDE_STORES,  // VDS_ATTN_WIDE_STORES: 16-byte stores of the 16x16 epilogues (default 1)

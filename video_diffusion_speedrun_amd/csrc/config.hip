@@ -19,6 +19,7 @@ const Def kDefs[N_KNOBS] = {
     {"gemm_mid_tn", "VDS_GEMM_MID_TN", 0.75},
     {"gemm_mid_factor", "VDS_GEMM_MID_FACTOR", 1.3},
     {"attn_mfma16", "VDS_ATTN_MFMA16", 7},
+    {"attn_delta_fold", "VDS_ATTN_DELTA_FOLD", 1},
     {"attn_tail_last", "VDS_ATTN_TAIL_LAST", 1},
     {"attn_fwd_wide", "VDS_ATTN_FWD_WIDE", 2},
     {"attn_wide_stores", "VDS_ATTN_WIDE_STORES", 1},
