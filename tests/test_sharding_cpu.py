@@ -20,8 +20,9 @@ CFG = dict(in_channels=16, patch_size=2, time_patch_size=2, hidden_size=128, dep
 CONSTS = ["patch_proj", "context_kv", "positional_embedding"]
 
 
-def make_model():
+def make_model(**over):
     from video_diffusion_speedrun_amd.model import DiT
+    CFG = dict(globals()["CFG"], **over)
     cfg = O.DiTConfig(**CFG)
     P = O.init_params(cfg, seed=7, randomize_zero_init=True, init_std_factor=1.0)
     m = DiT(**CFG)
@@ -317,3 +318,85 @@ def test_four_and_eight_rank_gloo_sharded_step(world, prefetch):
     reduce-scatter-averages at the world sizes the driver's scaling run uses (model.py:523-541), on gloo: every
     rank must end up with its slice of the single-process batch-mean gradient and AdamW update."""
     _run_two_ranks(_worker, prefetch, world=world)
+
+
+def _reshard_worker(rank, world, port, q, prefetch=1):
+    """the memory-bounded mode (`apply_fsdp(..., reshard_after_forward=True)`, reference model.py:525,541): ring of
+    parameter buffers, release after forward, re-gather in backward"""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(1 if world > 2 else 2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from video_diffusion_speedrun_amd.fsdp import ReshardRuntime, apply_fsdp
+        os.environ["VDS_AG_PREFETCH"] = str(prefetch)
+        m, cfg, P = make_model(depth=5)  # deeper than the ring: buffers are reused within a pass
+        m = apply_fsdp(m, torch.bfloat16, torch.float32, device="cpu", reshard_after_forward=True)
+        fs = m._fsdp
+        assert isinstance(fs, ReshardRuntime) and fs.n_slots == min(max(1, prefetch) + 2, cfg.depth)
+        assert all(g.full is None for g in m._groups[1:])  # no resident per-block copies
+        full, halves = _batches(world)
+        weights = {}
+        for step in range(2):  # the second pass finds the ring in the state the first one left
+            n0 = fs.n_all_gather
+            fs.pre_forward_root()
+            for gi, g in enumerate(m._groups):
+                if gi > 0:
+                    fs.pre_forward_block(gi - 1)
+                    held = [k for k in range(1, len(m._groups)) if fs.slot_of[k] is not None]
+                    assert gi in held and len(held) <= fs.n_slots and max(held) <= gi + max(1, prefetch), (gi, held)
+                for n in g.names:
+                    weights[n] = g.w(n).clone()
+                    assert torch.equal(weights[n], P[n].to(torch.bfloat16)), n
+                if gi > 0:
+                    fs.post_forward_block(gi - 1)
+                    assert (g.full is None) == (gi - 1 < cfg.depth - 1)  # every block but the last is released
+            fs.post_forward_root()
+            assert fs.n_all_gather - n0 == 1 + cfg.depth
+            grads, _ = _oracle_grads(cfg, weights, halves[rank])
+            for g in m._groups:
+                g.gfull.zero_()
+            fs.pre_backward_root()
+            for i in reversed(range(cfg.depth)):
+                fs.pre_backward_block(i)
+                g = m.block_group(i)
+                for n in g.names:  # gathered again: the same bf16 words
+                    assert torch.equal(g.w(n), weights[n]), n
+                    g.g(n).copy_(grads[n])
+                fs.post_backward_block(i)
+                assert g.full is None
+            for n in m.root_group.names:
+                m.root_group.g(n).copy_(grads[n])
+            fs.post_backward_root()
+            # forward: root + every block; backward: every block but the last again
+            assert fs.n_all_gather - n0 == 1 + cfg.depth + (cfg.depth - 1)
+            assert sorted(fs.free_slots) == list(range(fs.n_slots))
+        per_rank = [_oracle_grads(cfg, weights, h)[0] for h in halves]
+        gfull = {n: sum(gr[n] for gr in per_rank) / world for n in per_rank[0]}
+        for g in m._groups:
+            for n in g.names:
+                lo, hi = g.local_range(n)
+                g0 = g.rank * g.shard + lo - g.offsets[n]
+                ref = gfull[n].reshape(-1)[g0:g0 + (hi - lo)]
+                assert torch.allclose(g.params[n].grad, ref, rtol=1e-4, atol=1e-7), n
+        # a forward without a backward (sampling) leaves the last block gathered; the next forward starts clean
+        fs.pre_forward_root()
+        for i in range(cfg.depth):
+            fs.pre_forward_block(i)
+            fs.post_forward_block(i)
+        fs.pre_forward_root()
+        assert len(fs.free_slots) == fs.n_slots - min(max(1, prefetch), cfg.depth)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,prefetch", [(2, 1), (4, 2)], ids=["w2_window1", "w4_window2"])
+def test_reshard_after_forward_mode(world, prefetch):
+    """the reference's `reshard_after_forward` (model.py:525,541) as an optional memory-bounded mode of
+    the sharding runtime: block copies in a ring of prefetch + 2 buffers, released after their forward (all but the last
+    block's), gathered again in backward, same reduced gradients as the resident mode."""
+    _run_two_ranks(_reshard_worker, prefetch, world=world)

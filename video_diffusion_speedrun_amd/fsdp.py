@@ -10,9 +10,11 @@ MI355X-first re-design of the same contract:
     messages are what it wants.  The collectives are the kernel library's own (`vds_all_gather_bf16`,
     `vds_reduce_scatter_f32_avg`: csrc/comm.hip drives RCCL on a communicator created from a unique id that
     torch.distributed ships once at start-up; comm.py);
-  * 288 GB of HBM per GPU: the gathered bf16 copy of EVERY group (2.3 GB for DiT-XL) stays
+  * 288 GB of HBM per GPU: by default the gathered bf16 copy of EVERY group (2.3 GB for DiT-XL) stays
     resident from forward to backward, so the reference's backward re-all-gather
     (`reshard_after_forward`, model.py:525) is not needed at all -- all-gather traffic is halved;
+    `apply_fsdp(..., reshard_after_forward=True)` is the reference's memory-bounded behaviour (ReshardRuntime: the
+    blocks' copies live in a ring of prefetch + 2 buffers and are gathered again in backward);
   * the gathers of a step are issued in use order on a dedicated communication stream; the compute stream
     waits on the per-group event right before the first kernel that reads the group.  By default ALL of them
     are issued up-front (prefetch depth = everything: the links are busy for the first 11-78 ms of the step and
@@ -192,6 +194,116 @@ class ShardRuntime:
             g.publish_grads()
 
 
+class ReshardRuntime(ShardRuntime):
+    """`reshard_after_forward` of the reference's wrap (model.py:525,541: every block but the last frees its gathered
+    parameters after its forward and all-gathers them again in backward): the memory-bounded mode.  The gathered bf16
+    copies of the BLOCKS live in a ring of `prefetch + 2` buffers of the largest block's size instead of one resident
+    copy per block (DiT-XL: 3 x 80 MB instead of 2.3 GB; what pays for it is depth - 1 more all-gathers per step):
+
+      forward   block i's copy is gathered into a free buffer at most `prefetch` blocks ahead (default 1 = FSDP2) and
+                released when block i's forward kernels are queued -- the last block's stays, like the reference's;
+      backward  block i is gathered again (`prefetch` blocks ahead, downwards), released behind its reduce-scatter.
+
+    A buffer is handed to the next gather with an event recorded on the compute stream at release: the communication
+    stream waits for it, so a gather never overwrites weights a queued kernel still reads.  The root group (patch
+    embedding, time MLP, final layer: used at both ends of both passes) stays resident."""
+
+    def __init__(self, model, cast_fn, process_group=None):
+        super().__init__(model, cast_fn, process_group)
+        groups = model._groups
+        self.ahead = max(1, self.prefetch)
+        self.n_slots = min(self.ahead + 2, len(groups) - 1)
+        size = max(g.padded for g in groups[1:])
+        dev = groups[0].device
+        self.slots = [torch.zeros(size, dtype=torch.bfloat16, device=dev) for _ in range(self.n_slots)]
+        self.slot_free_ev = [None] * self.n_slots
+        self.free_slots = list(range(self.n_slots))
+        self.slot_of = [None] * len(groups)
+        for g in groups[1:]:  # the per-group gathered copies apply_fsdp allocated are not needed in this mode
+            g.full = None
+            g.gathered = False
+
+    def _gather_group(self, gi: int):
+        g: FlatGroup = self.model._groups[gi]
+        if gi == 0:
+            with self._on_comm():
+                g.gather(self.cast_fn, self.pg)
+                if self.cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(self.comm)
+                    self.gather_ev[0] = ev
+            self.n_all_gather += 1
+            return
+        if self.slot_of[gi] is not None:
+            return  # gathered (or in flight) already
+        if not self.free_slots:
+            raise RuntimeError("ReshardRuntime: no free parameter buffer (a block was not released)")
+        sl = self.free_slots.pop(0)
+        self.slot_of[gi] = sl
+        g.full = self.slots[sl][:g.padded]
+        with self._on_comm():
+            if self.cuda and self.slot_free_ev[sl] is not None:
+                self.comm.wait_event(self.slot_free_ev[sl])  # the kernels that read the previous tenant are done
+                self.slot_free_ev[sl] = None
+            g.gather(self.cast_fn, self.pg)
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(self.comm)
+                self.gather_ev[gi] = ev
+        self.n_all_gather += 1
+
+    def _release_group(self, gi: int):
+        sl = self.slot_of[gi]
+        if sl is None:
+            return
+        self._compute_waits(gi)  # (a gather nobody consumed: order the release behind it)
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.slot_free_ev[sl] = ev
+        self.slot_of[gi] = None
+        self.free_slots.append(sl)
+        g = self.model._groups[gi]
+        g.full = None
+        g.gathered = False
+
+    # ---- forward --------------------------------------------------------------------------
+    def pre_forward_root(self):
+        self._comm_waits_compute()  # the optimizer step that wrote master / shadow is done
+        n = len(self.model._groups)
+        for gi in range(1, n):  # a forward without a backward (sampling, evaluation) left its last block gathered
+            self._release_group(gi)
+        self._gather_group(0)
+        for gi in range(1, min(n, 1 + self.ahead)):
+            self._gather_group(gi)
+        self._compute_waits(0)
+
+    def pre_forward_block(self, i: int):
+        n = len(self.model._groups)
+        for gi in range(1 + i, min(n, 1 + i + 1 + self.ahead)):
+            self._gather_group(gi)
+        self._compute_waits(1 + i)
+
+    def post_forward_block(self, i: int):
+        if i < len(self.model._groups) - 2:  # (model.py:525: the last block is not resharded after forward)
+            self._release_group(1 + i)
+
+    # ---- backward -------------------------------------------------------------------------
+    def pre_backward_root(self):
+        for gi in range(len(self.model._groups)):
+            if gi == 0 or self.slot_of[gi] is not None:
+                self._compute_waits(gi)
+
+    def pre_backward_block(self, i: int):
+        for gi in range(1 + i, max(0, 1 + i - 1 - self.ahead), -1):
+            self._gather_group(gi)
+        self._compute_waits(1 + i)
+
+    def post_backward_block(self, i: int):
+        self._reduce(1 + i)
+        self._release_group(1 + i)
+
+
 class _Null:
     def __enter__(self):
         return self
@@ -201,14 +313,18 @@ class _Null:
 
 
 def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32, process_group=None,
-               device=None, cast_fn=None, force_runtime=False, world_rank=None):
+               device=None, cast_fn=None, force_runtime=False, world_rank=None, reshard_after_forward=None):
     """Shard `dit_model` over the ranks of `process_group` (default: the world) and return it
     -- the same object, still callable, still exposing get_mup_setup / named_parameters
     (model.py:512-542).  After this call every nn.Parameter is this rank's 1-D fp32 piece of
     its tensor (possibly empty), which is what the element-wise optimizer consumes.
 
     param_dtype / reduce_dtype: the reference passes bf16 / fp32 (train.py:323-325); those
-    are the only values the kernels implement."""
+    are the only values the kernels implement.
+
+    reshard_after_forward: False (default; also VDS_FSDP_RESHARD unset / 0) keeps every group's gathered bf16 copy
+    resident from forward to backward (2.3 GB for DiT-XL: no re-gather in backward); True (VDS_FSDP_RESHARD=1) is the
+    reference's memory-bounded behaviour (model.py:525,541) -- see ReshardRuntime."""
     if param_dtype != torch.bfloat16 or reduce_dtype != torch.float32:
         raise ValueError("apply_fsdp: the HIP path implements param_dtype=bf16, reduce_dtype=fp32 only")
     if world_rank is not None:
@@ -253,5 +369,8 @@ def apply_fsdp(dit_model, param_dtype=torch.bfloat16, reduce_dtype=torch.float32
         if device.type == "cuda" and world_rank is None and dist.is_initialized():
             from . import comm
             comm.ensure(process_group)  # the library's own RCCL communicator (vds_comm_*); collective call
-        dit_model._fsdp = ShardRuntime(dit_model, cast_fn, process_group)
+        if reshard_after_forward is None:
+            reshard_after_forward = os.environ.get("VDS_FSDP_RESHARD", "0") == "1"
+        rt = ReshardRuntime if (reshard_after_forward and len(groups) > 2) else ShardRuntime
+        dit_model._fsdp = rt(dit_model, cast_fn, process_group)
     return dit_model

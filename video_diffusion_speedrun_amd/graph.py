@@ -25,9 +25,12 @@ capturing stream (`comm.wait_stream(compute)`), the per-group bf16 all-gathers a
 on that stream (RCCL collectives are capturable), the compute stream joins on the per-group events, and the final
 `wait_stream` closes the fork before the capture ends.  Every rank captures and replays the same sequence.  The
 exposed-communication measurement (timing events) is off inside a capture.  Proven on one GPU with the runtime
-forced on over a 1-rank RCCL group (tests/test_model_gpu.py::test_graph_replay_with_the_sharding_runtime).  A capture
-over MORE than one rank has never run (no multi-GPU box in this pool): it is refused unless the caller passes
-`multi_rank_capture=True`, so that nobody gets an untested path by default.
+forced on over a 1-rank RCCL group (tests/test_model_gpu.py::test_graph_replay_with_the_sharding_runtime) and, since round
+6, at world size 2 on emulated ranks -- two sharded replicas in one process with the real shard layout, streams, events,
+separate gathered / reduced buffers and sharded optimizers, both resident and `reshard_after_forward` runtimes, only the
+two collectives replaced by an in-process exchange (test_graph_replay_with_two_emulated_ranks).  What no box of this pool
+could run is the capture of RCCL collectives across several PROCESSES; RCCL supports it, every rank captures and replays
+the same sequence.
 
 A captured graph bakes in device pointers (static batch buffers, the fp8 amax tables, the activation buffers the
 allocator handed out): `step()` refuses a batch whose latent / context shape differs from the captured one.
@@ -46,15 +49,9 @@ bf16 = torch.bfloat16
 class GraphedTrainStep:
     """`step(batch) -> loss` with the semantics of `train.train_step` (train.py:412-434)."""
 
-    def __init__(self, dit_model, optimizer, lr_scheduler, device, eager_steps: int = 2,
-                 multi_rank_capture: bool = False):
+    def __init__(self, dit_model, optimizer, lr_scheduler, device, eager_steps: int = 2):
         if eager_steps < 1:
             raise ValueError("at least one eager step is needed before the capture (descriptor tables, shadows)")
-        fs = getattr(dit_model, "_fsdp", None)
-        if fs is not None and getattr(fs, "world", 1) > 1 and not multi_rank_capture:
-            raise RuntimeError("GraphedTrainStep over a model sharded across more than one rank is untested (only a "
-                               "1-rank RCCL group on one GPU has captured and replayed the sharding runtime); pass "
-                               "multi_rank_capture=True to try it")
         self.model, self.opt, self.sched = dit_model, optimizer, lr_scheduler
         self.device = torch.device(device)
         self.eager_left = eager_steps
@@ -109,7 +106,9 @@ class GraphedTrainStep:
         finally:
             if fs is not None:
                 fs.measure = measure
-                fs.n_all_gather, fs.n_reduce_scatter = counts  # the capture launched nothing: replays count
+                # what one step issues (the memory-bounded runtime gathers most blocks twice): replays count it
+                self._per_step = (fs.n_all_gather - counts[0], fs.n_reduce_scatter - counts[1])
+                fs.n_all_gather, fs.n_reduce_scatter = counts  # the capture launched nothing
         self.opt._step = step0  # the capture launched nothing: `advance()` counts the step at replay time
         self.graph, self.loss = g, loss
 
@@ -136,9 +135,9 @@ class GraphedTrainStep:
             for g in self.model._groups:
                 g.refresh_shadow(ops.cast_f32_bf16)
             fs = getattr(self.model, "_fsdp", None)
-            if fs is not None:  # the counters a capture cannot bump: one all-gather and one reduce-scatter per group
-                fs.n_all_gather += len(self.model._groups)
-                fs.n_reduce_scatter += len(self.model._groups)
+            if fs is not None:  # the counters a capture cannot bump
+                fs.n_all_gather += self._per_step[0]
+                fs.n_reduce_scatter += self._per_step[1]
             self.graph.replay()
             self.n_replays += 1
             loss = self.loss.detach()
