@@ -42,6 +42,7 @@ _CROSS_ONES = os.environ.get("VDS_CROSS_ONES", "1") != "0"  # head_dim 72: cross
 # residual-V: d v_0 = sum over the mixed blocks of (1 - lambda_i) dv_i, summed in ONE pass before block 0's RoPE backward
 # (ops.dv0_reduce) instead of an fp32 read-modify-write of the accumulator in every block (0: the per-block form)
 _DV0_DEFER = os.environ.get("VDS_DV0_DEFER", "1") != "0"
+_DV0_CHUNK = max(1, int(os.environ.get("VDS_DV0_CHUNK", "9")))  # dv tensors kept alive between two reductions
 
 
 bf16, f32 = torch.bfloat16, torch.float32
@@ -669,9 +670,13 @@ class DiTBlock(nn.Module):
         defer = getattr(sv, "dv_terms", None)  # DiT.backward: [(dv, lambda)] of the mixed blocks, summed at block 0
         mix_mode = (2 if defer is not None else 1) if bs.mix else 0
         if mix_mode == 2:
-            defer.append((dv, W("lambda_param")))  # (keeps dv alive until block 0)
-        if first and dv0 is not None and defer:
-            ops.dv0_reduce([t for t, _ in defer], [l for _, l in defer], dv0, B, H, L, hd, hdp)
+            defer.append((dv, W("lambda_param")))  # (keeps dv alive until the next reduction)
+        # summed every _DV0_CHUNK blocks (and at block 0): at most that many dv tensors stay alive (DiT-XL, B = 12: 9 x 303 MB
+        # instead of 27 x 303 MB = 8 GB), for one more read-modify-write of the fp32 accumulator per chunk
+        if dv0 is not None and defer and (first or len(defer) >= _DV0_CHUNK):
+            ops.dv0_reduce([t for t, _ in defer], [l for _, l in defer], dv0, B, H, L, hd, hdp,
+                           accumulate=getattr(sv, "dv0_started", False))
+            sv.dv0_started = True
             defer.clear()
         rope_args = (dq, dk, dv, sv.cos, sv.sin, bs.qkv if bs.mix else None, sv.v0 if bs.mix else None,
                      W("lambda_param") if bs.mix else None, dv0 if bs.mix else (dv0 if first else None),
