@@ -226,7 +226,10 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_q4_kernel(const bf16_t* x
 // compiled out when there is no weight (the reference's default), which keeps the kernel at
 // >= 4 waves per SIMD -- it is HBM-bound and needs the loads in flight.
 template <int NC, bool HAS_W>
-__global__ __launch_bounds__(256, ((NC <= 3 && !HAS_W) ? 3 : 2)) void rmsnorm_mod_bwd_kernel(const bf16_t* dy, long lddy, const bf16_t* x, long ldx,
+// (round 6: at D = 1152 (NC = 3) three waves per SIMD spilled 20 registers into the row loop; two waves, unspilled, run
+// 3-4 % faster: 185 -> 180 us with a residual gradient, 150 -> 144 us without, tools/bench_row_kernels.py.  Requesting
+// the next row's streams before working on the current one needs 72 more registers and spills again: measured, not kept.)
+__global__ __launch_bounds__(256, ((NC <= 2 && !HAS_W) ? 3 : 2)) void rmsnorm_mod_bwd_kernel(const bf16_t* dy, long lddy, const bf16_t* x, long ldx,
                                                               const bf16_t* w, const float* mod, long ldmod,
                                                               int shift_col, int scale_col, const float* rstd,
                                                               const bf16_t* dres, long lddres, bf16_t* dx, long lddx,
