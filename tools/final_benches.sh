@@ -1,6 +1,6 @@
 #!/bin/bash
-# one bench line per BASELINE workload on one box (copied to profiles/r04/final_<workload>_bench.log)
-O=gpurun_out/r04final
+# one bench line per BASELINE workload on one box (copied to profiles/<round>/final_<workload>_bench.log)
+O=gpurun_out/${1:-r06}final
 mkdir -p $O
 show() { python -c "
 import json,sys
@@ -18,9 +18,9 @@ for w in c5 c2 c3a c4 c1; do
   python bench.py --workload $w --steps 8 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/final_${w}_bench.log; show final_${w}_bench
 done
 python bench.py --workload c1 --graph --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/final_c1_graph_bench.log; show final_c1_graph_bench
-VDS_FP8_TN=0 python bench.py --workload c5 --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/c5_with_transposed_copies_bench.log; show c5_with_transposed_copies_bench
 python bench.py --force-shard-runtime --steps 6 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' > $O/final_c3b_shard_runtime_w1_bench.log; show final_c3b_shard_runtime_w1_bench
-VDS_AG_PREFETCH=2 python bench.py --force-shard-runtime --steps 6 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' > $O/c3b_shard_runtime_w1_prefetch2_bench.log; show c3b_shard_runtime_w1_prefetch2_bench
+VDS_FSDP_RESHARD=1 python bench.py --force-shard-runtime --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-small-batch 2>/dev/null | grep '^{' > $O/c3b_shard_runtime_w1_reshard_bench.log; show c3b_shard_runtime_w1_reshard_bench
+python bench.py --deterministic --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-small-batch 2>/dev/null | grep '^{' > $O/c3b_deterministic_bench.log; show c3b_deterministic_bench
 python tools/bench_sampler.py > $O/sampler.log 2>&1; tail -3 $O/sampler.log
 for b in 1 2 4; do
   python bench.py --batch $b --steps 8 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' > $O/c3b_b${b}_bench.log; show c3b_b${b}_bench
