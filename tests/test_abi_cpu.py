@@ -132,3 +132,30 @@ def test_schedule_and_wgrad_split_helpers():
     assert _wgrad_split(324, 16, 512) == 1          # short contraction: never split below 8 K tiles
     s = _wgrad_split(81, 513, 512)
     assert 2 <= s <= 16 and 81 * s <= 1024
+
+
+def test_knob_table_and_deterministic_switch(lib):
+    """round 6: the library's tuning knobs are ONE table (csrc/config.h), filled from the environment when the library is
+    loaded and changed only through the C ABI; the deterministic mode needs its caller-allocated workspace (host-side
+    argument checks only: nothing is launched)."""
+    import math
+    import re
+    assert lib.vds_knob_get(b"gemm_narrow") == 1.0 and lib.vds_knob_get(b"gemm_group_m") == 4.0
+    assert lib.vds_knob_get(b"attn_mfma16") == 7.0 and lib.vds_knob_get(b"deterministic") == 0.0
+    assert math.isnan(lib.vds_knob_get(b"no_such_knob")) and lib.vds_knob_set(b"no_such_knob", 1.0) == -1
+    assert lib.vds_knob_set(b"gemm_narrow", 0.0) == 0 and lib.vds_knob_get(b"gemm_narrow") == 0.0
+    assert lib.vds_knob_set(b"gemm_narrow", 1.0) == 0
+    assert lib.vds_knob_set(b"deterministic", 1.0) == -1  # only with its workspace: vds_set_deterministic
+    assert lib.vds_set_deterministic(1, None, 0) == -1 and lib.vds_set_deterministic(2, None, 0) == -1
+    assert lib.vds_set_deterministic(0, None, 0) == 0 and lib.vds_knob_get(b"deterministic") == 0.0
+    assert lib.vds_flow_loss_workspace_floats(4, 1 << 20) == 4 * 256 and lib.vds_flow_loss_workspace_floats(3, 100) == 3
+    # every knob of config.h is in the table, and no kernel file reads the environment
+    csrc = os.path.join(REPO, "video_diffusion_speedrun_amd", "csrc")
+    enum = re.search(r"enum Knob \{(.*?)N_KNOBS", open(os.path.join(csrc, "config.h")).read(), re.S).group(1)
+    names = re.findall(r"^\s*([A-Z0-9_]+),", enum, re.M)
+    assert len(names) >= 20
+    for n in names:
+        assert not math.isnan(lib.vds_knob_get(n.lower().encode())), n
+    for f in os.listdir(csrc):
+        if f.endswith(".hip") and f != "config.hip":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f

@@ -1,7 +1,7 @@
-"""Same-box A/B of a per-call GEMM knob of the library (an environment variable it reads per call: 0 = off, 1 = on) at the
-DiT-XL shapes with the fused epilogues the model uses, bf16 and fp8.  Candidates run round-robin, median over the rounds.
-    B=12 python tools/bench_gemm_narrow.py                     # VDS_GEMM_NARROW: 256 x 128 body for a narrow last tile column
-    B=2 KNOB=VDS_GEMM_SK python tools/bench_gemm_narrow.py     # stream-K launches of the 256^2 kernel (round 5)"""
+"""Same-process A/B of a GEMM knob of the library (csrc/config.h; set through vds_knob_set: 0 = off, 1 = on) at the DiT-XL
+shapes with the fused epilogues the model uses, bf16 and fp8.  Candidates run round-robin, median over the rounds.
+    B=12 python tools/bench_gemm_narrow.py                     # gemm_narrow: 256 x 128 body for a narrow last tile column
+    B=12 KNOB=gemm_tn_joint python tools/bench_gemm_narrow.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -35,12 +35,12 @@ def ab(fns):
     return {k: sorted(v)[len(v) // 2] for k, v in times.items()}
 
 
-KNOB = os.environ.get("KNOB", "VDS_GEMM_NARROW")
+KNOB = os.environ.get("KNOB", "gemm_narrow")
 
 
 def with_env(val, fn):
     def run():
-        os.environ[KNOB] = val
+        ops.knob_set(KNOB, float(val))
         fn()
     return run
 

@@ -216,7 +216,7 @@ __device__ __forceinline__ unsigned cvt4_fp8(int fmt, float a, float b, float c,
 // The aux operand of a fused epilogue (GATE_RES: the residual stream, DGELU: the saved pre-activation) is requested
 // for all 8 row groups of the sub-tile BEFORE the accumulators are staged through LDS, so that the 8 loads are in
 // flight together and under the staging instead of one exposed HBM round trip per row group behind the stores.
-// WC: columns of the staged sub-tile that exist (64; 48 in the 256 x 192 tiling, whose lanes c8 >= 6 idle)
+// WC: columns of the staged sub-tile that exist (64; 32 in the narrow last tile column, whose lanes c8 >= 4 idle)
 // NIT: row groups of 8 rows per staged sub-tile (8: 64 rows; 4: the 32-row steps of the compact staging, see gemm_tile)
 template <int EPI, int WC = 64, int NIT = 8>
 __device__ __forceinline__ void epilogue_prefetch(const GemmP& p, int row0, int col0, int lane, u32x4 (&auxr)[NIT]) {
@@ -382,7 +382,7 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, const float* stg, 
                                               float& e_max) {
   const int c8 = lane & 7, rin = lane >> 3;
   if constexpr (WC < 64) {
-    if (c8 * 8 >= WC) {  // 256 x 192 tiling: the wave's sub-tile is 48 columns wide, lanes of chunks 6, 7 have no columns
+    if (c8 * 8 >= WC) {  // narrow last tile column: the wave's sub-tile is 32 columns wide, lanes of chunks 4 .. 7 have no columns
       if constexpr (EQ) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) ew[it] = u32x2{0u, 0u};
