@@ -362,13 +362,21 @@ def test_deterministic_mode_gives_bit_identical_gradients(vds, shape, request):
             assert rel(g1[k], g_atomic[k]) <= (5e-3 if k.endswith("lambda_param") else 2e-5), (k, rel(g1[k], g_atomic[k]))
 
 
-def test_shard_runtime_on_one_gpu_matches_unsharded(vds):
+@pytest.mark.parametrize("det", [False, True], ids=["atomics", "deterministic"])
+def test_shard_runtime_on_one_gpu_matches_unsharded(vds, det, monkeypatch, request):
     """the stream / event / RCCL choreography of fsdp.ShardRuntime, forced on at world_size 1
     (1-rank nccl group): three optimizer steps give the same losses and parameters as the
     unsharded model (same kernels, same order; the collectives are exact copies at W=1; the only
-    difference allowed is the summation order of the fp32 atomic accumulations)."""
+    difference allowed is the summation order of the fp32 atomic accumulations) -- and in deterministic mode
+    (fixed-order reductions; the unsharded model on the per-block adaLN form the sharded one uses, so that both run the
+    same kernel sequence) THE SAME BITS: resident copies, the reshard_after_forward ring and no sharding at all are then
+    indistinguishable in every loss and every parameter."""
     import torch.distributed as dist
     from video_diffusion_speedrun_amd.fsdp import apply_fsdp
+    if det:
+        monkeypatch.setenv("VDS_ADALN_BATCH", "0")
+        vds["ops"].set_deterministic(True, 256 << 20)
+        request.addfinalizer(lambda: vds["ops"].set_deterministic(False))
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -403,6 +411,11 @@ def test_shard_runtime_on_one_gpu_matches_unsharded(vds):
         # fp32 atomic accumulation order differs from run to run; AdamW's m / sqrt(v) amplifies a 1e-7 gradient
         # difference to ~1e-5 of a parameter tensor per step
         for l1, p1 in results[1:]:
+            if det:
+                assert l1 == l0, (l0, l1)
+                for k in p0:
+                    assert torch.equal(p1[k], p0[k]), k
+                continue
             assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
             for k in p0:
                 assert rel(p1[k], p0[k]) <= 2e-4, (k, rel(p1[k], p0[k]))
