@@ -664,7 +664,7 @@ def test_graph_replay_with_the_sharding_runtime(vds):
 
 
 @pytest.mark.parametrize("reshard", [False, True], ids=["resident", "reshard_after_forward"])
-def test_graph_replay_with_two_emulated_ranks(vds, monkeypatch, reshard):
+def test_graph_replay_with_two_emulated_ranks(vds, monkeypatch, reshard, parity_log):
     """VERDICT r5 item 8 / missing 3 (the reference compiles the FSDP-wrapped model, train.py:323-329): whole-step capture and
     replay of a model sharded over MORE than one rank.  Two replicas of one model in this process, each rank 0 / 1 of a
     world of 2 with the real shard layout, communication stream, per-group events, separate gathered and reduced buffers
@@ -735,14 +735,18 @@ def test_graph_replay_with_two_emulated_ranks(vds, monkeypatch, reshard):
     n_ag = (1 + cfg.depth + (cfg.depth - 1 if reshard else 0)) * len(batches)
     assert all(m._fsdp.n_all_gather == n_ag and m._fsdp.n_reduce_scatter == (1 + cfg.depth) * len(batches) for m in reps)
     for r in range(W):
-        assert all(abs(a - b_) <= 1e-4 * abs(a) for a, b_ in zip(l_ref, l_rep[r])), (r, l_ref, l_rep[r])
+        assert all(abs(a - b_) <= 1e-6 * abs(a) for a, b_ in zip(l_ref, l_rep[r])), (r, l_ref, l_rep[r])
     want = ref.full_state_dict()
+    worst = 0.0
     for gi, grp0 in enumerate(reps[0]._groups):
         flat = torch.cat([m._groups[gi].master for m in reps])
         for n in grp0.names:
             o0 = grp0.offsets[n]
             got = flat[o0:o0 + want[n].numel()].view(want[n].shape)
-            assert rel(got, want[n]) <= 3e-4, (n, rel(got, want[n]))
+            worst = max(worst, rel(got, want[n]))
+            assert rel(got, want[n]) <= 1e-6, (n, rel(got, want[n]))  # (measured 2e-8: profiles/r06/parity_report.jsonl)
+    parity_log("graph_replay_two_emulated_ranks", reshard=reshard, worst_param_rel=worst,
+               worst_loss_rel=max(abs(a - b_) / abs(a) for r in range(W) for a, b_ in zip(l_ref, l_rep[r])))
 
 
 def test_graph_replay_with_fp8_keeps_rolling_the_amax_history(vds):
