@@ -32,6 +32,8 @@ def _track(name, c, e):
 def _worst_grad_report(parity_log):
     yield
     parity_log("test_model_gpu.worst_gradient", worst_cos=_WORST["cos"], worst_rel=_WORST["rel"])
+    for name, (wl, wp) in _MARGINS.items():
+        parity_log("test_model_gpu.run_to_run." + name, worst_loss_rel=wl, worst_param_rel=wp)
 
 
 @pytest.fixture(scope="module")
@@ -46,6 +48,18 @@ def vds():
 def rel(a, b):
     a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
     return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+_MARGINS = {}
+
+
+def _note(name, loss_pairs, p1, p0):
+    """worst relative loss / parameter difference of a run-to-run comparison, kept for the parity report"""
+    wl = max((abs(a - b) / abs(a) for a, b in loss_pairs), default=0.0)
+    wp = max((rel(p1[k], p0[k]) for k in p0), default=0.0)
+    cur = _MARGINS.get(name, (0.0, 0.0))
+    _MARGINS[name] = (max(cur[0], wl), max(cur[1], wp))
+    return wl, wp
 
 
 def cosine(a, b):
@@ -408,17 +422,18 @@ def test_shard_runtime_on_one_gpu_matches_unsharded(vds, det, monkeypatch, reque
                 assert m._fsdp.n_all_gather == 3 * (1 + cfg.depth + extra) and m._fsdp.n_reduce_scatter == 3 * (1 + cfg.depth)
             results.append((losses, {k: v.clone() for k, v in m.full_state_dict().items()}))
         (l0, p0) = results[0]
-        # fp32 atomic accumulation order differs from run to run; AdamW's m / sqrt(v) amplifies a 1e-7 gradient
-        # difference to ~1e-5 of a parameter tensor per step
+        # fp32 atomic accumulation order differs from run to run
         for l1, p1 in results[1:]:
             if det:
                 assert l1 == l0, (l0, l1)
                 for k in p0:
                     assert torch.equal(p1[k], p0[k]), k
                 continue
-            assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+            _note("shard_runtime_w1", zip(l0, l1), p1, p0)
+            # (measured over nine runs on three boxes: losses equal, parameters <= 8.5e-8: profiles/r06/parity_report.jsonl)
+            assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
             for k in p0:
-                assert rel(p1[k], p0[k]) <= 2e-4, (k, rel(p1[k], p0[k]))
+                assert rel(p1[k], p0[k]) <= 2e-6, (k, rel(p1[k], p0[k]))
         from video_diffusion_speedrun_amd import comm
         assert comm.info()["active"] and comm.info()["world"] == 1  # the collectives went through vds_comm_*
     finally:
@@ -500,9 +515,10 @@ def test_checkpoint_resume_is_exact(vds, tmp_path, det, request):
         for k in ref:
             assert torch.equal(got[k], ref[k]), k
         return
-    assert abs(l3 - l3b) <= 1e-5 * abs(l3), (l3, l3b)
+    _note("checkpoint_resume", [(l3, l3b)], got, ref)
+    assert abs(l3 - l3b) <= 1e-6 * abs(l3), (l3, l3b)
     for k in ref:  # the restored state is bit-exact; the step after it differs by the fp32 atomic summation order only
-        assert rel(got[k], ref[k]) <= 1e-4, k
+        assert rel(got[k], ref[k]) <= 5e-7, k  # (measured 5e-9 .. 6e-9)
 
 
 def test_device_prefetcher_feeds_the_train_step(vds):
@@ -611,6 +627,7 @@ def test_graph_replay_matches_eager_steps(vds):
         results.append((losses, {k: v.clone() for k, v in m.full_state_dict().items()}))
     (l0, p0), (l1, p1) = results
     assert len(set(l0)) == 6  # different batches / draws every step
+    _note("graph_replay", zip(l0, l1), p1, p0)
     assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
     for k in p0:
         assert rel(p1[k], p0[k]) <= 2e-4, (k, rel(p1[k], p0[k]))
@@ -658,6 +675,7 @@ def test_graph_replay_with_the_sharding_runtime(vds):
         torch.cuda.synchronize()
         results.append((losses, {k: v.clone() for k, v in m.full_state_dict().items()}))
     (l0, p0), (l1, p1) = results
+    _note("graph_replay_shard_runtime", zip(l0, l1), p1, p0)
     assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
     for k in p0:
         assert rel(p1[k], p0[k]) <= 2e-4, (k, rel(p1[k], p0[k]))
