@@ -623,6 +623,7 @@ def main():
         comm_info = {"backend": "vds_comm (RCCL from csrc/comm.hip)" if ci["active"] else "torch.distributed nccl",
                      "communicator_world": ci["world"] if ci["active"] else dist.get_world_size(),
                      "rccl_version": ci["rccl_version"], "reduce_scatter_schedule": ci["schedule"],
+                     "runtime": type(fs).__name__,  # ShardRuntime (resident copies) | ReshardRuntime (reshard_after_forward)
                      "all_gathers_per_step": (fs.n_all_gather - n_ag0) / args.steps,
                      "reduce_scatters_per_step": (fs.n_reduce_scatter - n_rs0) / args.steps,
                      "all_gather_bytes_per_step": 2 * gbytes, "reduce_scatter_bytes_per_step": 4 * gbytes,

@@ -23,17 +23,20 @@ def test_first_multigpu_matrix_is_what_bench_py_accepts():
     runs = fm.matrix([1, 2, 4, 8])
     steps = [r for r in runs if r["kind"] == "step"]
     comm = [r for r in runs if r["kind"] == "comm_only"]
-    # N = 1: plain + through the sharding runtime; N > 1: 2 schedules x 2 all-gather windows; comm-only: N > 1 x 2 schedules
-    assert len(steps) == 2 + 3 * 4 and len(comm) == 3 * 2
-    assert {(r["n"], r["env"].get("VDS_COMM_SCHEDULE"), r["env"].get("VDS_AG_PREFETCH")) for r in steps if r["n"] > 1} == \
+    # N = 1: plain + through the sharding runtime; N > 1: 2 schedules x 2 all-gather windows + the reshard_after_forward
+    # mode; comm-only: N > 1 x 2 schedules
+    assert len(steps) == 2 + 3 * 5 and len(comm) == 3 * 2
+    plain = [r for r in steps if r["n"] > 1 and "VDS_FSDP_RESHARD" not in r["env"]]
+    assert {(r["n"], r["env"].get("VDS_COMM_SCHEDULE"), r["env"].get("VDS_AG_PREFETCH")) for r in plain} == \
         {(n, s, p) for n in (2, 4, 8) for s in ("rccl", "allpairs") for p in ("0", "2")}
+    assert sorted(r["n"] for r in steps if r["env"].get("VDS_FSDP_RESHARD") == "1") == [2, 4, 8]
     parser = bench.build_parser()
     for r in runs:
         assert r["argv"][0] == "bench.py"
         a = parser.parse_args(r["argv"][1:])  # raises SystemExit on a flag bench.py does not know
         assert a.gpus == r["n"] and a.workload == "c3b"
         assert a.comm_only == (r["kind"] == "comm_only")
-        assert set(r["env"]) <= {"VDS_COMM_SCHEDULE", "VDS_AG_PREFETCH"}
+        assert set(r["env"]) <= {"VDS_COMM_SCHEDULE", "VDS_AG_PREFETCH", "VDS_FSDP_RESHARD"}
         if r["kind"] == "step":  # the scaling points must be the headline measurement alone
             assert a.no_cpu_baseline and a.no_secondary and a.no_small_batch
     assert sum("--force-shard-runtime" in r["argv"] for r in runs) == 1

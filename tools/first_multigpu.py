@@ -6,7 +6,8 @@ reference, train.py:323-325, run_debug.sh:12):
     bash tools/first_multigpu.sh --gpus 1,2 --steps 10
     python tools/first_multigpu.py --dry-run     # print the command matrix as JSON lines, run nothing
 
-Runs  bench.py --gpus N  for N in {1,2,4,8} x VDS_COMM_SCHEDULE in {rccl, allpairs} x VDS_AG_PREFETCH in {0, 2}
+Runs  bench.py --gpus N  for N in {1,2,4,8} x VDS_COMM_SCHEDULE in {rccl, allpairs} x VDS_AG_PREFETCH in {0, 2}, plus one
+run per N in the reshard_after_forward mode (VDS_FSDP_RESHARD=1, window 1)
 (N = 1: one plain run + one through the sharding runtime, the knobs do not apply), then  bench.py --comm-only  per N > 1
 and schedule, and prints one table: samples/s, scaling efficiency against the N = 1 line, the step time of the slowest
 rank, the exposed communication per step (compute-stream stalls on the communication stream, max over ranks), the
@@ -37,6 +38,10 @@ def matrix(gpus, schedules=("rccl", "allpairs"), prefetch=(0, 2), steps=8, warmu
         for sch, pf in itertools.product(schedules, prefetch):
             runs.append({"kind": "step", "n": n, "env": {"VDS_COMM_SCHEDULE": sch, "VDS_AG_PREFETCH": str(pf)},
                          "argv": base + ["--gpus", str(n)]})
+        # the reference's memory-bounded behaviour (reshard_after_forward, model.py:525,541): ring of parameter buffers,
+        # depth - 1 more all-gathers per step (fsdp.ReshardRuntime; round 6)
+        runs.append({"kind": "step", "n": n, "env": {"VDS_COMM_SCHEDULE": schedules[0], "VDS_AG_PREFETCH": "1",
+                                                     "VDS_FSDP_RESHARD": "1"}, "argv": base + ["--gpus", str(n)]})
     for n in gpus:
         if n == 1:
             continue
@@ -71,6 +76,8 @@ def table(results):
         pf = run["env"].get("VDS_AG_PREFETCH", "-")
         if "--force-shard-runtime" in run["argv"]:
             sch = "runtime@1"
+        if run["env"].get("VDS_FSDP_RESHARD") == "1":
+            sch = "reshard"
         if not r:
             rows.append(f"{run['n']:>2} {sch:>9} {pf:>8} {'FAILED':>10}")
             continue
