@@ -502,6 +502,16 @@ def comm_only(model, args, world, rank, device, desc, B):
         dist.destroy_process_group()
 
 
+def _flush_c_stdio():
+    """RCCL prints its version banner through C stdio when a communicator is created; with stdout on a pipe that text sits in
+    the C buffer until exit and would land BEHIND the JSON line.  Flushing it first keeps the JSON line last on stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -693,6 +703,7 @@ def main():
                 out["cpu_baseline"]["c2_measured"] = cpu_baseline_c2()
             except Exception as e:  # noqa: BLE001
                 out.setdefault("cpu_baseline", {})["error"] = f"{type(e).__name__}: {e}"[:500]
+        _flush_c_stdio()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
