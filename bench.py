@@ -486,6 +486,7 @@ def comm_only(model, args, world, rank, device, desc, B):
         allr = [mine]
     ci = comm.info()
     if rank == 0:
+        _flush_c_stdio()
         print(json.dumps({
             "metric": "collectives of one train step, alone on the communication stream", "unit": "ms",
             "value": tot["all_gather"]["ms"] + tot["reduce_scatter"]["ms"], "higher_is_better": False, "n_gpus": world,
